@@ -1,0 +1,194 @@
+/* include/slslam_hip.h — C ABI of the MI355X-native SLSLAM optimisation back-end.
+ *
+ * Drop-in boundary for the reference's two optimisation hot paths.  The reference is C++ and has
+ * no FFI of its own; what a maintainer binds is the triple
+ *     XProblem::build(ceres::Problem*)  /  XProblem::set_options(ceres::Solver::Options*)  /
+ *     ceres::Solve(options, &problem, &summary)
+ * at the three call sites reference src/slam.cpp:643-663 (motion_only_ba), :924-952
+ * (bundle_adjustment) and :1283-1293 (pose_optimization).  Every entry point below cites the
+ * reference interface it replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The host-side C++ mirror of the reference classes (slslam_amd/host/lba_problem.h,
+ * po_problem.h and the minimal ceres facade) marshals into these calls; see INTEGRATION.md.
+ *
+ * All solves run on the GPU in hand-written HIP kernels (slslam_amd/csrc).  There is no CPU
+ * fallback: without a usable HIP device every compute entry point returns SLSLAM_ERR_NO_DEVICE.
+ */
+#ifndef SLSLAM_HIP_H_
+#define SLSLAM_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes */
+enum {
+  SLSLAM_OK = 0,
+  SLSLAM_ERR_INVALID_ARGUMENT = 1,
+  SLSLAM_ERR_NO_DEVICE = 2,        /* no HIP device / HIP runtime error */
+  SLSLAM_ERR_HIP = 3,
+  SLSLAM_ERR_UNSUPPORTED = 4,      /* problem shape outside what the kernels support */
+  SLSLAM_ERR_STATE = 5             /* call sequence violated (e.g. solve before finalize) */
+};
+
+/* Termination of one solve: mirrors ceres::Solver::Summary::termination_type of Ceres 1.7.
+ * The reference never inspects it (src/slam.cpp:663,944,1293); reported for diagnostics. */
+enum {
+  SLSLAM_NO_CONVERGENCE = 0,       /* max_num_iterations reached */
+  SLSLAM_GRADIENT_TOLERANCE = 1,
+  SLSLAM_FUNCTION_TOLERANCE = 2,
+  SLSLAM_PARAMETER_TOLERANCE = 3,
+  SLSLAM_NUMERICAL_FAILURE = 4,    /* parameters are left untouched, as Ceres does */
+  SLSLAM_MIN_RADIUS = 5
+};
+
+/* ------------------------------------------------------------------ options
+ * Replaces: ceres::Solver::Options as filled by LBAProblem::set_options
+ * (reference src/lba_problem.cpp:95-132) and POProblem::set_options (src/po_problem.cpp:67-77),
+ * plus the constants hard-coded in the hot path (baseline 0.12: src/lba_problem.h:101;
+ * Huber scale 1/406.05: src/lba_problem.cpp:78) and the gflags read by it (FLAGS_robust,
+ * src/lba_problem.cpp:35; FLAGS_max_num_iter, src/slam.cpp:647,928).
+ * Trust-region constants are the Ceres 1.7 defaults the reference leaves untouched. */
+typedef struct slslam_solver_options {
+  int    max_num_iterations;            /* lba_param_t.num_iterations / POProblem n_iter        */
+  double huber_delta;                   /* 1/406.05 when FLAGS_robust, <= 0 disables the loss   */
+  double baseline;                      /* stereo baseline, 0.12                                */
+  double initial_trust_region_radius;   /* 1e4   */
+  double max_trust_region_radius;       /* 1e16  */
+  double min_trust_region_radius;       /* 1e-32 */
+  double min_relative_decrease;         /* 1e-3  */
+  double min_lm_diagonal;               /* 1e-6  */
+  double max_lm_diagonal;               /* 1e32  */
+  int    max_num_consecutive_invalid_steps; /* 5 */
+  double function_tolerance;            /* 1e-6  */
+  double gradient_tolerance;            /* 1e-10 (relative to the initial max-norm, Ceres 1.7)  */
+  double parameter_tolerance;           /* 1e-8  */
+  int    jacobi_scaling;                /* 1     */
+  int    use_graph;                     /* 1: replay the LM iteration as a captured hipGraph    */
+  int    chunks_per_window;             /* 0 = auto; waves cooperating on one window            */
+} slslam_solver_options;
+
+/* Fills every field with the configuration the reference runs (robust loss on, 10 iterations). */
+void slslam_default_options(slslam_solver_options* opt);
+
+/* ------------------------------------------------------------------ summary
+ * Replaces: the four ceres::Solver::Summary fields the reference reads back
+ * (reference src/slam.cpp:949-952) + diagnostics. */
+typedef struct slslam_summary {
+  int    num_successful_steps;
+  int    num_unsuccessful_steps;
+  double initial_cost;
+  double final_cost;
+  double fixed_cost;
+  int    termination_type;
+  int    num_free_parameters;
+  int    num_residual_blocks;
+} slslam_summary;
+
+/* One record per LM iteration (index 0 = initial evaluation), for parity tests. */
+typedef struct slslam_iteration {
+  int    iteration;
+  int    step_is_valid;
+  int    step_is_successful;
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+  double model_cost_change;
+} slslam_iteration;
+
+/* ------------------------------------------------------------------ LBA window
+ * Replaces: ceres::lba_param_t (reference src/lba_problem.h:123-130) + the five arrays handed
+ * to LBAProblem through set_line_index / set_camera_index / set_fixed_index / set_observations /
+ * set_parameters (src/lba_problem.h:153-157); layouts as documented at src/lba_problem.h:188-196
+ * and built at src/slam.cpp:899-920.  All pointers are HOST pointers owned by the caller. */
+typedef struct slslam_lba_window {
+  int num_cameras;                /* lba_param_t.num_cameras      */
+  int num_lines;                  /* lba_param_t.num_lines        */
+  int num_observations;           /* lba_param_t.num_observations */
+  const int*    camera_index;     /* [M]                          */
+  const int*    line_index;       /* [M]                          */
+  const int*    fixed_index;      /* [2M]: [2i] camera constant, [2i+1] line constant */
+  const double* observations;     /* [8M]: x0 y0 x1 y1 (camera 0), x2 y2 x3 y3 (camera 1) */
+  double*       parameters;       /* [6C + 4L] in/out: cameras (w,t) then lines (a,b,g,t) */
+} slslam_lba_window;
+
+/* Replaces: LBAProblem::build + LBAProblem::set_options + ceres::Solve for ONE window
+ * (reference src/slam.cpp:924-944 and :643-663).  Synchronous; parameters solved in place.
+ * trace may be NULL; at most trace_cap records are written and *trace_len gets the count. */
+int slslam_lba_solve(const slslam_lba_window* window, const slslam_solver_options* opt,
+                     slslam_summary* summary, slslam_iteration* trace, int trace_cap, int* trace_len);
+
+/* ---- batched form: many independent windows resident in HBM, solved in lock-step.
+ * This is the throughput path (independent sliding windows / sequence shards);
+ * each window goes through exactly the per-window algorithm of slslam_lba_solve. */
+typedef struct slslam_lba_batch slslam_lba_batch;
+
+/* device < 0 selects the current HIP device. */
+int  slslam_lba_batch_create(int device, slslam_lba_batch** out);
+void slslam_lba_batch_destroy(slslam_lba_batch* b);
+/* Replaces LBAProblem::build for one more window: validates, copies and reorders the arrays on
+ * the host (observations grouped by line).  Returns the window's index in *index. */
+int  slslam_lba_batch_add(slslam_lba_batch* b, const slslam_lba_window* window, int* index);
+/* Uploads every added window to HBM; no windows can be added afterwards. */
+int  slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solver_options* opt);
+/* Replaces ceres::Solve for all windows: enqueues the complete LM solve on `stream`
+ * (a hipStream_t passed as void*, NULL = default stream) and returns without synchronising. */
+int  slslam_lba_batch_solve(slslam_lba_batch* b, void* stream);
+/* Restores the initial parameters on the device (for repeated timing of the same inputs). */
+int  slslam_lba_batch_reset(slslam_lba_batch* b, void* stream);
+/* Blocks until the stream's work is done and copies parameters + summaries back to the host. */
+int  slslam_lba_batch_download(slslam_lba_batch* b, void* stream);
+/* After download: solved parameters of window `index` in the caller's original layout. */
+int  slslam_lba_batch_get_parameters(const slslam_lba_batch* b, int index, double* parameters);
+int  slslam_lba_batch_get_summary(const slslam_lba_batch* b, int index, slslam_summary* summary);
+int  slslam_lba_batch_get_trace(const slslam_lba_batch* b, int index, slslam_iteration* trace,
+                                int trace_cap, int* trace_len);
+/* Copies all solved parameters, windows concatenated in add order, into a DEVICE buffer
+ * (for a collective on the results without a host round trip). */
+int  slslam_lba_batch_export_device(slslam_lba_batch* b, double* device_out, void* stream);
+/* Problem-size accounting for throughput reporting: totals over the batch. */
+int  slslam_lba_batch_counts(const slslam_lba_batch* b, long long* num_windows, long long* num_cameras,
+                             long long* num_free_cameras, long long* num_lines, long long* num_observations);
+/* Device time (ms) spent in each kernel family during the last solve, measured with HIP events
+ * on the solve stream when profiling is enabled (disables graph replay for that solve).
+ * names: 0 linearise+schur, 1 reduced solve, 2 back-substitution, 3 line trig, 4 candidate cost,
+ * 5 LM update, 6 init.  launches[i] receives the number of launches. */
+int  slslam_lba_batch_set_profiling(slslam_lba_batch* b, int enable);
+int  slslam_lba_batch_kernel_times(const slslam_lba_batch* b, double ms[8], int launches[8]);
+
+/* Test hook: evaluate residuals / Jacobians (after the Huber corrector, before Jacobi scaling)
+ * of window `index` at its CURRENT device parameters, returned in the caller's observation order:
+ * residuals[4M], j_cam[24M] (row-major 4x6), j_line[16M] (row-major 4x4), cost[1]. */
+int  slslam_lba_batch_linearise(slslam_lba_batch* b, int index, double* residuals, double* j_cam,
+                                double* j_line, double* cost);
+
+/* ------------------------------------------------------------------ pose graph
+ * Replaces: POProblem(size, n_iter) + set_pose_index_1/2 + set_constraints + set_parameters
+ * (reference src/po_problem.h:112-130) and the arrays built at src/slam.cpp:1262-1280. */
+typedef struct slslam_po_graph {
+  int num_poses;                  /* kfs.size()                                        */
+  int num_edges;                  /* POProblem::num_size()                             */
+  const int*    pose_index_1;     /* [E]                                               */
+  const int*    pose_index_2;     /* [E]                                               */
+  const double* constraints;      /* [6E]: (w,t) of C = T_{n2<-n1}                     */
+  double*       parameters;       /* [6N] in/out: (w,t) per pose; pose_index_1[0] is held constant */
+} slslam_po_graph;
+
+/* Replaces: POProblem::build + POProblem::set_options + ceres::Solve
+ * (reference src/slam.cpp:1283-1293).  Synchronous; parameters solved in place.
+ * opt->huber_delta and opt->baseline are ignored (no loss function: src/po_problem.cpp:27,55). */
+int slslam_po_solve(const slslam_po_graph* graph, const slslam_solver_options* opt,
+                    slslam_summary* summary, slslam_iteration* trace, int trace_cap, int* trace_len);
+
+/* ------------------------------------------------------------------ misc */
+int         slslam_device_count(void);          /* 0 when no HIP device is usable */
+const char* slslam_version(void);
+const char* slslam_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLSLAM_HIP_H_ */

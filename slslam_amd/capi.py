@@ -1,0 +1,287 @@
+"""ctypes binding of the C ABI in include/slslam_hip.h (libslslam_hip.so, built in-tree).
+
+The Python layer is plumbing for tests, benches and multi-GPU fan-out; the product is the HIP
+library.  There is no CPU fallback here: if the library is missing or no HIP device is usable
+the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libslslam_hip.so")
+
+OK = 0
+STATUS = {0: "ok", 1: "invalid argument", 2: "no usable HIP device", 3: "HIP runtime error",
+          4: "unsupported problem shape", 5: "invalid call sequence"}
+TERMINATION = {0: "NO_CONVERGENCE", 1: "GRADIENT_TOLERANCE", 2: "FUNCTION_TOLERANCE",
+               3: "PARAMETER_TOLERANCE", 4: "NUMERICAL_FAILURE", 5: "MIN_RADIUS"}
+KERNEL_FAMILIES = ["linearise_schur", "reduced_solve", "backsub", "line_trig", "candidate_cost",
+                   "lm_update", "init_linearise", "unused"]
+
+
+class SlslamError(RuntimeError):
+    def __init__(self, status, where):
+        super().__init__("%s: %s (status %d)" % (where, STATUS.get(status, "?"), status))
+        self.status = status
+
+
+class SolverOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("huber_delta", C.c_double), ("baseline", C.c_double),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("max_num_consecutive_invalid_steps", C.c_int), ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("jacobi_scaling", C.c_int), ("use_graph", C.c_int), ("chunks_per_window", C.c_int)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("num_successful_steps", C.c_int), ("num_unsuccessful_steps", C.c_int),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double), ("fixed_cost", C.c_double),
+                ("termination_type", C.c_int), ("num_free_parameters", C.c_int),
+                ("num_residual_blocks", C.c_int)]
+
+
+class Iteration(C.Structure):
+    _fields_ = [("iteration", C.c_int), ("step_is_valid", C.c_int), ("step_is_successful", C.c_int),
+                ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double),
+                ("step_norm", C.c_double), ("relative_decrease", C.c_double),
+                ("trust_region_radius", C.c_double), ("model_cost_change", C.c_double)]
+
+
+class LBAWindow(C.Structure):
+    _fields_ = [("num_cameras", C.c_int), ("num_lines", C.c_int), ("num_observations", C.c_int),
+                ("camera_index", C.POINTER(C.c_int)), ("line_index", C.POINTER(C.c_int)),
+                ("fixed_index", C.POINTER(C.c_int)), ("observations", C.POINTER(C.c_double)),
+                ("parameters", C.POINTER(C.c_double))]
+
+
+class POGraph(C.Structure):
+    _fields_ = [("num_poses", C.c_int), ("num_edges", C.c_int),
+                ("pose_index_1", C.POINTER(C.c_int)), ("pose_index_2", C.POINTER(C.c_int)),
+                ("constraints", C.POINTER(C.c_double)), ("parameters", C.POINTER(C.c_double))]
+
+
+# every symbol include/slslam_hip.h declares (checked by the CPU test-suite)
+EXPORTS = [
+    "slslam_default_options", "slslam_lba_solve", "slslam_lba_batch_create", "slslam_lba_batch_destroy",
+    "slslam_lba_batch_add", "slslam_lba_batch_finalize", "slslam_lba_batch_solve", "slslam_lba_batch_reset",
+    "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
+    "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts",
+    "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
+    "slslam_po_solve", "slslam_device_count", "slslam_version", "slslam_status_string",
+]
+
+_lib = None
+
+
+def lib():
+    """Load the in-tree HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlslamError(2, "libslslam_hip.so not built (run __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    L.slslam_default_options.argtypes = [C.POINTER(SolverOptions)]
+    L.slslam_default_options.restype = None
+    L.slslam_lba_solve.argtypes = [C.POINTER(LBAWindow), C.POINTER(SolverOptions), C.POINTER(Summary),
+                                   C.POINTER(Iteration), C.c_int, ip]
+    L.slslam_lba_batch_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.slslam_lba_batch_destroy.argtypes = [vp]
+    L.slslam_lba_batch_destroy.restype = None
+    L.slslam_lba_batch_add.argtypes = [vp, C.POINTER(LBAWindow), ip]
+    L.slslam_lba_batch_finalize.argtypes = [vp, C.POINTER(SolverOptions)]
+    L.slslam_lba_batch_solve.argtypes = [vp, vp]
+    L.slslam_lba_batch_reset.argtypes = [vp, vp]
+    L.slslam_lba_batch_download.argtypes = [vp, vp]
+    L.slslam_lba_batch_get_parameters.argtypes = [vp, C.c_int, dp]
+    L.slslam_lba_batch_get_summary.argtypes = [vp, C.c_int, C.POINTER(Summary)]
+    L.slslam_lba_batch_get_trace.argtypes = [vp, C.c_int, C.POINTER(Iteration), C.c_int, ip]
+    L.slslam_lba_batch_export_device.argtypes = [vp, vp, vp]
+    L.slslam_lba_batch_counts.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 5
+    L.slslam_lba_batch_set_profiling.argtypes = [vp, C.c_int]
+    L.slslam_lba_batch_kernel_times.argtypes = [vp, dp, ip]
+    L.slslam_lba_batch_linearise.argtypes = [vp, C.c_int, dp, dp, dp, dp]
+    L.slslam_po_solve.argtypes = [C.POINTER(POGraph), C.POINTER(SolverOptions), C.POINTER(Summary),
+                                  C.POINTER(Iteration), C.c_int, ip]
+    L.slslam_device_count.restype = C.c_int
+    L.slslam_version.restype = C.c_char_p
+    L.slslam_status_string.argtypes = [C.c_int]
+    L.slslam_status_string.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _check(status, where):
+    if status != OK:
+        raise SlslamError(status, where)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def default_options(**kw):
+    o = SolverOptions()
+    lib().slslam_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError("unknown solver option %r" % k)
+        setattr(o, k, v)
+    return o
+
+
+def device_count():
+    return lib().slslam_device_count()
+
+
+def _summary_dict(s):
+    d = {k: getattr(s, k) for k, _ in Summary._fields_}
+    d["termination"] = TERMINATION.get(d["termination_type"], "?")
+    return d
+
+
+def _trace_list(tr, n):
+    return [{k: getattr(tr[i], k) for k, _ in Iteration._fields_} for i in range(n)]
+
+
+class _WindowArrays:
+    """Keeps the numpy buffers a slslam_lba_window points to alive."""
+
+    def __init__(self, w, params=None):
+        self.cam = np.ascontiguousarray(w["camera_index"], dtype=np.int32)
+        self.line = np.ascontiguousarray(w["line_index"], dtype=np.int32)
+        self.fixed = np.ascontiguousarray(w["fixed_index"], dtype=np.int32).reshape(-1)
+        self.obs = np.ascontiguousarray(w["observations"], dtype=np.float64).reshape(-1)
+        self.params = np.array(w["parameters"] if params is None else params, dtype=np.float64).reshape(-1).copy()
+        m = len(self.cam)
+        if len(self.line) != m or len(self.fixed) != 2 * m or len(self.obs) != 8 * m:
+            raise ValueError("inconsistent window arrays")
+        if len(self.params) != 6 * int(w["num_cameras"]) + 4 * int(w["num_lines"]):
+            raise ValueError("parameter vector has the wrong length")
+        self.c = LBAWindow(int(w["num_cameras"]), int(w["num_lines"]), m, _ip(self.cam), _ip(self.line),
+                           _ip(self.fixed), _dp(self.obs), _dp(self.params))
+
+
+def lba_solve(w, params=None, trace_cap=64, **opt):
+    """One window through slslam_lba_solve (LBAProblem::build + set_options + ceres::Solve).
+    Returns (solved parameters, summary dict, trace list)."""
+    arr = _WindowArrays(w, params)
+    o = default_options(**opt)
+    s = Summary()
+    tr = (Iteration * trace_cap)()
+    n = C.c_int(0)
+    _check(lib().slslam_lba_solve(C.byref(arr.c), C.byref(o), C.byref(s), tr, trace_cap, C.byref(n)), "slslam_lba_solve")
+    return arr.params, _summary_dict(s), _trace_list(tr, min(n.value, trace_cap))
+
+
+class LBABatch:
+    """Many independent windows resident in HBM, solved in lock-step (slslam_lba_batch_*)."""
+
+    def __init__(self, device=-1):
+        self._h = C.c_void_p()
+        _check(lib().slslam_lba_batch_create(int(device), C.byref(self._h)), "slslam_lba_batch_create")
+        self.sizes = []          # (num_cameras, num_lines) per window
+        self.finalized = False
+
+    def close(self):
+        if self._h:
+            lib().slslam_lba_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add(self, w, params=None):
+        arr = _WindowArrays(w, params)
+        idx = C.c_int(-1)
+        _check(lib().slslam_lba_batch_add(self._h, C.byref(arr.c), C.byref(idx)), "slslam_lba_batch_add")
+        self.sizes.append((int(w["num_cameras"]), int(w["num_lines"])))
+        return idx.value
+
+    def finalize(self, **opt):
+        o = default_options(**opt)
+        _check(lib().slslam_lba_batch_finalize(self._h, C.byref(o)), "slslam_lba_batch_finalize")
+        self.finalized = True
+        self.options = o
+
+    def solve(self, stream=None):
+        _check(lib().slslam_lba_batch_solve(self._h, C.c_void_p(stream or 0)), "slslam_lba_batch_solve")
+
+    def reset(self, stream=None):
+        _check(lib().slslam_lba_batch_reset(self._h, C.c_void_p(stream or 0)), "slslam_lba_batch_reset")
+
+    def download(self, stream=None):
+        _check(lib().slslam_lba_batch_download(self._h, C.c_void_p(stream or 0)), "slslam_lba_batch_download")
+
+    def export_device(self, device_ptr, stream=None):
+        _check(lib().slslam_lba_batch_export_device(self._h, C.c_void_p(device_ptr), C.c_void_p(stream or 0)),
+               "slslam_lba_batch_export_device")
+
+    def parameters(self, i):
+        c, l = self.sizes[i]
+        out = np.empty(6 * c + 4 * l)
+        _check(lib().slslam_lba_batch_get_parameters(self._h, i, _dp(out)), "slslam_lba_batch_get_parameters")
+        return out
+
+    def summary(self, i):
+        s = Summary()
+        _check(lib().slslam_lba_batch_get_summary(self._h, i, C.byref(s)), "slslam_lba_batch_get_summary")
+        return _summary_dict(s)
+
+    def trace(self, i, cap=64):
+        tr = (Iteration * cap)()
+        n = C.c_int(0)
+        _check(lib().slslam_lba_batch_get_trace(self._h, i, tr, cap, C.byref(n)), "slslam_lba_batch_get_trace")
+        return _trace_list(tr, min(n.value, cap))
+
+    def counts(self):
+        v = [C.c_longlong(0) for _ in range(5)]
+        _check(lib().slslam_lba_batch_counts(self._h, *[C.byref(x) for x in v]), "slslam_lba_batch_counts")
+        return dict(zip(["windows", "cameras", "free_cameras", "lines", "observations"], [x.value for x in v]))
+
+    def total_parameters(self):
+        return sum(6 * c + 4 * l for c, l in self.sizes)
+
+    def set_profiling(self, enable):
+        _check(lib().slslam_lba_batch_set_profiling(self._h, int(bool(enable))), "slslam_lba_batch_set_profiling")
+
+    def kernel_times(self):
+        ms = np.zeros(8)
+        n = np.zeros(8, dtype=np.int32)
+        _check(lib().slslam_lba_batch_kernel_times(self._h, _dp(ms), _ip(n)), "slslam_lba_batch_kernel_times")
+        return {KERNEL_FAMILIES[i]: (float(ms[i]), int(n[i])) for i in range(8)}
+
+    def linearise(self, i, num_observations):
+        m = int(num_observations)
+        r, jc, jl, c = np.zeros((m, 4)), np.zeros((m, 4, 6)), np.zeros((m, 4, 4)), np.zeros(1)
+        _check(lib().slslam_lba_batch_linearise(self._h, i, _dp(r), _dp(jc), _dp(jl), _dp(c)), "slslam_lba_batch_linearise")
+        return float(c[0]), r, jc, jl
+
+
+def po_solve(g, params=None, trace_cap=64, **opt):
+    """One pose graph through slslam_po_solve (POProblem::build + set_options + ceres::Solve)."""
+    i1 = np.ascontiguousarray(g["pose_index_1"], dtype=np.int32)
+    i2 = np.ascontiguousarray(g["pose_index_2"], dtype=np.int32)
+    cons = np.ascontiguousarray(g["constraints"], dtype=np.float64).reshape(-1)
+    x = np.array(g["parameters"] if params is None else params, dtype=np.float64).reshape(-1).copy()
+    if len(i2) != len(i1) or len(cons) != 6 * len(i1) or len(x) != 6 * int(g["num_poses"]):
+        raise ValueError("inconsistent pose-graph arrays")
+    cg = POGraph(int(g["num_poses"]), len(i1), _ip(i1), _ip(i2), _dp(cons), _dp(x))
+    o = default_options(**opt)
+    s = Summary()
+    tr = (Iteration * trace_cap)()
+    n = C.c_int(0)
+    _check(lib().slslam_po_solve(C.byref(cg), C.byref(o), C.byref(s), tr, trace_cap, C.byref(n)), "slslam_po_solve")
+    return x, _summary_dict(s), _trace_list(tr, min(n.value, trace_cap))

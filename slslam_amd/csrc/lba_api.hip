@@ -1,0 +1,590 @@
+// slslam_amd/csrc/lba_api.hip — C ABI of the LBA path (include/slslam_hip.h): host orchestration
+// of the kernels in lba_kernels.h.  No CPU fallback: without a HIP device every compute entry
+// point fails with SLSLAM_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/slslam_hip.h"
+#include "lba_kernels.h"
+#include "lba_pack.h"
+
+using namespace slslam;
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      std::fprintf(stderr, "slslam: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? SLSLAM_ERR_NO_DEVICE : SLSLAM_ERR_HIP; \
+    }                                                                                   \
+  } while (0)
+
+extern "C" void slslam_default_options(slslam_solver_options* o) {
+  if (!o) return;
+  o->max_num_iterations = 10;                 // FLAGS_max_num_iter, reference src/main.cpp:23
+  o->huber_delta = 1.0 / 406.05;              // reference src/lba_problem.cpp:78-80, FLAGS_robust = true
+  o->baseline = 0.12;                         // reference src/lba_problem.h:101
+  o->initial_trust_region_radius = 1e4;       // Ceres 1.7 defaults below
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->jacobi_scaling = 1;
+  o->use_graph = 1;
+  o->chunks_per_window = 0;
+}
+
+extern "C" int slslam_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" const char* slslam_version(void) { return "slslam_amd 0.1 (gfx950)"; }
+
+extern "C" const char* slslam_status_string(int s) {
+  switch (s) {
+    case SLSLAM_OK: return "ok";
+    case SLSLAM_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case SLSLAM_ERR_NO_DEVICE: return "no usable HIP device";
+    case SLSLAM_ERR_HIP: return "HIP runtime error";
+    case SLSLAM_ERR_UNSUPPORTED: return "problem shape not supported by the kernels";
+    case SLSLAM_ERR_STATE: return "invalid call sequence";
+    default: return "unknown status";
+  }
+}
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    n = count;
+    if (count == 0) { p = nullptr; return SLSLAM_OK; }
+    HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+    return SLSLAM_OK;
+  }
+  int upload(const std::vector<T>& h) {
+    int rc = alloc(h.size());
+    if (rc) return rc;
+    if (!h.empty()) HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SLSLAM_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+Policy make_policy(const slslam_solver_options& o) {
+  Policy p;
+  p.huber_delta = o.huber_delta; p.baseline = o.baseline;
+  p.initial_radius = o.initial_trust_region_radius; p.max_radius = o.max_trust_region_radius;
+  p.min_radius = o.min_trust_region_radius; p.min_relative_decrease = o.min_relative_decrease;
+  p.min_lm_diagonal = o.min_lm_diagonal; p.max_lm_diagonal = o.max_lm_diagonal;
+  p.function_tolerance = o.function_tolerance; p.gradient_tolerance = o.gradient_tolerance;
+  p.parameter_tolerance = o.parameter_tolerance;
+  p.max_num_iterations = o.max_num_iterations; p.max_invalid = o.max_num_consecutive_invalid_steps;
+  p.jacobi_scaling = o.jacobi_scaling; p.pad = 0;
+  return p;
+}
+
+enum { FAM_LIN = 0, FAM_SOLVE = 1, FAM_BACKSUB = 2, FAM_TRIG = 3, FAM_COST = 4, FAM_UPDATE = 5, FAM_INIT = 6, FAM_N = 8 };
+
+}  // namespace
+
+struct slslam_lba_batch {
+  int device = 0;
+  bool finalized = false;
+  std::vector<PackedWindow> wins;
+  slslam_solver_options opt;
+  Policy pol;
+  // host mirrors
+  std::vector<WinDesc> h_wins;
+  std::vector<long long> h_param_off;     // per window offset into the exported parameter vector
+  long long total_params = 0;
+  std::vector<LMState> h_state0, h_state;
+  std::vector<IterRec> h_trace;
+  std::vector<double> h_params;
+  std::vector<int> h_ob_orig_off;          // per window offset into d_ob_orig
+  bool downloaded = false;
+  // device
+  DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<uint8_t> d_items;
+  DevBuf<double> d_cam_x, d_cam_x0, d_cam_scale; DevBuf<int> d_cam_cf, d_cam_win;
+  DevBuf<double> d_line_x, d_line_x0, d_line_scale; DevBuf<int> d_line_ptr, d_line_flags, d_line_win, d_line_orig;
+  DevBuf<double> d_ob; DevBuf<int> d_ob_cam, d_ob_orig;
+  DevBuf<double> d_slab, d_bs_part, d_cost_part, d_ysys, d_params_out;
+  DevBuf<LMState> d_state; DevBuf<IterRec> d_trace; DevBuf<long long> d_param_off;
+  BatchPtrs ptrs;
+  int nchunk = 0, nline = 0, ncam = 0;
+  long long nobs = 0;
+  size_t lds_lin = 0, lds_solve = 0, lds_bs = 0, lds_cost = 0;
+  // graph
+  hipGraphExec_t graph_exec = nullptr;
+  hipStream_t capture_stream = nullptr;
+  // profiling
+  bool profiling = false;
+  double fam_ms[FAM_N] = { 0 };
+  int fam_launches[FAM_N] = { 0 };
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<std::pair<int, int>> ev_used;   // (family, index of start event); stop = start + 1
+
+  void release() {
+    d_wins.release(); d_tiles.release(); d_chunks.release(); d_items.release();
+    d_cam_x.release(); d_cam_x0.release(); d_cam_scale.release(); d_cam_cf.release(); d_cam_win.release();
+    d_line_x.release(); d_line_x0.release(); d_line_scale.release(); d_line_ptr.release(); d_line_flags.release();
+    d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release();
+    d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
+    d_state.release(); d_trace.release(); d_param_off.release();
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (capture_stream) { (void)hipStreamDestroy(capture_stream); capture_stream = nullptr; }
+    for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    ev_pool.clear();
+  }
+};
+
+extern "C" int slslam_lba_batch_create(int device, slslam_lba_batch** out) {
+  if (!out) return SLSLAM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SLSLAM_ERR_NO_DEVICE;
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return SLSLAM_ERR_NO_DEVICE; }
+  if (device >= ndev) return SLSLAM_ERR_INVALID_ARGUMENT;
+  slslam_lba_batch* b = new (std::nothrow) slslam_lba_batch();
+  if (!b) return SLSLAM_ERR_HIP;
+  b->device = device;
+  slslam_default_options(&b->opt);
+  *out = b;
+  return SLSLAM_OK;
+}
+
+extern "C" void slslam_lba_batch_destroy(slslam_lba_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  b->release();
+  delete b;
+}
+
+extern "C" int slslam_lba_batch_add(slslam_lba_batch* b, const slslam_lba_window* w, int* index) {
+  if (!b || !w) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (b->finalized) return SLSLAM_ERR_STATE;
+  PackedWindow pw;
+  const int rc = pack_window(w, &pw);
+  if (rc != SLSLAM_OK) return rc;
+  if (index) *index = (int)b->wins.size();
+  b->wins.push_back(std::move(pw));
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solver_options* opt) {
+  if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (b->finalized) return SLSLAM_ERR_STATE;
+  if (opt) b->opt = *opt;
+  if (b->opt.max_num_iterations < 0 || b->opt.max_num_iterations > kMaxTrace - 2) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!(b->opt.initial_trust_region_radius > 0.0) || !(b->opt.baseline == b->opt.baseline)) return SLSLAM_ERR_INVALID_ARGUMENT;
+  b->pol = make_policy(b->opt);
+  HIP_TRY(hipSetDevice(b->device));
+  const int B = (int)b->wins.size();
+
+  // ---- global layout
+  std::vector<Tile> tiles; std::vector<Chunk> chunks; std::vector<uint8_t> items;
+  std::vector<double> cam_x, line_x, ob; std::vector<int> cam_cf, cam_win, line_ptr, line_flags, line_win, line_orig, ob_cam, ob_orig;
+  long long ncam = 0, nline = 0, nobs = 0, sys = 0, slab = 0, param_off = 0;
+  long long total_tiles = 0;
+  for (const PackedWindow& P : b->wins) total_tiles += (long long)P.tiles.size();
+  int maxC = 1, maxn = 0;
+  b->h_wins.resize(B); b->h_param_off.resize(B); b->h_ob_orig_off.resize(B);
+  for (const PackedWindow& P : b->wins) nobs += P.M;
+  b->nobs = nobs;
+  ob.resize((size_t)8 * (size_t)nobs);
+  long long obs_cursor = 0;
+  for (int wi = 0; wi < B; ++wi) {
+    const PackedWindow& P = b->wins[wi];
+    WinDesc& wd = b->h_wins[wi];
+    std::memset(&wd, 0, sizeof(wd));
+    wd.C = P.C; wd.Cf = P.Cf; wd.L = P.L; wd.M = P.M;
+    wd.cam_off = (int)ncam; wd.line_off = (int)nline; wd.obs_off = (int)obs_cursor;
+    wd.tile_off = (int)tiles.size(); wd.ntiles = (int)P.tiles.size();
+    wd.n = 6 * P.Cf; wd.sys_off = (int)sys; wd.nfree_params = P.nfree_params; wd.nkept = P.nkept;
+    maxC = std::max(maxC, P.C); maxn = std::max(maxn, wd.n);
+    b->h_param_off[wi] = param_off; param_off += 6LL * P.C + 4LL * P.L;
+    b->h_ob_orig_off[wi] = (int)obs_cursor;
+    // chunks: runs of tiles handled by one wave.  Few long chunks keep the per-chunk partial of
+    // the reduced system (a slab in HBM) small against the observation stream; many short chunks
+    // fill the chip when the batch is small.
+    int per_chunk;
+    if (b->opt.chunks_per_window > 0) per_chunk = std::max(1, (wd.ntiles + b->opt.chunks_per_window - 1) / b->opt.chunks_per_window);
+    else per_chunk = (int)std::min<long long>(32, std::max<long long>(4, total_tiles / 2048));
+    const std::vector<int> bounds = chunk_boundaries(wd.ntiles, per_chunk);
+    wd.chunk_off = (int)chunks.size(); wd.nchunks = (int)bounds.size() - 1;
+    const long long slab_stride = (long long)wd.n * (wd.n + 1) / 2 + 3LL * wd.n + kSlabScalars;
+    for (int c = 0; c < wd.nchunks; ++c) {
+      Chunk ck; ck.win = wi; ck.tile_begin = wd.tile_off + bounds[c]; ck.tile_end = wd.tile_off + bounds[c + 1];
+      ck.slab_off = (int)slab; slab += slab_stride;
+      chunks.push_back(ck);
+    }
+    if (slab > 0x7fffffffLL) return SLSLAM_ERR_UNSUPPORTED;
+    const int item_base = (int)(items.size() / 2);
+    for (Tile t : P.tiles) { t.line_begin += (int)nline; t.item_off += item_base; tiles.push_back(t); }
+    items.insert(items.end(), P.items.begin(), P.items.end());
+    for (int c = 0; c < P.C; ++c) {
+      for (int buf = 0; buf < 2; ++buf) for (int a = 0; a < 6; ++a) cam_x.push_back(P.cam_x[6 * (size_t)c + a]);
+      cam_cf.push_back(P.cam_cf[c]); cam_win.push_back(wi);
+    }
+    for (int s = 0; s < P.L; ++s) {
+      for (int buf = 0; buf < 2; ++buf) {
+        for (int a = 0; a < 4; ++a) line_x.push_back(P.line_u[4 * (size_t)s + a]);
+        for (int a = 4; a < kLineRec; ++a) line_x.push_back(0.0);
+      }
+      line_ptr.push_back((int)obs_cursor + P.line_ptr[s]);
+      line_flags.push_back(P.line_flags[s]); line_win.push_back(wi); line_orig.push_back(P.line_order[s]);
+    }
+    for (int o = 0; o < P.M; ++o) {
+      ob_cam.push_back(P.ob_cam[o]); ob_orig.push_back(P.ob_orig[o]);
+      for (int q = 0; q < 8; ++q) ob[(size_t)q * (size_t)nobs + (size_t)(obs_cursor + o)] = P.ob[(size_t)q * P.M + o];
+    }
+    ncam += P.C; nline += P.L; obs_cursor += P.M; sys += wd.n;
+  }
+  line_ptr.push_back((int)obs_cursor);
+  if (nobs > 0x7fffffffLL) return SLSLAM_ERR_UNSUPPORTED;
+  b->total_params = param_off; b->nchunk = (int)chunks.size(); b->nline = (int)nline; b->ncam = (int)ncam;
+
+  // ---- initial LM state (Ceres: LevenbergMarquardtStrategy ctor)
+  b->h_state0.assign(B, LMState());
+  for (int wi = 0; wi < B; ++wi) {
+    LMState& s = b->h_state0[wi];
+    std::memset(&s, 0, sizeof(s));
+    s.radius = b->pol.initial_radius; s.decrease_factor = 2.0; s.status = kRunning;
+  }
+
+  // ---- upload
+  int rc;
+  if ((rc = b->d_wins.upload(b->h_wins))) return rc;
+  if ((rc = b->d_tiles.upload(tiles))) return rc;
+  if ((rc = b->d_chunks.upload(chunks))) return rc;
+  if (items.empty()) items.push_back(0);
+  if ((rc = b->d_items.upload(items))) return rc;
+  if (cam_x.empty()) cam_x.assign(12, 0.0);
+  if ((rc = b->d_cam_x.upload(cam_x))) return rc;
+  if ((rc = b->d_cam_x0.upload(cam_x))) return rc;
+  if ((rc = b->d_cam_scale.alloc(std::max<size_t>(6, (size_t)6 * ncam)))) return rc;
+  if (cam_cf.empty()) { cam_cf.push_back(-1); cam_win.push_back(0); }
+  if ((rc = b->d_cam_cf.upload(cam_cf))) return rc;
+  if ((rc = b->d_cam_win.upload(cam_win))) return rc;
+  if (line_x.empty()) line_x.assign(2 * kLineRec, 0.0);
+  if ((rc = b->d_line_x.upload(line_x))) return rc;
+  if ((rc = b->d_line_x0.upload(line_x))) return rc;
+  if ((rc = b->d_line_scale.alloc(std::max<size_t>(4, (size_t)4 * nline)))) return rc;
+  if ((rc = b->d_line_ptr.upload(line_ptr))) return rc;
+  if (line_flags.empty()) { line_flags.push_back(1); line_win.push_back(0); line_orig.push_back(0); }
+  if ((rc = b->d_line_flags.upload(line_flags))) return rc;
+  if ((rc = b->d_line_win.upload(line_win))) return rc;
+  if ((rc = b->d_line_orig.upload(line_orig))) return rc;
+  if (ob.empty()) ob.assign(8, 0.0);
+  if ((rc = b->d_ob.upload(ob))) return rc;
+  if (ob_cam.empty()) { ob_cam.push_back(0); ob_orig.push_back(0); }
+  if ((rc = b->d_ob_cam.upload(ob_cam))) return rc;
+  if ((rc = b->d_ob_orig.upload(ob_orig))) return rc;
+  if ((rc = b->d_slab.alloc(std::max<size_t>(1, (size_t)slab)))) return rc;
+  if ((rc = b->d_bs_part.alloc(std::max<size_t>(1, (size_t)b->nchunk * kBsStride)))) return rc;
+  if ((rc = b->d_cost_part.alloc(std::max<size_t>(1, (size_t)b->nchunk)))) return rc;
+  if ((rc = b->d_ysys.alloc(std::max<size_t>(1, (size_t)sys)))) return rc;
+  if ((rc = b->d_params_out.alloc(std::max<size_t>(1, (size_t)param_off)))) return rc;
+  if ((rc = b->d_state.upload(b->h_state0))) return rc;
+  if ((rc = b->d_trace.alloc(std::max<size_t>(1, (size_t)B * kMaxTrace)))) return rc;
+  if ((rc = b->d_param_off.upload(b->h_param_off))) return rc;
+  HIP_TRY(hipMemset(b->d_trace.p, 0, b->d_trace.n * sizeof(IterRec)));
+  HIP_TRY(hipMemset(b->d_cam_scale.p, 0, b->d_cam_scale.n * sizeof(double)));
+  HIP_TRY(hipMemset(b->d_line_scale.p, 0, b->d_line_scale.n * sizeof(double)));
+
+  BatchPtrs& p = b->ptrs;
+  p.wins = b->d_wins.p; p.tiles = b->d_tiles.p; p.chunks = b->d_chunks.p; p.items = b->d_items.p;
+  p.cam_x = b->d_cam_x.p; p.cam_scale = b->d_cam_scale.p; p.cam_cf = b->d_cam_cf.p;
+  p.line_x = b->d_line_x.p; p.line_scale = b->d_line_scale.p; p.line_ptr = b->d_line_ptr.p;
+  p.line_flags = b->d_line_flags.p; p.line_win = b->d_line_win.p;
+  p.ob = b->d_ob.p; p.ob_cam = b->d_ob_cam.p; p.ob_stride = std::max<long long>(1, nobs);
+  p.slab = b->d_slab.p; p.bs_part = b->d_bs_part.p; p.cost_part = b->d_cost_part.p; p.ysys = b->d_ysys.p;
+  p.state = b->d_state.p; p.trace = b->d_trace.p;
+  p.nwin = B; p.nchunk = b->nchunk; p.nline = b->nline; p.ncam = b->ncam;
+
+  b->lds_lin = sizeof(double) * (size_t)lds_doubles_linearise(maxC, maxn);
+  b->lds_solve = sizeof(double) * (size_t)lds_doubles_solve(maxn);
+  b->lds_bs = sizeof(double) * (size_t)lds_doubles_backsub(maxC, maxn);
+  b->lds_cost = sizeof(double) * (size_t)lds_doubles_cost(maxC);
+  const size_t lds_max = std::max(std::max(b->lds_lin, b->lds_solve), std::max(b->lds_bs, b->lds_cost));
+  if (lds_max > 160 * 1024) return SLSLAM_ERR_UNSUPPORTED;
+  if (b->lds_lin > 48 * 1024) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
+  }
+  if (b->lds_solve > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
+  b->h_state.assign(B, LMState());
+  b->h_trace.assign((size_t)B * kMaxTrace, IterRec());
+  b->h_params.assign((size_t)param_off, 0.0);
+  b->finalized = true;
+  return SLSLAM_OK;
+}
+
+namespace {
+
+// Launch helper: optional event bracketing per kernel family.
+struct Launcher {
+  slslam_lba_batch* b;
+  hipStream_t s;
+  bool prof;
+  int begin(int fam) {
+    if (!prof) return SLSLAM_OK;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SLSLAM_ERR_HIP;
+    b->ev_pool.push_back(e0); b->ev_pool.push_back(e1);
+    b->ev_used.push_back({ fam, (int)b->ev_pool.size() - 2 });
+    if (hipEventRecord(e0, s) != hipSuccess) return SLSLAM_ERR_HIP;
+    return SLSLAM_OK;
+  }
+  int end() {
+    if (!prof) return SLSLAM_OK;
+    if (hipEventRecord(b->ev_pool.back(), s) != hipSuccess) return SLSLAM_ERR_HIP;
+    return SLSLAM_OK;
+  }
+};
+
+int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof) {
+  const BatchPtrs& p = b->ptrs;
+  const Policy& pol = b->pol;
+  const int B = p.nwin;
+  if (B == 0) return SLSLAM_OK;
+  Launcher L{ b, s, prof };
+  const dim3 blk64(64), blk256(256);
+  const dim3 g_chunk((unsigned)std::max(1, b->nchunk)), g_win((unsigned)B), g_line((unsigned)((b->nline + 255) / 256)),
+      g_upd((unsigned)((B + 63) / 64));
+  int rc;
+#define LAUNCH(fam, ...)                                   \
+  do {                                                     \
+    if ((rc = L.begin(fam))) return rc;                    \
+    __VA_ARGS__;                                           \
+    if ((rc = L.end())) return rc;                         \
+  } while (0)
+  if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 0));
+  if (b->nchunk > 0) LAUNCH(FAM_INIT, hipLaunchKernelGGL(k_linearise_schur<true>, g_chunk, blk64, b->lds_lin, s, p, pol));
+  LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol, 0));
+  for (int it = 0; it < pol.max_num_iterations; ++it) {
+    if (b->nchunk > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_linearise_schur<false>, g_chunk, blk64, b->lds_lin, s, p, pol));
+    LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve, g_win, blk64, b->lds_solve, s, p, pol));
+    if (b->nchunk > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub, g_chunk, blk64, b->lds_bs, s, p, pol));
+    if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 1));
+    if (b->nchunk > 0) LAUNCH(FAM_COST, hipLaunchKernelGGL(k_candidate_cost, g_chunk, blk64, b->lds_cost, s, p, pol));
+    LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol, 1));
+  }
+#undef LAUNCH
+  HIP_TRY(hipGetLastError());
+  return SLSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" int slslam_lba_batch_solve(slslam_lba_batch* b, void* stream) {
+  if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b->finalized) return SLSLAM_ERR_STATE;
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  b->downloaded = false;
+  if (b->profiling) {
+    for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
+    b->ev_pool.clear(); b->ev_used.clear();
+    return enqueue_solve(b, s, true);
+  }
+  if (!b->opt.use_graph) return enqueue_solve(b, s, false);
+  if (!b->graph_exec) {
+    // capture the whole solve (3 + 6 * max_iter launches) once; replay costs one host call
+    HIP_TRY(hipStreamCreateWithFlags(&b->capture_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamBeginCapture(b->capture_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_solve(b, b->capture_stream, false);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(b->capture_stream, &g);
+    if (rc != SLSLAM_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    HIP_TRY(e);
+    const hipError_t ei = hipGraphInstantiate(&b->graph_exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIP_TRY(ei);
+  }
+  HIP_TRY(hipGraphLaunch(b->graph_exec, s));
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_reset(slslam_lba_batch* b, void* stream) {
+  if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b->finalized) return SLSLAM_ERR_STATE;
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(b->d_cam_x.p, b->d_cam_x0.p, b->d_cam_x.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(b->d_line_x.p, b->d_line_x0.p, b->d_line_x.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(b->d_state.p, b->h_state0.data(), b->h_state0.size() * sizeof(LMState), hipMemcpyHostToDevice, s));
+  b->downloaded = false;
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_export_device(slslam_lba_batch* b, double* device_out, void* stream) {
+  if (!b || !device_out) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b->finalized) return SLSLAM_ERR_STATE;
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int total = b->ncam + b->nline;
+  if (total > 0)
+    hipLaunchKernelGGL(k_export, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b->ptrs,
+                       b->d_param_off.p, b->d_cam_win.p, b->d_line_orig.p, device_out);
+  HIP_TRY(hipGetLastError());
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_download(slslam_lba_batch* b, void* stream) {
+  if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b->finalized) return SLSLAM_ERR_STATE;
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc = slslam_lba_batch_export_device(b, b->d_params_out.p, stream);
+  if (rc) return rc;
+  if (!b->h_params.empty())
+    HIP_TRY(hipMemcpyAsync(b->h_params.data(), b->d_params_out.p, b->h_params.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (!b->h_state.empty()) {
+    HIP_TRY(hipMemcpyAsync(b->h_state.data(), b->d_state.p, b->h_state.size() * sizeof(LMState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(b->h_trace.data(), b->d_trace.p, b->h_trace.size() * sizeof(IterRec), hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  if (b->profiling) {
+    for (int f = 0; f < FAM_N; ++f) { b->fam_ms[f] = 0.0; b->fam_launches[f] = 0; }
+    for (const auto& u : b->ev_used) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, b->ev_pool[u.second], b->ev_pool[u.second + 1]) == hipSuccess) {
+        b->fam_ms[u.first] += ms; b->fam_launches[u.first]++;
+      }
+    }
+  }
+  b->downloaded = true;
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_get_parameters(const slslam_lba_batch* b, int index, double* parameters) {
+  if (!b || !parameters || index < 0 || index >= (int)b->wins.size()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b->downloaded) return SLSLAM_ERR_STATE;
+  const PackedWindow& P = b->wins[index];
+  const size_t n = (size_t)6 * P.C + (size_t)4 * P.L;
+  // Ceres leaves the user's parameters untouched on NUMERICAL_FAILURE
+  if (b->h_state[index].status == SLSLAM_NUMERICAL_FAILURE) std::memcpy(parameters, P.params0.data(), n * sizeof(double));
+  else std::memcpy(parameters, b->h_params.data() + b->h_param_off[index], n * sizeof(double));
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_get_summary(const slslam_lba_batch* b, int index, slslam_summary* s) {
+  if (!b || !s || index < 0 || index >= (int)b->wins.size()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b->downloaded) return SLSLAM_ERR_STATE;
+  const LMState& st = b->h_state[index];
+  s->num_successful_steps = st.n_success;
+  s->num_unsuccessful_steps = st.n_unsuccess;
+  s->initial_cost = st.initial_cost;
+  s->final_cost = st.min_cost < st.initial_cost ? st.min_cost : st.initial_cost;
+  s->fixed_cost = st.fixed_cost;
+  s->termination_type = st.status == kRunning ? SLSLAM_NO_CONVERGENCE : st.status;
+  s->num_free_parameters = b->wins[index].nfree_params;
+  s->num_residual_blocks = b->wins[index].nkept;
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_get_trace(const slslam_lba_batch* b, int index, slslam_iteration* trace, int cap, int* len) {
+  if (!b || index < 0 || index >= (int)b->wins.size()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b->downloaded) return SLSLAM_ERR_STATE;
+  const int n = std::min<int>(b->h_state[index].ntrace, kMaxTrace);
+  if (len) *len = n;
+  for (int i = 0; trace && i < n && i < cap; ++i) {
+    const IterRec& r = b->h_trace[(size_t)index * kMaxTrace + i];
+    slslam_iteration& o = trace[i];
+    o.iteration = r.iteration; o.step_is_valid = r.step_is_valid; o.step_is_successful = r.step_is_successful;
+    o.cost = r.cost; o.cost_change = r.cost_change; o.gradient_max_norm = r.gradient_max_norm;
+    o.step_norm = r.step_norm; o.relative_decrease = r.relative_decrease;
+    o.trust_region_radius = r.trust_region_radius; o.model_cost_change = r.model_cost_change;
+  }
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_counts(const slslam_lba_batch* b, long long* nw, long long* nc, long long* nfc,
+                                       long long* nl, long long* no) {
+  if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
+  long long w = 0, c = 0, fc = 0, l = 0, o = 0;
+  for (const PackedWindow& P : b->wins) { ++w; c += P.C; fc += P.Cf; l += P.L; o += P.M; }
+  if (nw) *nw = w; if (nc) *nc = c; if (nfc) *nfc = fc; if (nl) *nl = l; if (no) *no = o;
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_set_profiling(slslam_lba_batch* b, int enable) {
+  if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
+  b->profiling = enable != 0;
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_kernel_times(const slslam_lba_batch* b, double ms[8], int launches[8]) {
+  if (!b || !ms || !launches) return SLSLAM_ERR_INVALID_ARGUMENT;
+  for (int f = 0; f < FAM_N; ++f) { ms[f] = b->fam_ms[f]; launches[f] = b->fam_launches[f]; }
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_linearise(slslam_lba_batch* b, int index, double* residuals, double* j_cam,
+                                          double* j_line, double* cost) {
+  if (!b || index < 0 || index >= (int)b->wins.size() || !residuals || !j_cam || !j_line || !cost) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b->finalized) return SLSLAM_ERR_STATE;
+  HIP_TRY(hipSetDevice(b->device));
+  const PackedWindow& P = b->wins[index];
+  const size_t M = (size_t)P.M;
+  DevBuf<double> dr, djc, djl, dc;
+  int rc;
+  if ((rc = dr.alloc(std::max<size_t>(1, 4 * M))) || (rc = djc.alloc(std::max<size_t>(1, 24 * M))) ||
+      (rc = djl.alloc(std::max<size_t>(1, 16 * M))) || (rc = dc.alloc(1))) {
+    dr.release(); djc.release(); djl.release(); dc.release();
+    return rc;
+  }
+  // make sure the trig table of the current buffer is valid
+  if (b->nline > 0) hipLaunchKernelGGL(k_line_trig, dim3((unsigned)((b->nline + 255) / 256)), dim3(256), 0, 0, b->ptrs, 0);
+  hipLaunchKernelGGL(k_debug_linearise, dim3(1), dim3(64), b->lds_cost, 0, b->ptrs, b->pol, index,
+                     b->d_ob_orig.p, dr.p, djc.p, djl.p, dc.p);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess && M > 0) {
+    e = hipMemcpy(residuals, dr.p, 4 * M * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(j_cam, djc.p, 24 * M * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(j_line, djl.p, 16 * M * sizeof(double), hipMemcpyDeviceToHost);
+  }
+  if (e == hipSuccess) e = hipMemcpy(cost, dc.p, sizeof(double), hipMemcpyDeviceToHost);
+  dr.release(); djc.release(); djl.release(); dc.release();
+  HIP_TRY(e);
+  return SLSLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LBAProblem::build + set_options + ceres::Solve for one window (reference src/slam.cpp:924-944)
+extern "C" int slslam_lba_solve(const slslam_lba_window* w, const slslam_solver_options* opt,
+                                slslam_summary* summary, slslam_iteration* trace, int trace_cap, int* trace_len) {
+  if (!w) return SLSLAM_ERR_INVALID_ARGUMENT;
+  slslam_lba_batch* b = nullptr;
+  int rc = slslam_lba_batch_create(-1, &b);
+  if (rc) return rc;
+  slslam_solver_options o;
+  if (opt) o = *opt; else slslam_default_options(&o);
+  o.use_graph = 0;   // a single solve is replayed once: capture would only add latency
+  if ((rc = slslam_lba_batch_add(b, w, nullptr)) == SLSLAM_OK &&
+      (rc = slslam_lba_batch_finalize(b, &o)) == SLSLAM_OK &&
+      (rc = slslam_lba_batch_solve(b, nullptr)) == SLSLAM_OK &&
+      (rc = slslam_lba_batch_download(b, nullptr)) == SLSLAM_OK) {
+    rc = slslam_lba_batch_get_parameters(b, 0, w->parameters);
+    if (summary && rc == SLSLAM_OK) rc = slslam_lba_batch_get_summary(b, 0, summary);
+    if (rc == SLSLAM_OK) rc = slslam_lba_batch_get_trace(b, 0, trace, trace_cap, trace_len);
+  }
+  slslam_lba_batch_destroy(b);
+  return rc;
+}

@@ -1,0 +1,857 @@
+// slslam_amd/csrc/lba_kernels.h — hand-written CDNA4 (gfx950) kernels of the batched line
+// bundle adjustment.  One LM iteration of every window of the batch is six launches:
+//
+//   k_linearise_schur  one 64-lane wave per chunk of a window's lines; lane <-> observation,
+//                      a line owns a 2^g-lane group (segmented xor-shuffle reductions), per-wave
+//                      private partial of the reduced camera system in LDS (ds_add_f64)
+//   k_reduced_solve    one wave per window: ordered reduction of the chunk partials, LM damping,
+//                      in-LDS Cholesky of the (6 Cf)^2 system, candidate camera poses
+//   k_backsub          same sweep as the first kernel, back-substitutes every line, writes the
+//                      candidate line parameters and the step statistics
+//   k_line_trig        lane <-> line: sin/cos table of the candidate lines (the only trig)
+//   k_candidate_cost   residual-only sweep at the candidate point
+//   k_lm_update        per window: gain ratio, accept/reject, radius update, convergence tests
+//
+// What this replaces: everything ceres::Solve does for the problem LBAProblem::build wires up
+// (reference src/lba_problem.cpp:54-132, call sites src/slam.cpp:663,944).  Ceres evaluates
+// Jet<double,10> functors block by block, forms the sparse normal equations and factors them with
+// CHOLMOD on one thread; here the block structure (4x4 line blocks, 6x4 off-diagonal blocks,
+// 6x6 camera blocks) is exploited directly and nothing but observations and parameters is ever
+// read from HBM: Jacobians are recomputed per sweep instead of stored.
+#ifndef SLSLAM_LBA_KERNELS_H_
+#define SLSLAM_LBA_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include "lba_math.h"
+#include "lba_types.h"
+
+namespace slslam {
+
+enum { kCamTab = 29 };   // doubles per camera in LDS: R[9] JL[9] t[3] scale[6] + 2 pad (odd stride:
+                         // 58 dwords, conflict-free ds_read_b64 across cameras)
+
+__device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 2 + c; }  // r >= c
+
+__device__ __forceinline__ double group_sum(double v, int width) {
+  for (int o = 1; o < width; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ void lds_add(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ------------------------------------------------------------------------------------------
+// Everything a lane knows about its observation and its line after linearisation.
+struct LaneLin {
+  double rs[4];      // robustified residual
+  double Jc[24];     // robustified, Jacobi-scaled camera Jacobian (row-major 4x6)
+  double Jl[16];     // robustified, Jacobi-scaled line Jacobian (row-major 4x4)
+  double cost;       // rho/2 of this block
+  int cam;           // window-local camera id
+  int cf;            // free-camera index or -1
+  bool valid, kept, line_free;
+};
+
+// Load one observation + its line record and linearise it.  cur selects the parameter buffer.
+// SCALED: apply the Jacobi column scaling (false for the initial evaluation and the test hook).
+template <bool SCALED>
+__device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy& pol, const double* camtab,
+                                               const int* camcf, int ls, int j, int k, int o0, bool line_ok,
+                                               int cur, int safe_obs, LaneLin& L) {
+  L.valid = line_ok && j < k;
+  const int o = L.valid ? o0 + j : safe_obs;
+  double ob[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ob[q] = p.ob[(long long)q * p.ob_stride + o];
+  L.cam = p.ob_cam[o];
+  const int lsafe = line_ok ? ls : 0;
+  const double* lrec = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
+  double trig[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
+  const int lflags = p.line_flags[lsafe];
+  L.line_free = line_ok && !(lflags & 1);
+  const double* ct = camtab + L.cam * kCamTab;
+  double R[9], JL[9], t[3];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { R[q] = ct[q]; JL[q] = ct[9 + q]; }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) t[q] = ct[18 + q];
+  L.cf = camcf[L.cam];
+  L.kept = L.valid && !(L.cf < 0 && !L.line_free);
+  double cp[3], dv[3], dcp[12], ddv[9], r[4];
+  line_points_jac<double>(trig, cp, dv, dcp, ddv);
+  obs_linearise<double>(R, JL, t, cp, dv, dcp, ddv, ob, pol.baseline, r, L.Jc, L.Jl);
+  const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+  const double sr = huber_scale<double>(s, pol.huber_delta, &L.cost);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) L.rs[q] = r[q] * sr;
+  if (SCALED) {
+    const double* lsc = p.line_scale + (long long)lsafe * 4;
+    double sc[6], sl[4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) sc[a] = ct[21 + a] * sr;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sl[a] = lsc[a] * sr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) L.Jc[6 * q + a] *= sc[a];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) L.Jl[4 * q + a] *= sl[a];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 24; ++q) L.Jc[q] *= sr;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) L.Jl[q] *= sr;
+  }
+}
+
+// Per-line normal-equation block, summed over the line's group of lanes (every lane of the group
+// ends with the same values): H = sum Jl^T Jl (lower triangle, 10 values), g = sum Jl^T r.
+__device__ __forceinline__ void line_block(const LaneLin& L, int width, double H[10], double g[4]) {
+  const bool m = L.valid && L.line_free;
+  int q = 0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      double h = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h += L.Jl[4 * r + a] * L.Jl[4 * r + b];
+      H[q++] = group_sum(m ? h : 0.0, width);
+    }
+    double ga = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ga += L.Jl[4 * r + a] * L.rs[r];
+    g[a] = group_sum(m ? ga : 0.0, width);
+  }
+}
+
+// A = H + diag(D2), A = Lc Lc^T, K = Lc^-1 (lower, 10 values, same packing as H).
+// Returns false if A is not positive definite (only possible with non-finite input).
+__device__ __forceinline__ bool chol4_inverse(const double H[10], const double D2[4], double K[10]) {
+  // packing: (0,0)=0 (1,0)=1 (1,1)=2 (2,0)=3 (2,1)=4 (2,2)=5 (3,0)=6 (3,1)=7 (3,2)=8 (3,3)=9
+  const double a00 = H[0] + D2[0], a10 = H[1], a11 = H[2] + D2[1], a20 = H[3], a21 = H[4],
+               a22 = H[5] + D2[2], a30 = H[6], a31 = H[7], a32 = H[8], a33 = H[9] + D2[3];
+  bool ok = a00 > 0.0;
+  const double i0 = 1.0 / sqrt(a00);
+  const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+  const double d1 = a11 - l10 * l10;
+  ok = ok && d1 > 0.0;
+  const double i1 = 1.0 / sqrt(d1);
+  const double l21 = (a21 - l20 * l10) * i1, l31 = (a31 - l30 * l10) * i1;
+  const double d2 = a22 - l20 * l20 - l21 * l21;
+  ok = ok && d2 > 0.0;
+  const double i2 = 1.0 / sqrt(d2);
+  const double l32 = (a32 - l30 * l20 - l31 * l21) * i2;
+  const double d3 = a33 - l30 * l30 - l31 * l31 - l32 * l32;
+  ok = ok && d3 > 0.0;
+  const double i3 = 1.0 / sqrt(d3);
+  // inverse of the lower-triangular factor (diagonal of Lc is 1/i_k)
+  K[0] = i0; K[2] = i1; K[5] = i2; K[9] = i3;
+  K[1] = -l10 * K[0] * i1;
+  K[3] = -(l20 * K[0] + l21 * K[1]) * i2;
+  K[4] = -l21 * K[2] * i2;
+  K[6] = -(l30 * K[0] + l31 * K[1] + l32 * K[3]) * i3;
+  K[7] = -(l31 * K[2] + l32 * K[4]) * i3;
+  K[8] = -l32 * K[5] * i3;
+  return ok && isfinite(d3) && isfinite(i3);
+}
+
+__device__ __forceinline__ void lm_diag4(const double H[10], const Policy& pol, double radius, double D2[4]) {
+  const double d[4] = { H[0], H[2], H[5], H[9] };
+#pragma unroll
+  for (int a = 0; a < 4; ++a) D2[a] = fmin(fmax(d[a], pol.min_lm_diagonal), pol.max_lm_diagonal) / radius;
+}
+
+// F = (Jc^T Jl) K^T  (6x4, row-major):  the line's share of the elimination, so that
+// H_cl A^-1 H_lc = F F^T  and  H_cl A^-1 g_l = F (K g_l).
+__device__ __forceinline__ void lane_F(const LaneLin& L, const double K[10], double F[24]) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double h[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += L.Jc[6 * r + a] * L.Jl[4 * r + b];
+      h[b] = s;
+    }
+    F[4 * a + 0] = h[0] * K[0];
+    F[4 * a + 1] = h[0] * K[1] + h[1] * K[2];
+    F[4 * a + 2] = h[0] * K[3] + h[1] * K[4] + h[2] * K[5];
+    F[4 * a + 3] = h[0] * K[6] + h[1] * K[7] + h[2] * K[8] + h[3] * K[9];
+  }
+}
+
+// Camera table of one window in LDS.  WITH_JAC: R and JL at buffer `buf`; else R only.
+template <bool WITH_JAC, bool UNIT_SCALE>
+__device__ __forceinline__ void load_cam_table(const BatchPtrs& p, const WinDesc& wd, int buf, int lane,
+                                               double* camtab, int* camcf) {
+  for (int c = lane; c < wd.C; c += 64) {
+    const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + buf) * kCamRec;
+    double w[3] = { x[0], x[1], x[2] }, R[9], JL[9];
+    if (WITH_JAC) cam_prepare<double>(w, R, JL);
+    else { cam_rotation<double>(w, R); for (int q = 0; q < 9; ++q) JL[q] = 0.0; }
+    double* ct = camtab + c * kCamTab;
+    for (int q = 0; q < 9; ++q) { ct[q] = R[q]; ct[9 + q] = JL[q]; }
+    ct[18] = x[3]; ct[19] = x[4]; ct[20] = x[5];
+    for (int a = 0; a < 6; ++a) ct[21 + a] = UNIT_SCALE ? 1.0 : p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
+    camcf[c] = p.cam_cf[wd.cam_off + c];
+  }
+}
+
+__host__ __device__ inline int lds_doubles_linearise(int C, int n) {
+  // camtab + S tri + b + g + hdiag ; camcf ints appended (C ints -> (C+1)/2 doubles)
+  return C * kCamTab + (n * (n + 1)) / 2 + 3 * n + (C + 1) / 2 + 2;
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 1: linearise + per-line Schur elimination, partial reduced system per chunk.
+// INIT = initial evaluation (Ceres: cost, gradient and column norms at x0 for the Jacobi scaling):
+// no elimination, unit scaling, writes the per-line scale.
+template <bool INIT>
+__global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const Chunk ck = p.chunks[blockIdx.x];
+  const WinDesc wd = p.wins[ck.win];
+  const LMState* st = p.state + ck.win;
+  if (st->status != kRunning) return;
+  const int cur = st->cur;
+  const double radius = st->radius;
+  const int n = wd.n, ntri = (n * (n + 1)) / 2;
+  double* camtab = smem;
+  double* S = camtab + wd.C * kCamTab;
+  double* bvec = S + ntri;
+  double* gvec = bvec + n;
+  double* hvec = gvec + n;
+  int* camcf = (int*)(hvec + n);
+  load_cam_table<true, INIT>(p, wd, cur, lane, camtab, camcf);
+  for (int q = lane; q < ntri + 3 * n; q += 64) S[q] = 0.0;
+  __syncthreads();
+
+  double acc_cost = 0.0, acc_fixed = 0.0, acc_gmax = 0.0, acc_xn2 = 0.0;
+  int fail = 0;
+  for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
+    const Tile tl = p.tiles[t];
+    const int width = 1 << tl.glog2;
+    const int lsub = lane >> tl.glog2, j = lane & (width - 1);
+    const int ls = tl.line_begin + lsub;
+    const bool line_ok = lsub < tl.nlines;
+    int o0 = 0, k = 0;
+    if (line_ok) { o0 = p.line_ptr[ls]; k = p.line_ptr[ls + 1] - o0; }
+    LaneLin L;
+    lane_linearise<!INIT>(p, pol, camtab, camcf, ls, j, k, o0, line_ok, cur, wd.obs_off, L);
+    if (L.kept) acc_cost += L.cost;
+    if (INIT && L.valid && !L.kept) acc_fixed += L.cost;
+
+    double H[10], g[4];
+    line_block(L, width, H, g);
+    const bool line_active = L.line_free && k > 0;   // group-uniform
+
+    if (INIT) {
+      // Jacobi scaling of the line's columns: 1 / (1 + ||J_col||), estimated once at x0
+      if (line_ok && j == 0) {
+        const double d[4] = { H[0], H[2], H[5], H[9] };
+        double* lsc = p.line_scale + (long long)ls * 4;
+        const double* u = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
+        for (int a = 0; a < 4; ++a) {
+          lsc[a] = (pol.jacobi_scaling && line_active) ? 1.0 / (1.0 + sqrt(d[a])) : 1.0;
+          if (line_active) { acc_gmax = fmax(acc_gmax, fabs(g[a])); acc_xn2 += u[a] * u[a]; }
+        }
+      }
+      if (L.valid && L.cf >= 0) {
+        for (int a = 0; a < 6; ++a) {
+          double ga = 0.0, ha = 0.0;
+          for (int r = 0; r < 4; ++r) { ga += L.Jc[6 * r + a] * L.rs[r]; ha += L.Jc[6 * r + a] * L.Jc[6 * r + a]; }
+          lds_add(&gvec[6 * L.cf + a], ga);
+          lds_add(&hvec[6 * L.cf + a], ha);
+        }
+      }
+      continue;
+    }
+
+    // ---- eliminate the line: A = H + D^2, A^-1 = K^T K
+    double D2[4], K[10], u[4] = { 0, 0, 0, 0 }, F[24];
+    lm_diag4(H, pol, radius, D2);
+    bool okc = true;
+    if (line_active) okc = chol4_inverse(H, D2, K);
+    else { for (int q = 0; q < 10; ++q) K[q] = 0.0; }
+    if (!okc) fail = 1;
+    if (line_active) {
+      u[0] = K[0] * g[0];
+      u[1] = K[1] * g[0] + K[2] * g[1];
+      u[2] = K[3] * g[0] + K[4] * g[1] + K[5] * g[2];
+      u[3] = K[6] * g[0] + K[7] * g[1] + K[8] * g[2] + K[9] * g[3];
+      if (line_ok && j == 0) {
+        const double* lsc = p.line_scale + (long long)ls * 4;
+        for (int a = 0; a < 4; ++a) acc_gmax = fmax(acc_gmax, fabs(g[a] / lsc[a]));
+      }
+    }
+    const bool cam_free = L.valid && L.cf >= 0;
+    const bool elim = cam_free && L.line_free;       // this observation couples a free camera to a free line
+    if (elim) lane_F(L, K, F);
+    else { for (int q = 0; q < 24; ++q) F[q] = 0.0; }
+
+    if (cam_free) {
+      const int base = 6 * L.cf;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double ga = 0.0, ha = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ga += L.Jc[6 * r + a] * L.rs[r]; ha += L.Jc[6 * r + a] * L.Jc[6 * r + a]; }
+        const double fu = F[4 * a] * u[0] + F[4 * a + 1] * u[1] + F[4 * a + 2] * u[2] + F[4 * a + 3] * u[3];
+        lds_add(&gvec[base + a], ga);
+        lds_add(&hvec[base + a], ha);
+        lds_add(&bvec[base + a], ga - fu);
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          double v = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v += L.Jc[6 * r + a] * L.Jc[6 * r + b];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) v -= F[4 * a + m] * F[4 * b + m];
+          lds_add(&S[tri_index(base + a, base + b)], v);
+        }
+      }
+    }
+
+    // ---- off-diagonal camera pairs of the tile, balanced over the lanes
+    for (int base_it = 0; base_it < tl.nitems; base_it += 64) {
+      const int it = base_it + lane;
+      const bool has = it < tl.nitems;
+      int li = 0, lj = 0;
+      if (has) { li = p.items[2 * (long long)(tl.item_off + it)]; lj = p.items[2 * (long long)(tl.item_off + it) + 1]; }
+      double Fi[24], Fj[24];
+#pragma unroll
+      for (int q = 0; q < 24; ++q) { Fi[q] = __shfl(F[q], li); Fj[q] = __shfl(F[q], lj); }
+      const int ci = __shfl(L.cf, li), cj = __shfl(L.cf, lj);
+      if (has) {
+        if (cj != ci) {        // cj > ci by construction
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+              double v = 0.0;
+#pragma unroll
+              for (int m = 0; m < 4; ++m) v += Fj[4 * a + m] * Fi[4 * b + m];
+              lds_add(&S[tri_index(6 * cj + a, 6 * ci + b)], -v);
+            }
+        } else {               // the same camera observes the line twice: symmetric part
+          for (int a = 0; a < 6; ++a)
+            for (int b = 0; b <= a; ++b) {
+              double v = 0.0;
+              for (int m = 0; m < 4; ++m) v += Fj[4 * a + m] * Fi[4 * b + m] + Fi[4 * a + m] * Fj[4 * b + m];
+              lds_add(&S[tri_index(6 * ci + a, 6 * ci + b)], -v);
+            }
+        }
+      }
+    }
+  }
+
+  __syncthreads();
+  double* slab = p.slab + ck.slab_off;
+  for (int q = lane; q < ntri + 3 * n; q += 64) slab[q] = S[q];
+  const double c_sum = wave_sum(acc_cost), f_sum = wave_sum(acc_fixed), x_sum = wave_sum(acc_xn2);
+  const double g_max = wave_max(acc_gmax);
+  const int any_fail = __any(fail);
+  if (lane == 0) {
+    double* sc = slab + ntri + 3 * n;
+    sc[kScCost] = c_sum; sc[kScFixedCost] = f_sum; sc[kScGradMaxLine] = g_max; sc[kScXn2Line] = x_sum;
+    sc[kScFail] = any_fail ? 1.0 : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 2: reduced camera system of one window.  Ordered sum of the chunk partials
+// (bitwise reproducible), S += D_c^2, in-LDS Cholesky, y_c, candidate camera poses.
+// Also performs the gradient-tolerance test Ceres does right after accepting a step.
+__host__ __device__ inline int solve_stride(int n) { return ((n + 30) / 32) * 32 + 1; }  // == 1 (mod 32) doubles
+__host__ __device__ inline int lds_doubles_solve(int n) { return n * solve_stride(n) + 4 * n + 8; }
+
+__global__ __launch_bounds__(64) void k_reduced_solve(BatchPtrs p, Policy pol) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x;
+  const WinDesc wd = p.wins[w];
+  LMState* st = p.state + w;
+  if (st->status != kRunning) return;
+  const int n = wd.n, ntri = (n * (n + 1)) / 2, ld = solve_stride(n);
+  double* A = smem;               // n x ld, lower triangle used
+  double* bvec = A + n * ld;      // b | g | hdiag | y, contiguous
+  double* gvec = bvec + n;
+  double* hvec = gvec + n;
+  double* yvec = hvec + n;
+  const int cur = st->cur;
+  const double radius = st->radius;
+  const int need_grad_check = st->need_grad_check;
+  const double abs_grad_tol = st->abs_grad_tol;
+
+  // ordered (bitwise reproducible) reduction over the window's chunk partials
+  for (int r = 0; r < n; ++r)
+    for (int c = lane; c <= r; c += 64) {
+      const int q = tri_index(r, c);
+      double s = 0.0;
+      for (int k = 0; k < wd.nchunks; ++k) s += p.slab[p.chunks[wd.chunk_off + k].slab_off + q];
+      A[r * ld + c] = s;
+    }
+  for (int q = lane; q < 3 * n; q += 64) {
+    double s = 0.0;
+    for (int k = 0; k < wd.nchunks; ++k) s += p.slab[p.chunks[wd.chunk_off + k].slab_off + ntri + q];
+    bvec[q] = s;
+  }
+  double gmax_line = 0.0;
+  int fail = 0;
+  for (int k = 0; k < wd.nchunks; ++k) {
+    const double* sc = p.slab + p.chunks[wd.chunk_off + k].slab_off + ntri + 3 * n;
+    gmax_line = fmax(gmax_line, sc[kScGradMaxLine]);
+    if (sc[kScFail] != 0.0) fail = 1;
+  }
+  __syncthreads();
+
+  // gradient max-norm at the accepted point: gvec holds the SCALED gradient J'^T r, the true
+  // gradient is g / scale.  Ceres tests it right after accepting a step.
+  if (need_grad_check) {
+    double gm = 0.0;
+    for (int c = lane; c < wd.C; c += 64) {
+      const int cf = p.cam_cf[wd.cam_off + c];
+      if (cf < 0) continue;
+      for (int a = 0; a < 6; ++a)
+        gm = fmax(gm, fabs(gvec[6 * cf + a] / p.cam_scale[(long long)(wd.cam_off + c) * 6 + a]));
+    }
+    gm = fmax(wave_max(gm), gmax_line);
+    if (lane == 0) {
+      st->grad_max = gm;
+      st->need_grad_check = 0;
+      if (st->ntrace > 0 && st->ntrace <= kMaxTrace)
+        p.trace[(long long)w * kMaxTrace + st->ntrace - 1].gradient_max_norm = gm;
+      if (gm <= abs_grad_tol) st->status = 1 /* SLSLAM_GRADIENT_TOLERANCE */;
+    }
+    if (gm <= abs_grad_tol) return;
+  }
+
+  // LM damping of the camera columns: D^2 = clamp(diag(J'^T J')) / radius
+  for (int q = lane; q < n; q += 64) {
+    const double d2 = fmin(fmax(hvec[q], pol.min_lm_diagonal), pol.max_lm_diagonal) / radius;
+    hvec[q] = d2;
+    A[q * ld + q] += d2;
+    yvec[q] = bvec[q];
+  }
+  __syncthreads();
+
+  // left-looking Cholesky in LDS, lane <-> row (two rows per lane when n > 64)
+  for (int jc = 0; jc < n; ++jc) {
+    double s[2] = { 0.0, 0.0 };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = lane + 64 * h;
+      if (r >= jc && r < n) {
+        double v = A[r * ld + jc];
+        for (int k = 0; k < jc; ++k) v -= A[r * ld + k] * A[jc * ld + k];
+        s[h] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (lane + 64 * h == jc) A[jc * ld + jc] = (s[h] > 0.0 && isfinite(s[h])) ? sqrt(s[h]) : -1.0;
+    __syncthreads();
+    double d = A[jc * ld + jc];
+    if (!(d > 0.0)) { fail = 1; d = 1.0; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = lane + 64 * h;
+      if (r > jc && r < n) A[r * ld + jc] = s[h] / d;
+    }
+    __syncthreads();
+    if (!(A[jc * ld + jc] > 0.0)) { __syncthreads(); if (lane == 0) A[jc * ld + jc] = 1.0; __syncthreads(); }
+  }
+  // forward then backward substitution: serial in the pivot, lane-parallel over rows
+  for (int jc = 0; jc < n; ++jc) {
+    const double yj = yvec[jc] / A[jc * ld + jc];
+    __syncthreads();
+    if (lane == 0) yvec[jc] = yj;
+    for (int r = jc + 1 + lane; r < n; r += 64) yvec[r] -= A[r * ld + jc] * yj;
+    __syncthreads();
+  }
+  for (int jc = n - 1; jc >= 0; --jc) {
+    const double yj = yvec[jc] / A[jc * ld + jc];
+    __syncthreads();
+    if (lane == 0) yvec[jc] = yj;
+    for (int r = lane; r < jc; r += 64) yvec[r] -= A[jc * ld + r] * yj;
+    __syncthreads();
+  }
+
+  // step statistics of the camera block and candidate camera poses
+  double model = 0.0, dn2 = 0.0, xn2 = 0.0;
+  int bad = 0;
+  for (int q = lane; q < n; q += 64) {
+    const double y = yvec[q];
+    if (!isfinite(y)) bad = 1;
+    model += 0.5 * y * (gvec[q] + hvec[q] * y);
+    p.ysys[wd.sys_off + q] = y;
+  }
+  for (int c = lane; c < wd.C; c += 64) {
+    const int cf = p.cam_cf[wd.cam_off + c];
+    const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + cur) * kCamRec;
+    double* xc = p.cam_x + ((long long)(wd.cam_off + c) * 2 + (1 - cur)) * kCamRec;
+    for (int a = 0; a < 6; ++a) {
+      double v = x[a];
+      if (cf >= 0) {
+        const double d = -yvec[6 * cf + a] * p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
+        const double xn = v + d;
+        const double dd = v - xn;
+        dn2 += dd * dd;
+        xn2 += xn * xn;
+        v = xn;
+      }
+      xc[a] = v;
+    }
+  }
+  model = wave_sum(model); dn2 = wave_sum(dn2); xn2 = wave_sum(xn2);
+  const int any_bad = __any(bad | fail);
+  if (lane == 0) {
+    st->cam_model = model; st->cam_dn2 = dn2; st->cam_xn2 = xn2;
+    st->solve_failed = any_bad ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 3: back-substitution  y_l = A^-1 (g_l - sum_i H_cl,i^T y_c)  = K^T (u - K w),
+// candidate line parameters, line part of the step statistics.
+__host__ __device__ inline int lds_doubles_backsub(int C, int n) { return C * kCamTab + n + (C + 1) / 2 + 2; }
+
+__global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const Chunk ck = p.chunks[blockIdx.x];
+  const WinDesc wd = p.wins[ck.win];
+  const LMState* st = p.state + ck.win;
+  if (st->status != kRunning) return;
+  const int cur = st->cur;
+  const double radius = st->radius;
+  const int n = wd.n;
+  double* camtab = smem;
+  double* yc = camtab + wd.C * kCamTab;
+  int* camcf = (int*)(yc + n);
+  load_cam_table<true, false>(p, wd, cur, lane, camtab, camcf);
+  for (int q = lane; q < n; q += 64) yc[q] = p.ysys[wd.sys_off + q];
+  __syncthreads();
+
+  double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0;
+  for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
+    const Tile tl = p.tiles[t];
+    const int width = 1 << tl.glog2;
+    const int lsub = lane >> tl.glog2, j = lane & (width - 1);
+    const int ls = tl.line_begin + lsub;
+    const bool line_ok = lsub < tl.nlines;
+    int o0 = 0, k = 0;
+    if (line_ok) { o0 = p.line_ptr[ls]; k = p.line_ptr[ls + 1] - o0; }
+    LaneLin L;
+    lane_linearise<true>(p, pol, camtab, camcf, ls, j, k, o0, line_ok, cur, wd.obs_off, L);
+    double H[10], g[4];
+    line_block(L, width, H, g);
+    const bool line_active = L.line_free && k > 0;
+    // w = sum_i (Jc_i^T Jl_i)^T y_c[cam_i] = sum_i Jl_i^T (Jc_i y_c)
+    double wv[4] = { 0, 0, 0, 0 };
+    if (L.valid && L.cf >= 0 && L.line_free) {
+      double jy[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) s += L.Jc[6 * r + a] * yc[6 * L.cf + a];
+        jy[r] = s;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wv[a] = L.Jl[a] * jy[0] + L.Jl[4 + a] * jy[1] + L.Jl[8 + a] * jy[2] + L.Jl[12 + a] * jy[3];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wv[a] = group_sum(wv[a], width);
+    if (line_ok && j == 0) {
+      const double* xl = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
+      double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
+      double xn[4] = { xl[0], xl[1], xl[2], xl[3] };
+      if (line_active) {
+        double D2[4], K[10];
+        lm_diag4(H, pol, radius, D2);
+        chol4_inverse(H, D2, K);
+        // z = K (g - w);  y = K^T z
+        const double e0 = g[0] - wv[0], e1 = g[1] - wv[1], e2 = g[2] - wv[2], e3 = g[3] - wv[3];
+        const double z0 = K[0] * e0;
+        const double z1 = K[1] * e0 + K[2] * e1;
+        const double z2 = K[3] * e0 + K[4] * e1 + K[5] * e2;
+        const double z3 = K[6] * e0 + K[7] * e1 + K[8] * e2 + K[9] * e3;
+        double y[4];
+        y[0] = K[0] * z0 + K[1] * z1 + K[3] * z2 + K[6] * z3;
+        y[1] = K[2] * z1 + K[4] * z2 + K[7] * z3;
+        y[2] = K[5] * z2 + K[8] * z3;
+        y[3] = K[9] * z3;
+        const double* lsc = p.line_scale + (long long)ls * 4;
+        for (int a = 0; a < 4; ++a) {
+          acc_model += 0.5 * y[a] * (g[a] + D2[a] * y[a]);
+          const double v = xn[a] - y[a] * lsc[a];
+          const double dd = xn[a] - v;
+          acc_dn2 += dd * dd;
+          acc_xn2 += v * v;
+          xn[a] = v;
+        }
+      }
+      for (int a = 0; a < 4; ++a) xc[a] = xn[a];
+    }
+  }
+  const double m = wave_sum(acc_model), d = wave_sum(acc_dn2), x = wave_sum(acc_xn2);
+  if (lane == 0) {
+    double* bp = p.bs_part + (long long)blockIdx.x * kBsStride;
+    bp[kBsModel] = m; bp[kBsDn2] = d; bp[kBsXn2] = x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 4: sin/cos table of one parameter buffer of every line; lane <-> line.
+// which: 0 = the accepted buffer (initialisation), 1 = the candidate buffer.
+__global__ __launch_bounds__(256) void k_line_trig(BatchPtrs p, int which) {
+  const int ls = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ls >= p.nline) return;
+  const LMState* st = p.state + p.line_win[ls];
+  if (st->status != kRunning) return;
+  const int buf = which ? 1 - st->cur : st->cur;
+  double* rec = p.line_x + ((long long)ls * 2 + buf) * kLineRec;
+  double u[4] = { rec[0], rec[1], rec[2], rec[3] }, trig[7];
+  line_trig<double>(u, trig);
+  for (int q = 0; q < 7; ++q) rec[4 + q] = trig[q];
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 5: cost of the reduced program at the candidate point (residuals only).
+__host__ __device__ inline int lds_doubles_cost(int C) { return C * kCamTab + (C + 1) / 2 + 2; }
+
+__global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const Chunk ck = p.chunks[blockIdx.x];
+  const WinDesc wd = p.wins[ck.win];
+  const LMState* st = p.state + ck.win;
+  if (st->status != kRunning) return;
+  const int cand = 1 - st->cur;
+  double* camtab = smem;
+  int* camcf = (int*)(camtab + wd.C * kCamTab);
+  load_cam_table<false, true>(p, wd, cand, lane, camtab, camcf);
+  __syncthreads();
+  double acc = 0.0;
+  for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
+    const Tile tl = p.tiles[t];
+    const int width = 1 << tl.glog2;
+    const int lsub = lane >> tl.glog2, j = lane & (width - 1);
+    const int ls = tl.line_begin + lsub;
+    const bool line_ok = lsub < tl.nlines;
+    int o0 = 0, k = 0;
+    if (line_ok) { o0 = p.line_ptr[ls]; k = p.line_ptr[ls + 1] - o0; }
+    const bool valid = line_ok && j < k;
+    const int o = valid ? o0 + j : wd.obs_off;
+    double ob[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ob[q] = p.ob[(long long)q * p.ob_stride + o];
+    const int cam = p.ob_cam[o];
+    const int lsafe = line_ok ? ls : 0;
+    const double* lrec = p.line_x + ((long long)lsafe * 2 + cand) * kLineRec;
+    double trig[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
+    const bool line_free = !(p.line_flags[lsafe] & 1);
+    const double* ct = camtab + cam * kCamTab;
+    double R[9], tt[3], cp[3], dv[3], r[4], c;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) R[q] = ct[q];
+    tt[0] = ct[18]; tt[1] = ct[19]; tt[2] = ct[20];
+    line_points<double>(trig, cp, dv);
+    obs_residual<double>(R, tt, cp, dv, ob, pol.baseline, r);
+    huber_scale<double>(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], pol.huber_delta, &c);
+    const bool kept = valid && !(camcf[cam] < 0 && !line_free);
+    if (kept) acc += c;
+  }
+  const double s = wave_sum(acc);
+  if (lane == 0) p.cost_part[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 6: the trust-region bookkeeping of one window (one lane).
+// phase 0 = after the initial evaluation, 1 = after an LM iteration.
+__device__ __forceinline__ void push_trace(BatchPtrs& p, int w, LMState* st, const IterRec& r) {
+  if (st->ntrace < kMaxTrace) p.trace[(long long)w * kMaxTrace + st->ntrace] = r;
+  st->ntrace++;
+}
+
+__global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol, int phase) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= p.nwin) return;
+  const WinDesc wd = p.wins[w];
+  LMState* st = p.state + w;
+  if (st->status != kRunning) return;
+  const int n = wd.n, ntri = (n * (n + 1)) / 2;
+  IterRec rec;
+  rec.pad = 0;
+  if (phase == 0) {
+    // ---- Ceres: initial cost / gradient / Jacobi scale
+    double cost = 0.0, fixed = 0.0, gmax = 0.0, xn2 = 0.0;
+    for (int c = 0; c < wd.nchunks; ++c) {
+      const double* sc = p.slab + p.chunks[wd.chunk_off + c].slab_off + ntri + 3 * n;
+      cost += sc[kScCost]; fixed += sc[kScFixedCost]; gmax = fmax(gmax, sc[kScGradMaxLine]); xn2 += sc[kScXn2Line];
+    }
+    for (int c = 0; c < wd.C; ++c) {
+      const int cf = p.cam_cf[wd.cam_off + c];
+      const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + st->cur) * kCamRec;
+      for (int a = 0; a < 6; ++a) {
+        double sc = 1.0;
+        if (cf >= 0) {
+          double g = 0.0, h = 0.0;
+          for (int k = 0; k < wd.nchunks; ++k) {
+            const double* sl = p.slab + p.chunks[wd.chunk_off + k].slab_off + ntri;
+            g += sl[n + 6 * cf + a]; h += sl[2 * n + 6 * cf + a];
+          }
+          gmax = fmax(gmax, fabs(g));
+          xn2 += x[a] * x[a];
+          if (pol.jacobi_scaling) sc = 1.0 / (1.0 + sqrt(h));
+        }
+        p.cam_scale[(long long)(wd.cam_off + c) * 6 + a] = sc;
+      }
+    }
+    st->cost = cost; st->fixed_cost = fixed; st->initial_cost = cost + fixed; st->min_cost = cost + fixed;
+    st->x_norm = sqrt(xn2);
+    st->grad_max = gmax;
+    const double g0 = gmax > 1e-12 ? gmax : 1e-12;
+    st->abs_grad_tol = pol.gradient_tolerance * g0;
+    st->need_grad_check = 0;
+    if (wd.nfree_params == 0) { st->status = 2 /* FUNCTION_TOLERANCE: no free blocks */; return; }
+    if (!isfinite(cost)) { st->status = 4; return; }
+    if (gmax <= st->abs_grad_tol) { st->status = 1; return; }
+    rec.iteration = 0; rec.step_is_valid = 0; rec.step_is_successful = 0;
+    rec.cost = cost + fixed; rec.cost_change = 0; rec.gradient_max_norm = gmax; rec.step_norm = 0;
+    rec.relative_decrease = 0; rec.trust_region_radius = st->radius; rec.model_cost_change = 0;
+    push_trace(p, w, st, rec);
+    if (st->iter >= pol.max_num_iterations) st->status = 0;
+    return;
+  }
+
+  // ---- one LM iteration
+  double new_cost = 0.0, model = st->cam_model, dn2 = st->cam_dn2, xn2 = st->cam_xn2;
+  for (int c = 0; c < wd.nchunks; ++c) {
+    new_cost += p.cost_part[wd.chunk_off + c];
+    const double* bp = p.bs_part + (long long)(wd.chunk_off + c) * kBsStride;
+    model += bp[kBsModel]; dn2 += bp[kBsDn2]; xn2 += bp[kBsXn2];
+  }
+  const double cost = st->cost;
+  rec.iteration = st->iter + 1;
+  rec.step_is_valid = 0; rec.step_is_successful = 0;
+  rec.model_cost_change = model;
+  rec.cost_change = 0; rec.step_norm = 0; rec.relative_decrease = 0;
+  rec.gradient_max_norm = st->grad_max;
+  bool valid = !st->solve_failed && !(model < 0.0);
+  if (!isfinite(new_cost)) new_cost = 1.7976931348623157e308;
+  if (!valid) {
+    if (++st->n_invalid >= pol.max_invalid) { st->status = 4; return; }
+  } else {
+    st->n_invalid = 0;
+    rec.step_is_valid = 1;
+    rec.step_norm = sqrt(dn2);
+    if (rec.step_norm <= pol.parameter_tolerance * (st->x_norm + pol.parameter_tolerance)) { st->status = 3; return; }
+    rec.cost_change = cost - new_cost;
+    if (fabs(rec.cost_change) < pol.function_tolerance * cost) { st->status = 2; return; }
+    rec.relative_decrease = rec.cost_change / model;
+    rec.step_is_successful = rec.relative_decrease > pol.min_relative_decrease;
+  }
+  if (rec.step_is_successful) {
+    st->n_success++;
+    const double q = 2.0 * rec.relative_decrease - 1.0;
+    double f = 1.0 - q * q * q;
+    if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+    st->radius = fmin(st->radius / f, pol.max_radius);
+    st->decrease_factor = 2.0;
+    st->cur = 1 - st->cur;
+    st->cost = new_cost;
+    st->x_norm = sqrt(xn2);
+    st->need_grad_check = 1;      // the next linearisation supplies the gradient at the new point
+  } else {
+    st->n_unsuccess++;
+    if (rec.step_is_valid) { st->radius = st->radius / st->decrease_factor; st->decrease_factor *= 2.0; }
+    else st->radius *= 0.5;
+  }
+  rec.cost = st->cost + st->fixed_cost;
+  rec.trust_region_radius = st->radius;
+  if (rec.cost < st->min_cost) st->min_cost = rec.cost;
+  push_trace(p, w, st, rec);
+  st->iter = rec.iteration;
+  if (st->radius < pol.min_radius) { st->status = 5; return; }
+  if (st->iter >= pol.max_num_iterations) { st->status = 0; return; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Test hook: per-observation robustified residuals / Jacobians (unscaled) in the caller's order.
+__global__ __launch_bounds__(64) void k_debug_linearise(BatchPtrs p, Policy pol, int w, const int* ob_orig,
+                                                        double* out_r, double* out_jc, double* out_jl, double* out_cost) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const WinDesc wd = p.wins[w];
+  const LMState* st = p.state + w;
+  const int cur = st->cur;
+  double* camtab = smem;
+  int* camcf = (int*)(camtab + wd.C * kCamTab);
+  load_cam_table<true, true>(p, wd, cur, lane, camtab, camcf);
+  __syncthreads();
+  double acc = 0.0;
+  for (int l = 0; l < wd.L; ++l) {
+    const int ls = wd.line_off + l;
+    const int o0 = p.line_ptr[ls], k = p.line_ptr[ls + 1] - o0;
+    for (int j0 = 0; j0 < k; j0 += 64) {
+      const int j = j0 + lane;
+      LaneLin L;
+      lane_linearise<false>(p, pol, camtab, camcf, ls, j, k, o0, true, cur, wd.obs_off, L);
+      if (L.valid) {
+        const int orig = ob_orig[o0 + j];
+        for (int q = 0; q < 4; ++q) out_r[4 * (long long)orig + q] = L.rs[q];
+        for (int q = 0; q < 24; ++q) out_jc[24 * (long long)orig + q] = L.Jc[q];
+        for (int q = 0; q < 16; ++q) out_jl[16 * (long long)orig + q] = L.Jl[q];
+        acc += L.cost;
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) *out_cost = acc;
+}
+
+// Gathers the accepted parameters of every window into the caller's layout
+// [6C | 4L] per window, windows concatenated.  lane <-> parameter block.
+__global__ __launch_bounds__(256) void k_export(BatchPtrs p, const long long* win_param_off, const int* cam_win,
+                                                const int* line_orig, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < p.ncam) {
+    const int w = cam_win[i];
+    const WinDesc wd = p.wins[w];
+    const int cur = p.state[w].cur;
+    const double* x = p.cam_x + ((long long)i * 2 + cur) * kCamRec;
+    double* o = out + win_param_off[w] + 6 * (long long)(i - wd.cam_off);
+    for (int a = 0; a < 6; ++a) o[a] = x[a];
+  } else if (i < p.ncam + p.nline) {
+    const int ls = i - p.ncam;
+    const int w = p.line_win[ls];
+    const WinDesc wd = p.wins[w];
+    const int cur = p.state[w].cur;
+    const double* x = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
+    double* o = out + win_param_off[w] + 6 * (long long)wd.C + 4 * (long long)line_orig[ls];
+    for (int a = 0; a < 4; ++a) o[a] = x[a];
+  }
+}
+
+}  // namespace slslam
+#endif  // SLSLAM_LBA_KERNELS_H_

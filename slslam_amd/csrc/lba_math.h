@@ -1,0 +1,220 @@
+// slslam_amd/csrc/lba_math.h — per-observation arithmetic of the line bundle adjustment,
+// shared by every LBA kernel (and compiled for the host by tests/ to cross-check it against the
+// oracle's dual-number Jacobians without a GPU).
+//
+// What it replaces: the reference evaluates `LineReprojectionError::operator()<Jet<double,10>>`
+// (reference src/lba_problem.h:46-118) through ceres::AutoDiffCostFunction<...,4,6,4>
+// (src/lba_problem.cpp:65-74) once per observation.  Here the same residual is differentiated
+// analytically and factored so that the expensive pieces are computed once per owner instead of
+// once per observation:
+//   per camera  : R(w) and the SO(3) left Jacobian JL(w) (cam_prepare)        — 1 sincos pair
+//   per line    : sin/cos table of (a,b,g) and cot(t)   (line_trig)          — the only other trig
+//   per obs     : 4 residuals, J_cam 4x6, J_line 4x4    (obs_linearise)      — FMAs, 2 rsqrt
+//
+// Derivation (SURVEY.md 8a "Analytic-Jacobian recipe"): with P_k = R cp + t - k B e_x,
+// dc = R dv, n = P_k x dc, s = sqrt(n0^2+n1^2), m = n/s, r = -(x m0 + y m1 + m2):
+//   q  = dr/dn  = -([x y 1] - rho [m0 m1 0]) / s,  rho = -r
+//   gP = dr/dP  = dc x q,     gD = dr/ddc = q x P
+//   dr/dt = gP;  dr/dw = ((R cp) x gP + dc x gD)^T JL(w)   [d(R p)/dw = -[R p]x JL];
+//   dr/du_j = (R^T gP).dcp_j + (R^T gD).ddv_j
+#ifndef SLSLAM_LBA_MATH_H_
+#define SLSLAM_LBA_MATH_H_
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define SLS_HD __host__ __device__ __forceinline__
+#else
+#define SLS_HD inline
+#endif
+
+namespace slslam {
+
+// Rotation matrix (row-major) of the angle-axis w and the left Jacobian of SO(3),
+//   d(R(w) p)/dw = -[R p]x JL(w),   JL = (sin t/t) I + ((1-cos t)/t) [u]x + (1 - sin t/t) u u^T.
+// Value follows ceres::AngleAxisRotatePoint as used at lba_problem.h:75-76:
+// R = c I + s [u]x + (1-c) u u^T for theta > 0 and the first-order branch I + [w]x at theta == 0
+// (hit by every solve: the newest keyframe is exactly identity, slam.cpp:1322), where JL = I.
+template <typename T>
+SLS_HD void cam_prepare(const T w[3], T R[9], T JL[9]) {
+  const T th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  if (th2 > T(0)) {
+    const T th = sqrt(th2);
+    const T ith = T(1) / th;
+    const T u[3] = { w[0] * ith, w[1] * ith, w[2] * ith };
+    const T s = sin(th), c = cos(th);
+    const T sh = sin(T(0.5) * th);
+    const T omc = T(2) * sh * sh;                       // 1 - cos(theta) without cancellation
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) R[3 * i + j] = omc * u[i] * u[j] + (i == j ? c : T(0));
+    R[1] += -s * u[2]; R[2] += s * u[1];
+    R[3] += s * u[2];  R[5] += -s * u[0];
+    R[6] += -s * u[1]; R[7] += s * u[0];
+    const T sot = s * ith, oot = omc * ith, rem = T(1) - sot;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) JL[3 * i + j] = rem * u[i] * u[j] + (i == j ? sot : T(0));
+    JL[1] += -oot * u[2]; JL[2] += oot * u[1];
+    JL[3] += oot * u[2];  JL[5] += -oot * u[0];
+    JL[6] += -oot * u[1]; JL[7] += oot * u[0];
+  } else {
+    R[0] = T(1); R[1] = -w[2]; R[2] = w[1];
+    R[3] = w[2]; R[4] = T(1); R[5] = -w[0];
+    R[6] = -w[1]; R[7] = w[0]; R[8] = T(1);
+    for (int k = 0; k < 9; ++k) JL[k] = T(0);
+    JL[0] = JL[4] = JL[8] = T(1);
+  }
+}
+
+// Rotation only (candidate-cost evaluation needs no derivative).
+template <typename T>
+SLS_HD void cam_rotation(const T w[3], T R[9]) {
+  const T th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  if (th2 > T(0)) {
+    const T th = sqrt(th2);
+    const T ith = T(1) / th;
+    const T u[3] = { w[0] * ith, w[1] * ith, w[2] * ith };
+    const T s = sin(th), c = cos(th);
+    const T sh = sin(T(0.5) * th);
+    const T omc = T(2) * sh * sh;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) R[3 * i + j] = omc * u[i] * u[j] + (i == j ? c : T(0));
+    R[1] += -s * u[2]; R[2] += s * u[1];
+    R[3] += s * u[2];  R[5] += -s * u[0];
+    R[6] += -s * u[1]; R[7] += s * u[0];
+  } else {
+    R[0] = T(1); R[1] = -w[2]; R[2] = w[1];
+    R[3] = w[2]; R[4] = T(1); R[5] = -w[0];
+    R[6] = -w[1]; R[7] = w[0]; R[8] = T(1);
+  }
+}
+
+// sin/cos table of the orthonormal line parameters (lba_problem.h:56-63):
+// trig = {s1,c1,s2,c2,s3,c3,d} with d = cos(t)/sin(t).
+template <typename T>
+SLS_HD void line_trig(const T u[4], T trig[7]) {
+  trig[0] = sin(u[0]); trig[1] = cos(u[0]);
+  trig[2] = sin(u[1]); trig[3] = cos(u[1]);
+  trig[4] = sin(u[2]); trig[5] = cos(u[2]);
+  trig[6] = cos(u[3]) / sin(u[3]);
+}
+
+// Closest point cp = -d col2 and direction dv = col1 of R_l = Rz(g) Ry(b) Rx(a)
+// (lba_problem.h:66-72), from the trig table.
+template <typename T>
+SLS_HD void line_points(const T trig[7], T cp[3], T dv[3]) {
+  const T s1 = trig[0], c1 = trig[1], s2 = trig[2], c2 = trig[3], s3 = trig[4], c3 = trig[5], d = trig[6];
+  cp[0] = -(c1 * s2 * c3 + s1 * s3) * d;
+  cp[1] = -(c1 * s2 * s3 - s1 * c3) * d;
+  cp[2] = -(c1 * c2) * d;
+  dv[0] = s1 * s2 * c3 - c1 * s3;
+  dv[1] = s1 * s2 * s3 + c1 * c3;
+  dv[2] = s1 * c2;
+}
+
+// cp, dv and their partials w.r.t. (a,b,g,t): dcp[j] = d cp / d u_j, ddv[j] = d dv / d u_j
+// (ddv[3] == 0 and is not stored).
+template <typename T>
+SLS_HD void line_points_jac(const T trig[7], T cp[3], T dv[3], T dcp[12], T ddv[9]) {
+  const T s1 = trig[0], c1 = trig[1], s2 = trig[2], c2 = trig[3], s3 = trig[4], c3 = trig[5], d = trig[6];
+  const T col0[3] = { c2 * c3, c2 * s3, -s2 };
+  const T col2[3] = { c1 * s2 * c3 + s1 * s3, c1 * s2 * s3 - s1 * c3, c1 * c2 };
+  dv[0] = s1 * s2 * c3 - c1 * s3;
+  dv[1] = s1 * s2 * s3 + c1 * c3;
+  dv[2] = s1 * c2;
+  for (int i = 0; i < 3; ++i) cp[i] = -d * col2[i];
+  // a: d col1 = col2, d col2 = -col1
+  for (int i = 0; i < 3; ++i) { dcp[i] = d * dv[i]; ddv[i] = col2[i]; }
+  // b: d col1 = s1 col0, d col2 = c1 col0
+  for (int i = 0; i < 3; ++i) { dcp[3 + i] = -d * c1 * col0[i]; ddv[3 + i] = s1 * col0[i]; }
+  // g: d col = e_z x col
+  dcp[6] = d * col2[1]; dcp[7] = -d * col2[0]; dcp[8] = T(0);
+  ddv[6] = -dv[1];      ddv[7] = dv[0];        ddv[8] = T(0);
+  // t: d d/dt = -(1 + d^2)
+  const T dd = T(1) + d * d;
+  for (int i = 0; i < 3; ++i) dcp[9 + i] = dd * col2[i];
+}
+
+// 4 residuals of one stereo observation (lba_problem.h:75-115); no derivatives.
+template <typename T>
+SLS_HD void obs_residual(const T R[9], const T t[3], const T cp[3], const T dv[3],
+                         const T ob[8], T baseline, T r[4]) {
+  T P[3], dc[3];
+  for (int i = 0; i < 3; ++i) {
+    P[i] = R[3 * i] * cp[0] + R[3 * i + 1] * cp[1] + R[3 * i + 2] * cp[2] + t[i];
+    dc[i] = R[3 * i] * dv[0] + R[3 * i + 1] * dv[1] + R[3 * i + 2] * dv[2];
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (k == 1) P[0] -= baseline;
+    const T n0 = P[1] * dc[2] - P[2] * dc[1];
+    const T n1 = P[2] * dc[0] - P[0] * dc[2];
+    const T n2 = P[0] * dc[1] - P[1] * dc[0];
+    const T is = T(1) / sqrt(n0 * n0 + n1 * n1);
+    const T m0 = n0 * is, m1 = n1 * is, m2 = n2 * is;
+    r[2 * k] = -(ob[4 * k] * m0 + ob[4 * k + 1] * m1 + m2);
+    r[2 * k + 1] = -(ob[4 * k + 2] * m0 + ob[4 * k + 3] * m1 + m2);
+  }
+}
+
+// Residuals and row-major Jacobians Jc[4][6] (w, t) and Jl[4][4] (a, b, g, t).
+template <typename T>
+SLS_HD void obs_linearise(const T R[9], const T JL[9], const T t[3],
+                          const T cp[3], const T dv[3], const T dcp[12], const T ddv[9],
+                          const T ob[8], T baseline, T r[4], T Jc[24], T Jl[16]) {
+  T Q[3], P[3], dc[3];
+  for (int i = 0; i < 3; ++i) {
+    Q[i] = R[3 * i] * cp[0] + R[3 * i + 1] * cp[1] + R[3 * i + 2] * cp[2];
+    P[i] = Q[i] + t[i];
+    dc[i] = R[3 * i] * dv[0] + R[3 * i + 1] * dv[1] + R[3 * i + 2] * dv[2];
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (k == 1) P[0] -= baseline;
+    const T n0 = P[1] * dc[2] - P[2] * dc[1];
+    const T n1 = P[2] * dc[0] - P[0] * dc[2];
+    const T n2 = P[0] * dc[1] - P[1] * dc[0];
+    const T is = T(1) / sqrt(n0 * n0 + n1 * n1);
+    const T m0 = n0 * is, m1 = n1 * is, m2 = n2 * is;
+    for (int e = 0; e < 2; ++e) {
+      const int row = 2 * k + e;
+      const T x = ob[4 * k + 2 * e], y = ob[4 * k + 2 * e + 1];
+      const T rho = x * m0 + y * m1 + m2;
+      r[row] = -rho;
+      const T q0 = -(x - rho * m0) * is, q1 = -(y - rho * m1) * is, q2 = -is;
+      const T gP[3] = { dc[1] * q2 - dc[2] * q1, dc[2] * q0 - dc[0] * q2, dc[0] * q1 - dc[1] * q0 };
+      const T gD[3] = { q1 * P[2] - q2 * P[1], q2 * P[0] - q0 * P[2], q0 * P[1] - q1 * P[0] };
+      // tau = (R cp) x gP + dc x gD ;  dr/dw = tau^T JL
+      const T tau[3] = { Q[1] * gP[2] - Q[2] * gP[1] + dc[1] * gD[2] - dc[2] * gD[1],
+                         Q[2] * gP[0] - Q[0] * gP[2] + dc[2] * gD[0] - dc[0] * gD[2],
+                         Q[0] * gP[1] - Q[1] * gP[0] + dc[0] * gD[1] - dc[1] * gD[0] };
+      T* jc = Jc + 6 * row;
+      for (int j = 0; j < 3; ++j) jc[j] = tau[0] * JL[j] + tau[1] * JL[3 + j] + tau[2] * JL[6 + j];
+      jc[3] = gP[0]; jc[4] = gP[1]; jc[5] = gP[2];
+      T hP[3], hD[3];                                    // R^T gP, R^T gD
+      for (int i = 0; i < 3; ++i) {
+        hP[i] = R[i] * gP[0] + R[3 + i] * gP[1] + R[6 + i] * gP[2];
+        hD[i] = R[i] * gD[0] + R[3 + i] * gD[1] + R[6 + i] * gD[2];
+      }
+      T* jl = Jl + 4 * row;
+      for (int j = 0; j < 3; ++j)
+        jl[j] = hP[0] * dcp[3 * j] + hP[1] * dcp[3 * j + 1] + hP[2] * dcp[3 * j + 2]
+              + hD[0] * ddv[3 * j] + hD[1] * ddv[3 * j + 1] + hD[2] * ddv[3 * j + 2];
+      jl[3] = hP[0] * dcp[9] + hP[1] * dcp[10] + hP[2] * dcp[11];
+    }
+  }
+}
+
+// ceres::HuberLoss(a) + Corrector for rho'' <= 0 (lba_problem.cpp:78-80): returns the factor
+// sqrt(rho') that scales both residual and Jacobian, and the block cost rho/2.
+// a <= 0 disables the loss (FLAGS_robust = false).
+template <typename T>
+SLS_HD T huber_scale(T s, T a, T* cost) {
+  if (a > T(0) && s > a * a) {
+    const T rn = sqrt(s);
+    *cost = T(0.5) * (T(2) * a * rn - a * a);
+    return sqrt(a / rn);
+  }
+  *cost = T(0.5) * s;
+  return T(1);
+}
+
+}  // namespace slslam
+#endif  // SLSLAM_LBA_MATH_H_

@@ -1,0 +1,47 @@
+// slslam_amd/csrc/lba_pack.h — host-side "build" stage of the LBA batch: validates the caller's
+// arrays and reorders them into the HBM layout of lba_types.h.
+//
+// Mirrors what LBAProblem::build does for Ceres (reference src/lba_problem.cpp:54-93): one residual
+// block per observation wired to camera block camera_index[i] and line block line_index[i]
+// (:83-84), a block is constant if ANY observation flags it (:88-91).  Instead of M heap-allocated
+// cost functions the build emits:
+//   * lines sorted by observation count class (group width 2^g), observations grouped by line with
+//     the free-camera observations first (ascending free index),
+//   * tiles (one 64-lane pass each), the balanced list of off-diagonal camera-pair work items per
+//     tile, and chunks (runs of tiles handled by one wave).
+// Pure host C++ (no HIP), so the CPU test-suite can check its invariants.
+#ifndef SLSLAM_LBA_PACK_H_
+#define SLSLAM_LBA_PACK_H_
+
+#include <vector>
+#include <cstdint>
+#include "lba_types.h"
+#include "../../include/slslam_hip.h"
+
+namespace slslam {
+
+struct PackedWindow {
+  int C = 0, Cf = 0, L = 0, M = 0;
+  int nfree_params = 0, nkept = 0;
+  std::vector<int> cam_cf;          // [C]  free index or -1
+  std::vector<double> cam_x;        // [C*6] initial
+  std::vector<int> line_order;      // [L]  sorted position -> original line
+  std::vector<int> line_flags;      // [L]  sorted; bit0 constant
+  std::vector<double> line_u;       // [L*4] sorted; initial (a,b,g,t)
+  std::vector<int> line_ptr;        // [L+1] sorted; window-local offsets into the sorted observations
+  std::vector<int> ob_orig;         // [M]  sorted position -> original observation
+  std::vector<int> ob_cam;          // [M]  sorted
+  std::vector<double> ob;           // [8*M] SoA: ob[q*M + o]
+  std::vector<Tile> tiles;          // line_begin window-local; item_off window-local
+  std::vector<uint8_t> items;       // 2 bytes per item
+  std::vector<double> params0;      // caller's original parameter vector (for lines/cams never touched)
+};
+
+// Returns SLSLAM_OK or an error status; on error `out` is unspecified.
+int pack_window(const slslam_lba_window* w, PackedWindow* out);
+
+// Splits ntiles into chunks of at most tiles_per_chunk tiles; returns boundaries [nchunks+1].
+std::vector<int> chunk_boundaries(int ntiles, int tiles_per_chunk);
+
+}  // namespace slslam
+#endif

@@ -1,0 +1,123 @@
+// slslam_amd/csrc/lba_types.h — HBM data layout of a batch of LBA windows.
+//
+// Host code (lba_pack.cpp) builds these arrays once per batch ("LBAProblem::build" stage,
+// reference src/lba_problem.cpp:54-93); the kernels in lba_kernels.hip only read them, except for
+// the double-buffered parameter records and the per-window LM state.
+#ifndef SLSLAM_LBA_TYPES_H_
+#define SLSLAM_LBA_TYPES_H_
+
+#include <stdint.h>
+
+namespace slslam {
+
+enum { kRunning = -1 };                 // LMState.status while the window is still iterating
+enum { kMaxTrace = 64 };                // iteration records kept per window
+enum { kLineRec = 12 };                 // doubles per line record: u[4], trig[7], pad
+enum { kCamRec = 6 };                   // doubles per camera record: w[3], t[3]
+enum { kSlabScalars = 8 };              // per-chunk scalars written by the linearise kernel
+enum { kMaxCams = 64, kMaxFreeCams = 20 };
+
+// per-chunk scalar slots (linearise kernel)
+enum { kScCost = 0, kScFixedCost = 1, kScGradMaxLine = 2, kScXn2Line = 3, kScFail = 4 };
+// per-chunk scalar slots (back-substitution kernel)
+enum { kBsModel = 0, kBsDn2 = 1, kBsXn2 = 2, kBsStride = 4 };
+
+struct WinDesc {
+  int C, Cf, L, M;        // cameras, free cameras, lines, observations
+  int cam_off;            // first camera record
+  int line_off;           // first (sorted) line record
+  int obs_off;            // first (sorted) observation
+  int tile_off, ntiles;
+  int chunk_off, nchunks;
+  int n;                  // 6 * Cf, order of the reduced camera system
+  int sys_off;            // offset (doubles) of this window's y_c vector
+  int nfree_params;       // 6 Cf + 4 (free lines with >= 1 kept block)
+  int nkept;              // residual blocks in the reduced program
+  int pad;
+};
+
+// A tile is one 64-lane pass: 64 >> glog2 consecutive (sorted) lines, each owning a group of
+// 1 << glog2 lanes; lane (l, j) handles observation line_ptr[l] + j.
+struct Tile {
+  int line_begin;         // global sorted line index of the first line
+  int16_t nlines;
+  int16_t glog2;
+  int item_off;           // off-diagonal camera-pair work items of this tile
+  int nitems;
+};
+
+struct Chunk {
+  int win;
+  int tile_begin, tile_end;   // global tile indices
+  int slab_off;               // doubles; slab = [S tri(n)] [b n] [g n] [hdiag n] [scalars]
+};
+
+// Levenberg-Marquardt state of one window (restates the locals of Ceres 1.7
+// TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy; policy table in DESIGN.md §5).
+struct LMState {
+  double radius;
+  double decrease_factor;
+  double cost;              // reduced-program cost at the accepted point
+  double x_norm;
+  double fixed_cost;
+  double initial_cost;      // incl. fixed cost
+  double min_cost;          // min over recorded iteration costs (incl. fixed cost)
+  double abs_grad_tol;
+  double grad_max;          // |g|_inf at the accepted point
+  double cam_model, cam_dn2, cam_xn2;   // camera parts of the step statistics (reduced solve)
+  int status;               // kRunning or a SLSLAM_* termination type
+  int cur;                  // which parameter buffer holds the accepted point
+  int iter;                 // iterations recorded so far
+  int n_success, n_unsuccess, n_invalid;
+  int solve_failed;
+  int need_grad_check;      // gradient at the accepted point not yet tested
+  int ntrace;
+  int pad;
+};
+
+struct IterRec {            // same fields as slslam_iteration
+  int iteration, step_is_valid, step_is_successful, pad;
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius,
+         model_cost_change;
+};
+
+struct Policy {             // numeric policy, by value into every kernel that needs it
+  double huber_delta, baseline;
+  double initial_radius, max_radius, min_radius;
+  double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  int max_num_iterations, max_invalid, jacobi_scaling, pad;
+};
+
+// Everything the kernels need, passed by value.
+struct BatchPtrs {
+  const WinDesc* wins;
+  const Tile* tiles;
+  const Chunk* chunks;
+  const uint8_t* items;       // 2 bytes per item: (lane_i, lane_j), camera(lane_i) <= camera(lane_j)
+  // cameras
+  double* cam_x;              // [ncam][2][6]
+  double* cam_scale;          // [ncam][6]
+  const int* cam_cf;          // [ncam] index among the window's free cameras, or -1
+  // lines (sorted order)
+  double* line_x;             // [nline][2][12]
+  double* line_scale;         // [nline][4]
+  const int* line_ptr;        // [nline+1] first sorted observation of each line
+  const int* line_flags;      // [nline] bit0: constant
+  const int* line_win;        // [nline]
+  // observations (sorted, structure of arrays)
+  const double* ob;           // [8][ob_stride]
+  const int* ob_cam;          // [nobs] window-local camera id
+  long long ob_stride;
+  // per-chunk / per-window work areas
+  double* slab;               // linearise/Schur partials
+  double* bs_part;            // [nchunk][kBsStride]
+  double* cost_part;          // [nchunk]
+  double* ysys;               // y_c per window (sys_off)
+  LMState* state;
+  IterRec* trace;             // [nwin][kMaxTrace]
+  int nwin, nchunk, nline, ncam;
+};
+
+}  // namespace slslam
+#endif
