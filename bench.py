@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py — LBA iterations/sec on synthetic 10-keyframe / ~2000-line windows (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: every rank solves its own batch of
+independent sliding windows (LBAProblem::build'ed once, resident in HBM) with the full
+Levenberg-Marquardt loop (max 10 iterations, Huber loss, Ceres-1.7 policy) through the C ABI.
+Work per GPU is fixed as N grows (weak scaling); there is no data-path collective, only one
+all-reduce of the run summary per timed region.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = LM iterations (successful + unsuccessful trust-region
+steps, as slam.cpp:949-950 counts them) of all ranks / max-over-ranks wall time of the K steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from slslam_amd import capi, synth  # noqa: E402
+from slslam_amd.dist import allreduce_summary  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes_linearise(counts):
+    """Algorithmic HBM bytes of ONE launch of the dominant kernel (linearise + Schur sweep):
+    SURVEY.md 8d per-window figure for one of the three observation sweeps,
+    M*(64+8) + L*32 + C*48 + (6 Cf)^2*8, summed over the windows the launch processes."""
+    return sum(72 * m + 32 * l + 48 * c + 8 * (6 * cf) ** 2 for (c, cf, l, m) in counts)
+
+
+def cpu_baseline(windows, budget_s=12.0):
+    """The oracle (oracle/*.c: Jet<10> autodiff + Huber + Ceres-1.7 LM + block Schur, one thread,
+    as the reference pins Ceres to num_threads = 1) timed on this host on a bounded sample of the
+    SAME windows.  Returns (iterations/s, description, solved parameters list)."""
+    from oracle import pyoracle          # cpu_baseline leg only
+    its, t0, outs = 0, time.perf_counter(), []
+    for w in windows:
+        x, s, _ = pyoracle.lba_solve(w, linear_solver=1)
+        its += s["num_successful_steps"] + s["num_unsuccessful_steps"]
+        outs.append(x)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return its / dt, "%d of the bench windows (%.1f s, %d LM iterations), 1 thread" % (len(outs), dt, its), outs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--windows", type=int, default=1024, help="independent windows per GPU")
+    ap.add_argument("--lines", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph (no per-kernel events)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- synthetic inputs of the named shape, distinct per rank, resident in HBM before timing
+    B = args.windows
+    windows = [synth.make_window(1_000_000 * rank + i, num_lines=args.lines) for i in range(B)]
+    batch = capi.LBABatch(device=local_rank)
+    for w in windows:
+        batch.add(w)
+    batch.finalize(use_graph=1 if args.graph else 0)
+    batch.set_profiling(not args.graph)
+    stream = torch.cuda.current_stream().cuda_stream
+    counts = [(w["num_cameras"], w["num_free_cameras"], w["num_lines"], len(w["camera_index"])) for w in windows]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.reset(stream)
+        batch.solve(stream)
+    torch.cuda.synchronize()
+    batch.iterations(stream, clear=True)
+    batch.set_profiling(not args.graph)          # drop warm-up events
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.reset(stream)
+        batch.solve(stream)
+    iters_local = batch.iterations(stream)        # synchronises the stream
+    iters_total, _, _ = allreduce_summary(iters_local, 0.0, 0.0, device=dev)
+    barrier()
+    dt_local = time.perf_counter() - t0
+    t = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- results of the last step (outside the timed region)
+    batch.download(stream)
+    summaries = [batch.summary(i) for i in range(B)]
+    init_cost = sum(s["initial_cost"] for s in summaries)
+    final_cost = sum(s["final_cost"] for s in summaries)
+
+    if rank == 0:
+        out = {
+            "metric": "LBA iterations/sec (10-KF window, ~2k lines)",
+            "value": iters_total / elapsed,
+            "unit": "LM iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic 10 free + 10 fixed keyframe window, %d lines, ~%d observations; "
+                                   "full LM solve (Huber, <=10 iterations, Schur + back-substitution)" % (
+                                       args.lines, int(np.mean([c[3] for c in counts]))),
+                       "windows_per_gpu": B, "lines": args.lines, "parallelism": "windows sharded over %d GPU(s)" % world,
+                       "launch": "hipGraph replay" if args.graph else "eager + hipEvents"},
+            "lm_iterations": iters_total,
+            "sum_initial_cost_rank0": init_cost, "sum_final_cost_rank0": final_cost,
+        }
+        kt = batch.kernel_times()
+        ms, n = kt["linearise_schur"]
+        if n > 0:
+            bytes_launch = algorithmic_bytes_linearise(counts)
+            achieved = bytes_launch / (ms / n * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("windows") == B and tj.get("lines") == args.lines:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": "k_linearise_schur", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": ms / n, "launches": n}
+            out["kernel_ms_per_step"] = {k: v[0] / max(args.steps, 1) for k, v in kt.items() if v[1] > 0}
+        if world == 1 and not args.no_cpu_baseline:
+            v, sample, outs = cpu_baseline(windows)
+            out["cpu_baseline"] = {"value": v, "unit": "LM iterations/s", "cores": 1, "kind": "port", "sample": sample,
+                                   "host_cores_available": os.cpu_count()}
+            # trajectory error of the GPU solve against the oracle solve of the same windows
+            err = []
+            for i, xo in enumerate(outs):
+                xg = batch.parameters(i)
+                nf = 6 * windows[i]["num_free_cameras"]
+                err.append(np.linalg.norm(synth.camera_centers(xg[:nf]) - synth.camera_centers(xo[:nf]), axis=1))
+            err = np.concatenate(err)
+            out["traj_error_vs_oracle"] = {"rms_m": float(np.sqrt((err ** 2).mean())), "mean_m": float(err.mean()),
+                                           "keyframes": int(err.size)}
+        print(json.dumps(out))
+    batch.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

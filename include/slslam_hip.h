@@ -139,6 +139,10 @@ int  slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solver_options*
 int  slslam_lba_batch_solve(slslam_lba_batch* b, void* stream);
 /* Restores the initial parameters on the device (for repeated timing of the same inputs). */
 int  slslam_lba_batch_reset(slslam_lba_batch* b, void* stream);
+/* Trust-region steps (successful + unsuccessful, the count the reference accumulates at
+ * src/slam.cpp:949-950) executed by all windows since the counter was last cleared; synchronises
+ * the stream.  Lets a bench count iterations over several solves without per-window downloads. */
+int  slslam_lba_batch_iterations(slslam_lba_batch* b, void* stream, long long* iterations, int clear);
 /* Blocks until the stream's work is done and copies parameters + summaries back to the host. */
 int  slslam_lba_batch_download(slslam_lba_batch* b, void* stream);
 /* After download: solved parameters of window `index` in the caller's original layout. */
@@ -153,7 +157,8 @@ int  slslam_lba_batch_export_device(slslam_lba_batch* b, double* device_out, voi
 int  slslam_lba_batch_counts(const slslam_lba_batch* b, long long* num_windows, long long* num_cameras,
                              long long* num_free_cameras, long long* num_lines, long long* num_observations);
 /* Device time (ms) spent in each kernel family during the last solve, measured with HIP events
- * on the solve stream when profiling is enabled (disables graph replay for that solve).
+ * on the solve stream while profiling is enabled (solves are then launched eagerly instead of
+ * replaying the captured graph); times accumulate over solves until set_profiling is called again.
  * names: 0 linearise+schur, 1 reduced solve, 2 back-substitution, 3 line trig, 4 candidate cost,
  * 5 LM update, 6 init.  launches[i] receives the number of launches. */
 int  slslam_lba_batch_set_profiling(slslam_lba_batch* b, int enable);

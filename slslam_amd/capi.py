@@ -70,7 +70,7 @@ EXPORTS = [
     "slslam_lba_batch_add", "slslam_lba_batch_finalize", "slslam_lba_batch_solve", "slslam_lba_batch_reset",
     "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts",
-    "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
+    "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
     "slslam_po_solve", "slslam_device_count", "slslam_version", "slslam_status_string",
 ]
 
@@ -103,6 +103,7 @@ def lib():
     L.slslam_lba_batch_get_trace.argtypes = [vp, C.c_int, C.POINTER(Iteration), C.c_int, ip]
     L.slslam_lba_batch_export_device.argtypes = [vp, vp, vp]
     L.slslam_lba_batch_counts.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 5
+    L.slslam_lba_batch_iterations.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.c_int]
     L.slslam_lba_batch_set_profiling.argtypes = [vp, C.c_int]
     L.slslam_lba_batch_kernel_times.argtypes = [vp, dp, ip]
     L.slslam_lba_batch_linearise.argtypes = [vp, C.c_int, dp, dp, dp, dp]
@@ -250,6 +251,12 @@ class LBABatch:
         v = [C.c_longlong(0) for _ in range(5)]
         _check(lib().slslam_lba_batch_counts(self._h, *[C.byref(x) for x in v]), "slslam_lba_batch_counts")
         return dict(zip(["windows", "cameras", "free_cameras", "lines", "observations"], [x.value for x in v]))
+
+    def iterations(self, stream=None, clear=False):
+        v = C.c_longlong(0)
+        _check(lib().slslam_lba_batch_iterations(self._h, C.c_void_p(stream or 0), C.byref(v), int(clear)),
+               "slslam_lba_batch_iterations")
+        return v.value
 
     def total_parameters(self):
         return sum(6 * c + 4 * l for c, l in self.sizes)

@@ -119,6 +119,7 @@ struct slslam_lba_batch {
   bool downloaded = false;
   // device
   DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<uint8_t> d_items;
+  DevBuf<unsigned long long> d_iter_counter;
   DevBuf<double> d_cam_x, d_cam_x0, d_cam_scale; DevBuf<int> d_cam_cf, d_cam_win;
   DevBuf<double> d_line_x, d_line_x0, d_line_scale; DevBuf<int> d_line_ptr, d_line_flags, d_line_win, d_line_orig;
   DevBuf<double> d_ob; DevBuf<int> d_ob_cam, d_ob_orig;
@@ -144,7 +145,7 @@ struct slslam_lba_batch {
     d_line_x.release(); d_line_x0.release(); d_line_scale.release(); d_line_ptr.release(); d_line_flags.release();
     d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release();
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
-    d_state.release(); d_trace.release(); d_param_off.release();
+    d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release();
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     if (capture_stream) { (void)hipStreamDestroy(capture_stream); capture_stream = nullptr; }
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -197,7 +198,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
 
   // ---- global layout
   std::vector<Tile> tiles; std::vector<Chunk> chunks; std::vector<uint8_t> items;
-  std::vector<double> cam_x, line_x, ob; std::vector<int> cam_cf, cam_win, line_ptr, line_flags, line_win, line_orig, ob_cam, ob_orig;
+  std::vector<double> cam_x, line_x, ob, cam_x0, line_u0; std::vector<int> cam_cf, cam_win, line_ptr, line_flags, line_win, line_orig, ob_cam, ob_orig;
   long long ncam = 0, nline = 0, nobs = 0, sys = 0, slab = 0, param_off = 0;
   long long total_tiles = 0;
   for (const PackedWindow& P : b->wins) total_tiles += (long long)P.tiles.size();
@@ -238,6 +239,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     items.insert(items.end(), P.items.begin(), P.items.end());
     for (int c = 0; c < P.C; ++c) {
       for (int buf = 0; buf < 2; ++buf) for (int a = 0; a < 6; ++a) cam_x.push_back(P.cam_x[6 * (size_t)c + a]);
+      for (int a = 0; a < 6; ++a) cam_x0.push_back(P.cam_x[6 * (size_t)c + a]);
       cam_cf.push_back(P.cam_cf[c]); cam_win.push_back(wi);
     }
     for (int s = 0; s < P.L; ++s) {
@@ -245,6 +247,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
         for (int a = 0; a < 4; ++a) line_x.push_back(P.line_u[4 * (size_t)s + a]);
         for (int a = 4; a < kLineRec; ++a) line_x.push_back(0.0);
       }
+      for (int a = 0; a < 4; ++a) line_u0.push_back(P.line_u[4 * (size_t)s + a]);
       line_ptr.push_back((int)obs_cursor + P.line_ptr[s]);
       line_flags.push_back(P.line_flags[s]); line_win.push_back(wi); line_orig.push_back(P.line_order[s]);
     }
@@ -275,14 +278,16 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if ((rc = b->d_items.upload(items))) return rc;
   if (cam_x.empty()) cam_x.assign(12, 0.0);
   if ((rc = b->d_cam_x.upload(cam_x))) return rc;
-  if ((rc = b->d_cam_x0.upload(cam_x))) return rc;
+  if (cam_x0.empty()) cam_x0.assign(6, 0.0);
+  if ((rc = b->d_cam_x0.upload(cam_x0))) return rc;
   if ((rc = b->d_cam_scale.alloc(std::max<size_t>(6, (size_t)6 * ncam)))) return rc;
   if (cam_cf.empty()) { cam_cf.push_back(-1); cam_win.push_back(0); }
   if ((rc = b->d_cam_cf.upload(cam_cf))) return rc;
   if ((rc = b->d_cam_win.upload(cam_win))) return rc;
   if (line_x.empty()) line_x.assign(2 * kLineRec, 0.0);
   if ((rc = b->d_line_x.upload(line_x))) return rc;
-  if ((rc = b->d_line_x0.upload(line_x))) return rc;
+  if (line_u0.empty()) line_u0.assign(4, 0.0);
+  if ((rc = b->d_line_x0.upload(line_u0))) return rc;
   if ((rc = b->d_line_scale.alloc(std::max<size_t>(4, (size_t)4 * nline)))) return rc;
   if ((rc = b->d_line_ptr.upload(line_ptr))) return rc;
   if (line_flags.empty()) { line_flags.push_back(1); line_win.push_back(0); line_orig.push_back(0); }
@@ -302,6 +307,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if ((rc = b->d_state.upload(b->h_state0))) return rc;
   if ((rc = b->d_trace.alloc(std::max<size_t>(1, (size_t)B * kMaxTrace)))) return rc;
   if ((rc = b->d_param_off.upload(b->h_param_off))) return rc;
+  if ((rc = b->d_iter_counter.alloc(1))) return rc;
+  HIP_TRY(hipMemset(b->d_iter_counter.p, 0, sizeof(unsigned long long)));
   HIP_TRY(hipMemset(b->d_trace.p, 0, b->d_trace.n * sizeof(IterRec)));
   HIP_TRY(hipMemset(b->d_cam_scale.p, 0, b->d_cam_scale.n * sizeof(double)));
   HIP_TRY(hipMemset(b->d_line_scale.p, 0, b->d_line_scale.n * sizeof(double)));
@@ -314,6 +321,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.ob = b->d_ob.p; p.ob_cam = b->d_ob_cam.p; p.ob_stride = std::max<long long>(1, nobs);
   p.slab = b->d_slab.p; p.bs_part = b->d_bs_part.p; p.cost_part = b->d_cost_part.p; p.ysys = b->d_ysys.p;
   p.state = b->d_state.p; p.trace = b->d_trace.p;
+  p.iter_counter = b->d_iter_counter.p; p.cam_x0 = b->d_cam_x0.p; p.line_u0 = b->d_line_x0.p;
   p.nwin = B; p.nchunk = b->nchunk; p.nline = b->nline; p.ncam = b->ncam;
 
   b->lds_lin = sizeof(double) * (size_t)lds_doubles_linearise(maxC, maxn);
@@ -398,11 +406,7 @@ extern "C" int slslam_lba_batch_solve(slslam_lba_batch* b, void* stream) {
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
   b->downloaded = false;
-  if (b->profiling) {
-    for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
-    b->ev_pool.clear(); b->ev_used.clear();
-    return enqueue_solve(b, s, true);
-  }
+  if (b->profiling) return enqueue_solve(b, s, true);   // events accumulate until set_profiling()
   if (!b->opt.use_graph) return enqueue_solve(b, s, false);
   if (!b->graph_exec) {
     // capture the whole solve (3 + 6 * max_iter launches) once; replay costs one host call
@@ -426,10 +430,24 @@ extern "C" int slslam_lba_batch_reset(slslam_lba_batch* b, void* stream) {
   if (!b->finalized) return SLSLAM_ERR_STATE;
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipMemcpyAsync(b->d_cam_x.p, b->d_cam_x0.p, b->d_cam_x.n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemcpyAsync(b->d_line_x.p, b->d_line_x0.p, b->d_line_x.n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemcpyAsync(b->d_state.p, b->h_state0.data(), b->h_state0.size() * sizeof(LMState), hipMemcpyHostToDevice, s));
+  const long long total = (long long)b->ncam + b->nline + b->ptrs.nwin;
+  if (total > 0)
+    hipLaunchKernelGGL(k_reset, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b->ptrs, b->pol);
+  HIP_TRY(hipGetLastError());
   b->downloaded = false;
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_iterations(slslam_lba_batch* b, void* stream, long long* iterations, int clear) {
+  if (!b || !iterations) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b->finalized) return SLSLAM_ERR_STATE;
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, b->d_iter_counter.p, sizeof(v), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (clear) HIP_TRY(hipMemsetAsync(b->d_iter_counter.p, 0, sizeof(v), s));
+  *iterations = (long long)v;
   return SLSLAM_OK;
 }
 
@@ -527,6 +545,10 @@ extern "C" int slslam_lba_batch_counts(const slslam_lba_batch* b, long long* nw,
 extern "C" int slslam_lba_batch_set_profiling(slslam_lba_batch* b, int enable) {
   if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
   b->profiling = enable != 0;
+  (void)hipSetDevice(b->device);
+  for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
+  b->ev_pool.clear(); b->ev_used.clear();
+  for (int f = 0; f < FAM_N; ++f) { b->fam_ms[f] = 0.0; b->fam_launches[f] = 0; }
   return SLSLAM_OK;
 }
 

@@ -792,6 +792,7 @@ __global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol, int p
   if (rec.cost < st->min_cost) st->min_cost = rec.cost;
   push_trace(p, w, st, rec);
   st->iter = rec.iteration;
+  atomicAdd(p.iter_counter, 1ULL);   // one trust-region step (successful or not), as slam.cpp:949-950 counts
   if (st->radius < pol.min_radius) { st->status = 5; return; }
   if (st->iter >= pol.max_num_iterations) { st->status = 0; return; }
 }
@@ -828,6 +829,28 @@ __global__ __launch_bounds__(64) void k_debug_linearise(BatchPtrs p, Policy pol,
   }
   acc = wave_sum(acc);
   if (lane == 0) *out_cost = acc;
+}
+
+// Restores the initial parameters and LM state of every window (repeated solves of the same
+// inputs).  lane <-> parameter block / window.
+__global__ __launch_bounds__(256) void k_reset(BatchPtrs p, Policy pol) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < p.ncam) {
+    double* x = p.cam_x + (long long)i * 2 * kCamRec;
+    for (int a = 0; a < 6; ++a) { x[a] = p.cam_x0[(long long)i * 6 + a]; x[kCamRec + a] = x[a]; }
+  } else if (i < p.ncam + p.nline) {
+    const int ls = i - p.ncam;
+    double* x = p.line_x + (long long)ls * 2 * kLineRec;
+    for (int a = 0; a < 4; ++a) { x[a] = p.line_u0[(long long)ls * 4 + a]; x[kLineRec + a] = x[a]; }
+  } else if (i < p.ncam + p.nline + p.nwin) {
+    LMState* st = p.state + (i - p.ncam - p.nline);
+    LMState z;
+    z.radius = pol.initial_radius; z.decrease_factor = 2.0; z.cost = 0; z.x_norm = 0; z.fixed_cost = 0;
+    z.initial_cost = 0; z.min_cost = 0; z.abs_grad_tol = 0; z.grad_max = 0; z.cam_model = 0; z.cam_dn2 = 0; z.cam_xn2 = 0;
+    z.status = kRunning; z.cur = 0; z.iter = 0; z.n_success = 0; z.n_unsuccess = 0; z.n_invalid = 0;
+    z.solve_failed = 0; z.need_grad_check = 0; z.ntrace = 0; z.pad = 0;
+    *st = z;
+  }
 }
 
 // Gathers the accepted parameters of every window into the caller's layout

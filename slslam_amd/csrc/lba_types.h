@@ -116,6 +116,9 @@ struct BatchPtrs {
   double* ysys;               // y_c per window (sys_off)
   LMState* state;
   IterRec* trace;             // [nwin][kMaxTrace]
+  unsigned long long* iter_counter;   // LM iterations executed by the batch since the counter was cleared
+  const double* cam_x0;       // [ncam][6] initial camera poses (reset)
+  const double* line_u0;      // [nline][4] initial line parameters (reset)
   int nwin, nchunk, nline, ncam;
 };
 

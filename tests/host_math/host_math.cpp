@@ -22,3 +22,33 @@ void hm_obs_residual(const double* cam, const double* line, const double* obs, d
 }
 double hm_huber(double s, double a, double* cost) { return slslam::huber_scale<double>(s, a, cost); }
 }
+
+// ---- pack inspection (host-only code of the product, lba_pack.cpp)
+#include "../../slslam_amd/csrc/lba_pack.h"
+#include <cstring>
+extern "C" {
+// Packs one window and copies the layout into caller buffers (sized generously by the test).
+int hm_pack(int C, int L, int M, const int* cam, const int* line, const int* fixed, const double* obs, double* params,
+            int* out_counts /*Cf, ntiles, nitems, nfree_params, nkept*/, int* line_order, int* line_ptr, int* ob_orig,
+            int* ob_cam, int* tiles /*4 ints per tile: line_begin,nlines,glog2,nitems*/, unsigned char* items, int* cam_cf,
+            int max_tiles, int max_items) {
+  slslam_lba_window w{C, L, M, cam, line, fixed, obs, params};
+  slslam::PackedWindow P;
+  const int rc = slslam::pack_window(&w, &P);
+  if (rc) return rc;
+  if ((int)P.tiles.size() > max_tiles || (int)P.items.size() / 2 > max_items) return -1;
+  out_counts[0] = P.Cf; out_counts[1] = (int)P.tiles.size(); out_counts[2] = (int)P.items.size() / 2;
+  out_counts[3] = P.nfree_params; out_counts[4] = P.nkept;
+  std::memcpy(line_order, P.line_order.data(), sizeof(int) * L);
+  std::memcpy(line_ptr, P.line_ptr.data(), sizeof(int) * (L + 1));
+  std::memcpy(ob_orig, P.ob_orig.data(), sizeof(int) * M);
+  std::memcpy(ob_cam, P.ob_cam.data(), sizeof(int) * M);
+  std::memcpy(cam_cf, P.cam_cf.data(), sizeof(int) * C);
+  for (size_t t = 0; t < P.tiles.size(); ++t) {
+    tiles[4 * t] = P.tiles[t].line_begin; tiles[4 * t + 1] = P.tiles[t].nlines;
+    tiles[4 * t + 2] = P.tiles[t].glog2; tiles[4 * t + 3] = P.tiles[t].nitems;
+  }
+  std::memcpy(items, P.items.data(), P.items.size());
+  return 0;
+}
+}

@@ -1,0 +1,217 @@
+"""GPU parity tests of the line bundle adjustment: the HIP path (through the C ABI) against the
+oracle on the same seeded inputs, against the committed golden optimum, and - at the bench's full
+window size - through size-independent properties.  Everything here needs a real MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from slslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# fp64 on both sides: per-iteration quantities agree to round-off; the tolerance below only absorbs
+# the different summation order (wave shuffles / LDS atomics vs serial loops) and FMA contraction.
+REL = 1e-9
+
+
+def _assert_trace_parity(t_ref, t_hip, n=None):
+    assert len(t_ref) == len(t_hip)
+    for a, b in list(zip(t_ref, t_hip))[:n]:
+        assert a["iteration"] == b["iteration"]
+        assert a["step_is_successful"] == b["step_is_successful"] and a["step_is_valid"] == b["step_is_valid"]
+        assert abs(a["cost"] - b["cost"]) <= REL * abs(a["cost"])
+        assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-6 * a["trust_region_radius"]
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-6 * (a["step_norm"] + 1e-12)
+        assert abs(a["relative_decrease"] - b["relative_decrease"]) <= 1e-5 * (abs(a["relative_decrease"]) + 1e-3)
+
+
+def _assert_summary_parity(s_ref, s_hip):
+    for k in ("num_successful_steps", "num_unsuccessful_steps", "termination_type", "num_free_parameters", "num_residual_blocks"):
+        assert s_ref[k] == s_hip[k], k
+    for k in ("initial_cost", "final_cost", "fixed_cost"):
+        assert abs(s_ref[k] - s_hip[k]) <= REL * abs(s_ref[k]) + 1e-300, k
+
+
+def test_linearise_matches_oracle(hip, oracle):
+    """Residuals + analytic Jacobians of the kernels vs the dual-number restatement of
+    AutoDiffCostFunction<LineReprojectionError,4,6,4> + HuberLoss corrector."""
+    for seed, robust in ((1, True), (2, False)):
+        w = synth.make_window(seed, num_lines=150)
+        b = hip.LBABatch()
+        b.add(w)
+        b.finalize(huber_delta=(1.0 / 406.05 if robust else 0.0))
+        c, r, jc, jl = b.linearise(0, len(w["camera_index"]))
+        c0, r0, jc0, jl0 = oracle.lba_cost(w, w["parameters"], huber_delta=(1.0 / 406.05 if robust else 0.0), want_jac=True)
+        assert abs(c - c0) <= 1e-13 * c0
+        assert np.abs(r - r0).max() < 1e-14
+        assert (np.abs(jc - jc0) / (1 + np.abs(jc0))).max() < 1e-12
+        assert (np.abs(jl - jl0) / (1 + np.abs(jl0))).max() < 1e-12
+        b.close()
+
+
+@pytest.mark.parametrize("seed,lines,kf,free", [(1, 60, 20, 10), (2, 200, 20, 10), (3, 500, 20, 10), (4, 80, 6, 3), (5, 40, 20, 20)])
+def test_solve_trace_matches_oracle(hip, oracle, seed, lines, kf, free):
+    """LM iteration by iteration: cost, gain ratio, radius, step norm, accept/reject decisions."""
+    w = synth.make_window(seed, num_lines=lines, num_kf=kf, num_free=free)
+    x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+    x1, s1, t1 = hip.lba_solve(w)
+    _assert_trace_parity(t0, t1, n=4)                  # the first iterations agree to round-off ...
+    _assert_summary_parity(s0, s1)
+    # ... later ones inherit the conditioning of the problem (oracle dense-vs-Schur differ as much)
+    assert np.abs(x0 - x1).max() < 1e-5
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-7 * s0["final_cost"]
+
+
+def test_one_iteration_is_roundoff_exact(hip, oracle):
+    w = synth.make_window(11, num_lines=300)
+    x0, s0, t0 = oracle.lba_solve(w, linear_solver=0, max_num_iterations=1)      # dense normal equations
+    x1, s1, t1 = hip.lba_solve(w, max_num_iterations=1)
+    _assert_trace_parity(t0, t1)
+    assert np.abs(x0 - x1).max() < 1e-9
+
+
+def test_motion_only_shape(hip, oracle):
+    """motion_only_ba (slam.cpp:578-675): one free camera, identity camera + every line constant."""
+    w = synth.make_motion_only(2, num_lines=60)
+    x0, s0, t0 = oracle.lba_solve(w)
+    x1, s1, t1 = hip.lba_solve(w)
+    _assert_trace_parity(t0, t1)
+    _assert_summary_parity(s0, s1)
+    assert s1["fixed_cost"] > 0 and s1["num_free_parameters"] == 6
+    assert np.array_equal(x1[6:], w["parameters"][6:])
+    assert np.abs(x0[:6] - x1[:6]).max() < 1e-10
+
+
+def test_non_robust_and_unscaled_variants(hip, oracle):
+    w = synth.make_window(6, num_lines=100)
+    for kw_h, kw_o in (({"huber_delta": 0.0}, {"huber_delta": 0.0}), ({"jacobi_scaling": 0}, {"jacobi_scaling": 0})):
+        o_args = {k: v for k, v in kw_o.items() if k != "huber_delta"}
+        x0, s0, t0 = oracle.lba_solve(w, huber_delta=kw_o.get("huber_delta", 1.0 / 406.05), linear_solver=1, **o_args)
+        x1, s1, t1 = hip.lba_solve(w, **kw_h)
+        _assert_trace_parity(t0, t1, n=3)
+        assert s0["num_successful_steps"] == s1["num_successful_steps"]
+
+
+def test_edge_cases(hip, oracle):
+    w = synth.make_window(7, num_lines=50)
+    # (a) nothing free: costs are the fixed cost, parameters untouched
+    w_all = dict(w, fixed_index=np.ones_like(w["fixed_index"]))
+    x, s, t = hip.lba_solve(w_all)
+    xo, so, _ = oracle.lba_solve(w_all)
+    assert np.array_equal(x, w["parameters"]) and s["num_free_parameters"] == 0
+    assert abs(s["initial_cost"] - so["initial_cost"]) < 1e-13 * so["initial_cost"] and s["initial_cost"] == s["final_cost"]
+    # (b) zero iterations
+    x, s, t = hip.lba_solve(w, max_num_iterations=0)
+    assert np.array_equal(x, w["parameters"]) and len(t) == 1
+    # (c) unused camera / line slots and a ragged, unsorted observation order
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(len(w["camera_index"]))
+    w2 = dict(w, num_cameras=22, num_lines=53,
+              camera_index=w["camera_index"][perm], line_index=w["line_index"][perm],
+              fixed_index=w["fixed_index"].reshape(-1, 2)[perm].reshape(-1), observations=w["observations"][perm],
+              parameters=np.concatenate([w["parameters"][:120], rng.normal(size=12), w["parameters"][120:], rng.uniform(0.2, 1, 12)]))
+    x0, s0, t0 = oracle.lba_solve(w2, linear_solver=1)
+    x1, s1, t1 = hip.lba_solve(w2)
+    _assert_trace_parity(t0, t1, n=3)
+    assert np.array_equal(x1[120:132], w2["parameters"][120:132]) and np.array_equal(x1[-12:], w2["parameters"][-12:])
+    assert np.abs(x0 - x1).max() < 1e-5
+    # (d) a camera observing the same line twice (duplicate residual blocks)
+    dup = np.arange(len(w["camera_index"]))
+    dup = np.concatenate([dup, dup[w["camera_index"] < 3][:40]])
+    w3 = dict(w, camera_index=w["camera_index"][dup], line_index=w["line_index"][dup],
+              fixed_index=w["fixed_index"].reshape(-1, 2)[dup].reshape(-1), observations=w["observations"][dup])
+    x0, s0, t0 = oracle.lba_solve(w3, linear_solver=1, max_num_iterations=2)
+    x1, s1, t1 = hip.lba_solve(w3, max_num_iterations=2)
+    _assert_trace_parity(t0, t1)
+    # (e) empty window
+    we = dict(num_cameras=2, num_lines=2, camera_index=np.zeros(0, np.int32), line_index=np.zeros(0, np.int32),
+              fixed_index=np.zeros(0, np.int32), observations=np.zeros((0, 8)), parameters=np.arange(20.0))
+    x, s, t = hip.lba_solve(we)
+    assert np.array_equal(x, np.arange(20.0)) and s["initial_cost"] == 0.0
+
+
+def test_golden_optimum(hip):
+    """Converged HIP solve vs the scipy.optimize.least_squares optimum committed in tests/golden."""
+    z = np.load(os.path.join(GOLD, "lba_optimum.npz"))
+    w = {k: z[k] for k in z.files}
+    w["num_cameras"], w["num_lines"] = int(z["num_cameras"]), int(z["num_lines"])
+    x, s, t = hip.lba_solve(w, max_num_iterations=60, function_tolerance=1e-16, parameter_tolerance=1e-14, gradient_tolerance=1e-16)
+    assert abs(s["final_cost"] - float(z["optimum_cost"])) < 1e-9 * float(z["optimum_cost"])
+    assert np.abs(x - z["optimum"]).max() < 1e-4
+    assert abs(s["initial_cost"] - float(z["initial_cost"])) < 1e-13 * float(z["initial_cost"])
+
+
+def test_batch_equals_single_and_is_reproducible(hip, oracle):
+    """Windows are independent: a window solved inside a ragged batch gives the same result as
+    alone; two runs of the same batch are bitwise identical (ordered reductions)."""
+    ws = [synth.make_window(20 + i, num_lines=l, num_kf=k, num_free=f)
+          for i, (l, k, f) in enumerate([(120, 20, 10), (40, 6, 3), (300, 20, 10), (75, 12, 5), (200, 20, 10), (10, 4, 2)])]
+    ws.append(synth.make_motion_only(9, num_lines=30))
+    b = hip.LBABatch()
+    for w in ws:
+        b.add(w)
+    b.finalize()
+    b.solve(); b.download()
+    first = [b.parameters(i).copy() for i in range(len(ws))]
+    summ = [b.summary(i) for i in range(len(ws))]
+    b.reset(); b.solve(); b.download()
+    for i, w in enumerate(ws):
+        assert np.array_equal(first[i], b.parameters(i)), "window %d not reproducible" % i
+        xs, ss, _ = hip.lba_solve(w)
+        assert ss["num_successful_steps"] == summ[i]["num_successful_steps"]
+        assert np.abs(xs - first[i]).max() < 1e-9
+        xo, so, _ = oracle.lba_solve(w, linear_solver=1)
+        assert np.abs(xo - first[i]).max() < 1e-5
+        assert abs(so["final_cost"] - summ[i]["final_cost"]) <= 1e-7 * so["final_cost"]
+    its = sum(s["num_successful_steps"] + s["num_unsuccessful_steps"] for s in summ)
+    assert b.iterations(clear=True) == 2 * its          # two solves since finalize
+    assert b.counts()["windows"] == len(ws)
+    b.close()
+
+
+def test_graph_replay_equals_eager_launches(hip):
+    w = [synth.make_window(40 + i, num_lines=100) for i in range(4)]
+    out = []
+    for use_graph in (1, 0):
+        b = hip.LBABatch()
+        for x in w:
+            b.add(x)
+        b.finalize(use_graph=use_graph)
+        b.solve()
+        b.download()
+        out.append([b.parameters(i) for i in range(4)])
+        if not use_graph:
+            b.set_profiling(True)
+            b.reset(); b.solve(); b.download()
+            kt = b.kernel_times()
+            assert kt["linearise_schur"][1] == 10 and kt["linearise_schur"][0] > 0
+            assert all(np.array_equal(b.parameters(i), out[-1][i]) for i in range(4))
+        b.close()
+    for a, c in zip(*out):
+        assert np.array_equal(a, c)
+
+
+def test_full_size_window_properties(hip, oracle):
+    """BASELINE config: 10 free + 10 fixed keyframes, 2000 lines.  Oracle parity on the full window
+    plus size-independent properties: monotone accepted costs, fixed blocks untouched, the optimum
+    reduces the reprojection cost to the noise floor, trajectory error vs truth shrinks."""
+    w = synth.make_window(1234, num_lines=2000)
+    x1, s1, t1 = hip.lba_solve(w)
+    x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+    _assert_trace_parity(t0, t1, n=3)
+    assert s0["num_successful_steps"] == s1["num_successful_steps"]
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-6 * s0["final_cost"]
+    costs = [r["cost"] for r in t1]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
+    assert np.array_equal(x1[60:120], w["parameters"][60:120])           # the 10 fixed keyframes
+    M = len(w["camera_index"])
+    noise_floor = 0.5 * 4 * M * (0.5 / 406.05) ** 2
+    assert s1["final_cost"] < 1.5 * noise_floor < s1["initial_cost"]
+    c_true = synth.camera_centers(w["true_parameters"][:60])
+    e0 = np.linalg.norm(synth.camera_centers(w["parameters"][:60]) - c_true, axis=1)
+    e1 = np.linalg.norm(synth.camera_centers(x1[:60]) - c_true, axis=1)
+    assert np.sqrt((e1 ** 2).mean()) < np.sqrt((e0 ** 2).mean())
+    eo = np.linalg.norm(synth.camera_centers(x1[:60]) - synth.camera_centers(x0[:60]), axis=1)
+    assert np.sqrt((eo ** 2).mean()) < 1e-6                              # trajectory RMS vs the oracle solve

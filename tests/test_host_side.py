@@ -1,0 +1,199 @@
+"""CPU tests of the product's host-side code: the device math header compiled for the host,
+the window packer, and the C ABI surface (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from slslam_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DP = C.POINTER(C.c_double)
+IP = C.POINTER(C.c_int)
+
+
+def _dp(a):
+    return a.ctypes.data_as(DP)
+
+
+def _ip(a):
+    return a.ctypes.data_as(IP)
+
+
+def test_analytic_jacobian_matches_oracle_dual_numbers(host_math, oracle):
+    """slslam_amd/csrc/lba_math.h (what every LBA kernel evaluates) vs the oracle's Jet<10>
+    restatement of AutoDiffCostFunction<LineReprojectionError,4,6,4> (lba_problem.cpp:65-74)."""
+    w = synth.make_window(3, num_lines=200)
+    prm, Cn = w["parameters"], w["num_cameras"]
+    worst = np.zeros(3)
+    for i in range(len(w["camera_index"])):
+        cam = prm[6 * w["camera_index"][i]:][:6].copy()
+        line = prm[6 * Cn + 4 * w["line_index"][i]:][:4].copy()
+        ob = w["observations"][i].copy()
+        r0, jc0, jl0 = oracle.line_residual_jet(cam, line, ob)
+        r, jc, jl, r2 = np.zeros(4), np.zeros((4, 6)), np.zeros((4, 4)), np.zeros(4)
+        host_math.hm_obs_linearise(_dp(cam), _dp(line), _dp(ob), C.c_double(0.12), _dp(r), _dp(jc), _dp(jl))
+        host_math.hm_obs_residual(_dp(cam), _dp(line), _dp(ob), C.c_double(0.12), _dp(r2))
+        worst = np.maximum(worst, [max(abs(r - r0).max(), abs(r2 - r0).max()),
+                                   (abs(jc - jc0) / (1 + abs(jc0))).max(), (abs(jl - jl0) / (1 + abs(jl0))).max()])
+    assert worst[0] < 1e-14 and worst[1] < 1e-13 and worst[2] < 1e-13
+
+
+@pytest.mark.parametrize("scale", [0.0, 1e-12, 1e-3, 0.5, 3.0])
+def test_rotation_branches(host_math, oracle, scale):
+    """theta == 0 (the identity keyframe, slam.cpp:1322) takes the first-order branch of
+    AngleAxisRotatePoint; tiny and large angles go through Rodrigues."""
+    rng = np.random.default_rng(1)
+    w = synth.make_window(4, num_lines=20)
+    line = w["parameters"][6 * 20:6 * 20 + 4].copy()
+    ob = w["observations"][0].copy()
+    cam = np.concatenate([rng.normal(size=3) * scale, rng.normal(size=3)])
+    r0, jc0, jl0 = oracle.line_residual_jet(cam, line, ob)
+    r, jc, jl = np.zeros(4), np.zeros((4, 6)), np.zeros((4, 4))
+    host_math.hm_obs_linearise(_dp(cam), _dp(line), _dp(ob), C.c_double(0.12), _dp(r), _dp(jc), _dp(jl))
+    assert abs(r - r0).max() < 1e-14
+    assert abs(jc - jc0).max() < 1e-12 * (1 + abs(jc0).max())
+    assert abs(jl - jl0).max() < 1e-12 * (1 + abs(jl0).max())
+
+
+def test_huber_corrector(host_math, oracle):
+    a = 1.0 / 406.05
+    for s in (0.0, 0.3 * a * a, a * a, 4 * a * a, 1.0):
+        cost = C.c_double(0)
+        host_math.hm_huber.restype = C.c_double
+        f = host_math.hm_huber(C.c_double(s), C.c_double(a), C.byref(cost))
+        rho = oracle.huber(s, a)
+        assert abs(f - np.sqrt(rho[1])) < 1e-15 and abs(cost.value - 0.5 * rho[0]) < 1e-18
+    f = host_math.hm_huber(C.c_double(1.0), C.c_double(0.0), C.byref(cost))   # FLAGS_robust = false
+    assert f == 1.0 and cost.value == 0.5
+
+
+def _pack(host_math, w):
+    Cn, L = int(w["num_cameras"]), int(w["num_lines"])
+    cam = np.ascontiguousarray(w["camera_index"], dtype=np.int32)
+    line = np.ascontiguousarray(w["line_index"], dtype=np.int32)
+    fixed = np.ascontiguousarray(w["fixed_index"], dtype=np.int32)
+    obs = np.ascontiguousarray(w["observations"], dtype=np.float64).reshape(-1)
+    prm = np.ascontiguousarray(w["parameters"], dtype=np.float64).copy()
+    M = len(cam)
+    counts = np.zeros(5, dtype=np.int32)
+    lo, lp = np.zeros(max(L, 1), dtype=np.int32), np.zeros(L + 1, dtype=np.int32)
+    oo, oc, cf = np.zeros(max(M, 1), dtype=np.int32), np.zeros(max(M, 1), dtype=np.int32), np.zeros(max(Cn, 1), dtype=np.int32)
+    max_tiles, max_items = L + 8, 64 * M + 8
+    tiles = np.zeros(4 * max_tiles, dtype=np.int32)
+    items = np.zeros(2 * max_items, dtype=np.uint8)
+    rc = host_math.hm_pack(Cn, L, M, _ip(cam), _ip(line), _ip(fixed), _dp(obs), _dp(prm), _ip(counts), _ip(lo), _ip(lp),
+                           _ip(oo), _ip(oc), _ip(tiles), items.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cf), max_tiles, max_items)
+    return rc, dict(Cf=int(counts[0]), ntiles=int(counts[1]), nitems=int(counts[2]), nfree=int(counts[3]), nkept=int(counts[4]),
+                    line_order=lo[:L], line_ptr=lp, ob_orig=oo[:M], ob_cam=oc[:M], cam_cf=cf[:Cn],
+                    tiles=tiles[:4 * int(counts[1])].reshape(-1, 4), items=items[:2 * int(counts[2])].reshape(-1, 2))
+
+
+def test_pack_invariants(host_math):
+    """LBAProblem::build replacement (lba_pack.cpp): a permutation of lines/observations into
+    64-lane tiles plus the camera-pair work items; nothing lost, nothing duplicated."""
+    w = synth.make_window(6, num_lines=300)
+    rc, P = _pack(host_math, w)
+    assert rc == 0
+    L, M = 300, len(w["camera_index"])
+    assert P["Cf"] == 10 and P["nkept"] == M and P["nfree"] == 60 + 4 * L
+    assert sorted(P["line_order"]) == list(range(L)) and sorted(P["ob_orig"]) == list(range(M))
+    assert P["line_ptr"][0] == 0 and P["line_ptr"][L] == M
+    for s in range(L):
+        sel = P["ob_orig"][P["line_ptr"][s]:P["line_ptr"][s + 1]]
+        assert np.all(w["line_index"][sel] == P["line_order"][s])        # grouped by line
+        cf = P["cam_cf"][w["camera_index"][sel]]
+        nf = int((cf >= 0).sum())
+        assert np.all(cf[:nf] >= 0) and np.all(cf[nf:] < 0) and np.all(np.diff(cf[:nf]) >= 0)   # free first, ascending
+    assert np.array_equal(P["ob_cam"], w["camera_index"][P["ob_orig"]])
+    # tiles cover the sorted lines exactly once; group width fits the line's observations
+    covered, expect_items, it = 0, 0, 0
+    for lb, nl, g, ni in P["tiles"]:
+        assert lb == covered and 1 <= nl <= (64 >> g)
+        for s in range(lb, lb + nl):
+            k = P["line_ptr"][s + 1] - P["line_ptr"][s]
+            assert k <= (1 << g) and (g == 1 or k > (1 << (g - 1)))
+            sel = P["ob_orig"][P["line_ptr"][s]:P["line_ptr"][s + 1]]
+            kf = int((P["cam_cf"][w["camera_index"][sel]] >= 0).sum())
+            base = (s - lb) << g
+            want = {(base + i, base + j) for i in range(kf) for j in range(i + 1, kf)}
+            got = {tuple(x) for x in P["items"][it + expect_items - expect_items:it + ni]} if ni else set()
+            expect_items += len(want)
+            assert want <= {tuple(x) for x in P["items"][it:it + ni]}
+        assert expect_items == ni
+        it += ni
+        expect_items = 0
+        covered += nl
+    assert covered == L and it == P["nitems"]
+
+
+def test_pack_edge_cases(host_math):
+    # motion-only shape: lines constant -> no elimination work items, 1 free camera
+    rc, P = _pack(host_math, synth.make_motion_only(1, num_lines=25))
+    assert rc == 0 and P["Cf"] == 1 and P["nitems"] == 0 and P["nfree"] == 6
+    assert P["nkept"] == 25                      # the (fixed camera, fixed line) blocks leave the program
+    # empty window
+    rc, P = _pack(host_math, dict(num_cameras=2, num_lines=3, camera_index=[], line_index=[], fixed_index=[],
+                                  observations=np.zeros((0, 8)), parameters=np.zeros(24)))
+    assert rc == 0 and P["ntiles"] >= 1 and P["nfree"] == 0
+    # out-of-range index and non-finite input are rejected
+    w = synth.make_window(2, num_lines=10)
+    bad = dict(w, camera_index=w["camera_index"].copy()); bad["camera_index"][0] = 99
+    assert _pack(host_math, bad)[0] == 1
+    bad = dict(w, observations=w["observations"].copy()); bad["observations"][0, 0] = np.nan
+    assert _pack(host_math, bad)[0] == 1
+    # more free cameras than the reduced-system kernel supports
+    big = synth.make_window(2, num_lines=30, num_kf=24, num_free=24)
+    assert _pack(host_math, big)[0] == 4
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "slslam_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(slslam_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from slslam_amd import capi
+    L = capi.lib()
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "include/slslam_hip.h declares %s but the library does not export it" % n
+    assert sorted(capi.EXPORTS) == names
+    assert b"gfx950" in L.slslam_version()
+
+
+def test_default_options_are_the_reference_configuration():
+    from slslam_amd import capi
+    o = capi.default_options()
+    assert o.max_num_iterations == 10                         # main.cpp:23
+    assert abs(o.huber_delta - 1.0 / 406.05) < 1e-18          # lba_problem.cpp:78
+    assert o.baseline == 0.12                                 # lba_problem.h:101
+    assert (o.initial_trust_region_radius, o.min_relative_decrease, o.function_tolerance) == (1e4, 1e-3, 1e-6)
+    with pytest.raises(TypeError):
+        capi.default_options(no_such_option=1)
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product must fail loudly, never route through a CPU path."""
+    from slslam_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    w = synth.make_window(0, num_lines=10)
+    with pytest.raises(capi.SlslamError) as e:
+        capi.lba_solve(w)
+    assert e.value.status == 2
+    with pytest.raises(capi.SlslamError):
+        capi.LBABatch()
+    # the product never imports, links or calls the oracle
+    pat = re.compile(r"(import\s+oracle|from\s+oracle|pyoracle|liboracle|slslam_oracle\.h|oracle_[a-z_]+\()")
+    for d in ("slslam_amd", os.path.join("slslam_amd", "csrc"), os.path.join("slslam_amd", "host"), "include"):
+        p = os.path.join(ROOT, d)
+        if not os.path.isdir(p):
+            continue
+        for f in os.listdir(p):
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                assert not pat.search(open(os.path.join(p, f)).read()), "%s/%s references the oracle" % (d, f)
