@@ -11,9 +11,14 @@ from slslam_amd import synth
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# fp64 on both sides: per-iteration quantities agree to round-off; the tolerance below only absorbs
-# the different summation order (wave shuffles / LDS atomics vs serial loops) and FMA contraction.
+# fp64 on both sides.  The initial evaluation and the first step agree to round-off (different
+# summation order: wave shuffles / LDS atomics vs serial loops, FMA contraction).  Later iterations
+# inherit the conditioning of the problem: the oracle's own dense and Schur back-ends drift apart
+# at the same rate (tests/test_oracle.py::test_dense_and_schur_linear_solvers_agree), so the
+# tolerance widens with the iteration index.  Stated tolerances: cost rel 1e-13 (it 0),
+# 1e-10 (it 1), 1e-6 (later); final parameters 1e-5; final cost rel 1e-7.
 REL = 1e-9
+REL_BY_ITER = {0: 1e-13, 1: 1e-10}
 
 
 def _assert_trace_parity(t_ref, t_hip, n=None):
@@ -21,17 +26,17 @@ def _assert_trace_parity(t_ref, t_hip, n=None):
     for a, b in list(zip(t_ref, t_hip))[:n]:
         assert a["iteration"] == b["iteration"]
         assert a["step_is_successful"] == b["step_is_successful"] and a["step_is_valid"] == b["step_is_valid"]
-        assert abs(a["cost"] - b["cost"]) <= REL * abs(a["cost"])
+        assert abs(a["cost"] - b["cost"]) <= REL_BY_ITER.get(a["iteration"], 1e-6) * abs(a["cost"])
         assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-6 * a["trust_region_radius"]
-        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-6 * (a["step_norm"] + 1e-12)
-        assert abs(a["relative_decrease"] - b["relative_decrease"]) <= 1e-5 * (abs(a["relative_decrease"]) + 1e-3)
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-5 * (a["step_norm"] + 1e-12)
+        assert abs(a["relative_decrease"] - b["relative_decrease"]) <= 1e-4 * (abs(a["relative_decrease"]) + 1e-3)
 
 
 def _assert_summary_parity(s_ref, s_hip):
     for k in ("num_successful_steps", "num_unsuccessful_steps", "termination_type", "num_free_parameters", "num_residual_blocks"):
         assert s_ref[k] == s_hip[k], k
-    for k in ("initial_cost", "final_cost", "fixed_cost"):
-        assert abs(s_ref[k] - s_hip[k]) <= REL * abs(s_ref[k]) + 1e-300, k
+    for k, tol in (("initial_cost", 1e-12), ("fixed_cost", 1e-12), ("final_cost", 1e-7)):
+        assert abs(s_ref[k] - s_hip[k]) <= tol * abs(s_ref[k]) + 1e-300, k
 
 
 def test_linearise_matches_oracle(hip, oracle):
