@@ -1,0 +1,519 @@
+// slslam_amd/csrc/po_kernels.h — hand-written CDNA4 kernels of the pose-graph optimisation.
+//
+// What this replaces: ceres::Solve on the problem POProblem::build wires up (reference
+// src/po_problem.cpp:40-77, call site src/slam.cpp:1283-1293): one <6,6,6> residual block per edge,
+// Te = T2^-1 * (C * T1) in (angle-axis, translation) form (src/po_problem.h:68-108), pose1 of
+// edge 0 constant, no loss function, SPARSE_NORMAL_CHOLESKY.
+//
+//   k_po_linearise   lane <-> (edge, seed direction): the templated SE(3) functor is evaluated on
+//                    a one-direction dual number per lane (12 lanes = the 12 columns of [J1|J2]),
+//                    columns are exchanged by wave shuffles and J^T J / J^T r go to the dense
+//                    normal matrix with fp64 global atomics (E ~ 300 edges: tiny)
+//   k_po_prepare     gradient max-norm, Jacobi scale (first call), LM damping, rhs
+//   k_po_potrf_diag / k_po_panel_update
+//                    blocked right-looking Cholesky of the dense (6N)^2 matrix, 64x64 blocks;
+//                    TRSM and the trailing SYRK/GEMM run on v_mfma_f64_16x16x4_f64 - the one
+//                    real matrix contraction on this path
+//   k_po_trisolve    forward / backward substitution
+//   k_po_candidate   x+ = x - scale*y and the step statistics;  k_po_cost  cost at x+
+//   k_po_update      trust-region bookkeeping (same policy as the LBA path)
+#ifndef SLSLAM_PO_KERNELS_H_
+#define SLSLAM_PO_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include "lba_types.h"
+
+namespace slslam {
+
+// ------------------------------------------------------------------------------------------
+// one-direction forward-mode dual number
+struct Dual {
+  double v, d;
+};
+__device__ __forceinline__ Dual mk(double v, double d = 0.0) { Dual r; r.v = v; r.d = d; return r; }
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return mk(a.v + b.v, a.d + b.d); }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return mk(a.v - b.v, a.d - b.d); }
+__device__ __forceinline__ Dual operator-(Dual a) { return mk(-a.v, -a.d); }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return mk(a.v * b.v, a.v * b.d + a.d * b.v); }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) { const double q = a.v / b.v; return mk(q, (a.d - q * b.d) / b.v); }
+__device__ __forceinline__ Dual dsin(Dual a) { return mk(sin(a.v), cos(a.v) * a.d); }
+__device__ __forceinline__ Dual dcos(Dual a) { return mk(cos(a.v), -sin(a.v) * a.d); }
+__device__ __forceinline__ Dual dsqrt(Dual a) { const double s = sqrt(a.v); return mk(s, a.d / (2.0 * s)); }
+__device__ __forceinline__ Dual datan2(Dual y, Dual x) { return mk(atan2(y.v, x.v), (x.v * y.d - y.v * x.d) / (x.v * x.v + y.v * y.v)); }
+__device__ __forceinline__ double val(Dual a) { return a.v; }
+
+// plain-double overloads so that the functor below also instantiates for T = double
+__device__ __forceinline__ double dsin(double a) { return sin(a); }
+__device__ __forceinline__ double dcos(double a) { return cos(a); }
+__device__ __forceinline__ double dsqrt(double a) { return sqrt(a); }
+__device__ __forceinline__ double datan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ double val(double a) { return a; }
+template <typename T> __device__ __forceinline__ T cst(double v);
+template <> __device__ __forceinline__ double cst<double>(double v) { return v; }
+template <> __device__ __forceinline__ Dual cst<Dual>(double v) { return mk(v); }
+
+// ceres::AngleAxisRotatePoint (Rodrigues; first-order branch at zero) — used by gc_T_inv / gc_T_20
+template <typename T>
+__device__ __forceinline__ void aa_rotate(const T w[3], const T p[3], T out[3]) {
+  const T th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  if (val(th2) > 0.0) {
+    const T th = dsqrt(th2);
+    const T u0 = w[0] / th, u1 = w[1] / th, u2 = w[2] / th;
+    const T c = dcos(th), s = dsin(th);
+    const T x0 = u1 * p[2] - u2 * p[1], x1 = u2 * p[0] - u0 * p[2], x2 = u0 * p[1] - u1 * p[0];
+    const T dot = u0 * p[0] + u1 * p[1] + u2 * p[2];
+    const T omc = cst<T>(1.0) - c;
+    out[0] = p[0] * c + x0 * s + u0 * omc * dot;
+    out[1] = p[1] * c + x1 * s + u1 * omc * dot;
+    out[2] = p[2] * c + x2 * s + u2 * omc * dot;
+  } else {
+    out[0] = p[0] + (w[1] * p[2] - w[2] * p[1]);
+    out[1] = p[1] + (w[2] * p[0] - w[0] * p[2]);
+    out[2] = p[2] + (w[0] * p[1] - w[1] * p[0]);
+  }
+}
+
+// gc_w_20 (reference src/po_problem.h:42-52): w20 = log(exp(w21) exp(w10)) through quaternions
+// (ceres::AngleAxisToQuaternion, QuaternionProduct, QuaternionToAngleAxis)
+template <typename T>
+__device__ __forceinline__ void aa_to_quat(const T a[3], T q[4]) {
+  const T t2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+  if (val(t2) > 0.0) {
+    const T th = dsqrt(t2);
+    const T half = th * cst<T>(0.5);
+    const T k = dsin(half) / th;
+    q[0] = dcos(half); q[1] = a[0] * k; q[2] = a[1] * k; q[3] = a[2] * k;
+  } else {
+    q[0] = cst<T>(1.0); q[1] = a[0] * cst<T>(0.5); q[2] = a[1] * cst<T>(0.5); q[3] = a[2] * cst<T>(0.5);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void quat_to_aa(const T q[4], T a[3]) {
+  const T s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (val(s2) > 0.0) {
+    const T st = dsqrt(s2);
+    const T two = cst<T>(2.0) * ((val(q[0]) < 0.0) ? datan2(-st, -q[0]) : datan2(st, q[0]));
+    const T k = two / st;
+    a[0] = q[1] * k; a[1] = q[2] * k; a[2] = q[3] * k;
+  } else {
+    a[0] = q[1] * cst<T>(2.0); a[1] = q[2] * cst<T>(2.0); a[2] = q[3] * cst<T>(2.0);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void se3_compose(const T T21[6], const T T10[6], T T20[6]) {   // gc_T_20, :55-64
+  T q21[4], q10[4], q[4];
+  aa_to_quat<T>(T21, q21);
+  aa_to_quat<T>(T10, q10);
+  q[0] = q21[0] * q10[0] - q21[1] * q10[1] - q21[2] * q10[2] - q21[3] * q10[3];
+  q[1] = q21[0] * q10[1] + q21[1] * q10[0] + q21[2] * q10[3] - q21[3] * q10[2];
+  q[2] = q21[0] * q10[2] - q21[1] * q10[3] + q21[2] * q10[0] + q21[3] * q10[1];
+  q[3] = q21[0] * q10[3] + q21[1] * q10[2] - q21[2] * q10[1] + q21[3] * q10[0];
+  quat_to_aa<T>(q, T20);
+  aa_rotate<T>(T21, T10 + 3, T20 + 3);
+  T20[3] = T20[3] + T21[3]; T20[4] = T20[4] + T21[4]; T20[5] = T20[5] + T21[5];
+}
+template <typename T>
+__device__ __forceinline__ void se3_inverse(const T P[6], T Pi[6]) {                       // gc_T_inv, :27-39
+  Pi[0] = -P[0]; Pi[1] = -P[1]; Pi[2] = -P[2];
+  const T v[3] = { -P[3], -P[4], -P[5] };
+  aa_rotate<T>(Pi, v, Pi + 3);
+}
+// PoseConstraintError::operator() (reference src/po_problem.h:74-105): Te = T2^-1 * (C * T1)
+template <typename T>
+__device__ __forceinline__ void pose_constraint_error(const T T1[6], const T T2[6], const T C[6], T Te[6]) {
+  T Tc[6], T2i[6];
+  se3_compose<T>(C, T1, Tc);
+  se3_inverse<T>(T2, T2i);
+  se3_compose<T>(T2i, Tc, Te);
+}
+
+// ------------------------------------------------------------------------------------------
+struct PoPtrs {
+  const int* p1; const int* p2;      // [E]
+  const double* cons;                // [6E]
+  const int* slot;                   // [N] offset of the pose in the reduced vector or -1 (gauge / unused)
+  double* x;                         // [2][6N] accepted / candidate poses
+  double* scale;                     // [n]
+  double* H;                         // [n x ld] normal matrix, lower triangle; overwritten by its factor
+  double* g;                         // [n] scaled gradient J'^T r
+  double* d2;                        // [n] LM damping
+  double* y;                         // [n] rhs -> solution
+  double* linv;                      // [64 x 64] inverse of the current diagonal block
+  double* scal;                      // [8] 0 cost, 1 candidate cost, 2 model, 3 dn2, 4 xn2, 5 fixed cost
+  int* flags;                        // [2] 0: factorisation failure
+  LMState* st;
+  IterRec* trace;
+  int N, E, n, ld;
+};
+enum { kPoCost = 0, kPoCandCost = 1, kPoModel = 2, kPoDn2 = 3, kPoXn2 = 4, kPoFixed = 5 };
+
+// lane <-> (edge, column of [J1|J2]); 5 edges per wave.
+// mode 0: accumulate H, g, cost at the accepted point (scaled columns)
+// mode 1: cost only at the candidate point
+__global__ __launch_bounds__(64) void k_po_linearise(PoPtrs p, int mode) {
+  const LMState* st = p.st;
+  if (st->status != kRunning) return;
+  const int lane = threadIdx.x;
+  const int el = lane / 12, d = lane - 12 * el;
+  const int e = blockIdx.x * 5 + el;
+  const bool ok = el < 5 && e < p.E;
+  const int buf = mode ? 1 - st->cur : st->cur;
+  const double* X = p.x + (long long)buf * 6 * p.N;
+  const int es = ok ? e : 0;
+  const int a = p.p1[es], b = p.p2[es];
+  double cost = 0.0;
+  if (mode == 1) {
+    if (ok && d == 0) {
+      double T1[6], T2[6], C[6], Te[6];
+      for (int i = 0; i < 6; ++i) { T1[i] = X[6 * a + i]; T2[i] = X[6 * b + i]; C[i] = p.cons[6 * es + i]; }
+      pose_constraint_error<double>(T1, T2, C, Te);
+      const bool kept = p.slot[a] >= 0 || p.slot[b] >= 0;
+      if (kept) for (int i = 0; i < 6; ++i) cost += 0.5 * Te[i] * Te[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) cost += __shfl_xor(cost, o);
+    if (lane == 0) atomicAdd(&p.scal[kPoCandCost], cost);
+    return;
+  }
+  Dual T1[6], T2[6], C[6], Te[6];
+  for (int i = 0; i < 6; ++i) {
+    T1[i] = mk(X[6 * a + i], d == i ? 1.0 : 0.0);
+    T2[i] = mk(X[6 * b + i], d == 6 + i ? 1.0 : 0.0);
+    C[i] = mk(p.cons[6 * es + i]);
+  }
+  pose_constraint_error<Dual>(T1, T2, C, Te);
+  const int sa = p.slot[a], sb = p.slot[b];
+  const int my = d < 6 ? (sa >= 0 ? sa + d : -1) : (sb >= 0 ? sb + d - 6 : -1);
+  const bool kept = sa >= 0 || sb >= 0;
+  const double sc = (my >= 0) ? p.scale[my] : 0.0;
+  double col[6], gsum = 0.0;
+  for (int q = 0; q < 6; ++q) { col[q] = Te[q].d * sc; gsum += col[q] * Te[q].v; }
+  const int base = 12 * el;
+  for (int dp = 0; dp < 12; ++dp) {
+    double h = 0.0;
+    for (int q = 0; q < 6; ++q) h += col[q] * __shfl(col[q], base + dp);
+    const int other = __shfl(my, base + dp);
+    if (ok && my >= 0 && other >= 0 && my >= other) atomicAdd(&p.H[(long long)my * p.ld + other], h);
+  }
+  if (ok && my >= 0) atomicAdd(&p.g[my], gsum);
+  if (ok && d == 0) {
+    double c = 0.0;
+    for (int q = 0; q < 6; ++q) c += 0.5 * Te[q].v * Te[q].v;
+    if (kept) cost = c; else atomicAdd(&p.scal[kPoFixed], c);
+  }
+  for (int o = 32; o > 0; o >>= 1) cost += __shfl_xor(cost, o);
+  if (lane == 0) atomicAdd(&p.scal[kPoCost], cost);
+}
+
+// one workgroup: gradient max-norm, Jacobi scale on the first call, damping, rhs.
+// first = 1: H holds the UNSCALED J^T J (scale == 1); compute scale, rescale H and g in place.
+__global__ __launch_bounds__(256) void k_po_prepare(PoPtrs p, Policy pol, int first) {
+  LMState* st = p.st;
+  if (st->status != kRunning) return;
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  double gm = 0.0;
+  for (int i = tid; i < p.n; i += 256) {
+    double s = p.scale[i];
+    if (first) {
+      s = pol.jacobi_scaling ? 1.0 / (1.0 + sqrt(p.H[(long long)i * p.ld + i])) : 1.0;
+      gm = fmax(gm, fabs(p.g[i]));
+      p.scale[i] = s;
+    } else {
+      gm = fmax(gm, fabs(p.g[i] / s));
+    }
+  }
+  red[tid] = gm;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmax(red[tid], red[tid + o]); __syncthreads(); }
+  gm = red[0];
+  __syncthreads();
+  const int ngc = st->need_grad_check;
+  __syncthreads();
+  if (first) {
+    // initial evaluation (Ceres: cost, gradient, column norms at x0).  The host re-linearises with
+    // the scale computed here, so nothing is damped or solved in this call.
+    if (tid == 0) {
+      double xn2 = 0.0;
+      const double* X = p.x + (long long)st->cur * 6 * p.N;
+      for (int k = 0; k < p.N; ++k) if (p.slot[k] >= 0) for (int i = 0; i < 6; ++i) xn2 += X[6 * k + i] * X[6 * k + i];
+      st->cost = p.scal[kPoCost]; st->fixed_cost = p.scal[kPoFixed];
+      st->initial_cost = st->cost + st->fixed_cost; st->min_cost = st->initial_cost;
+      st->x_norm = sqrt(xn2); st->grad_max = gm;
+      st->abs_grad_tol = pol.gradient_tolerance * (gm > 1e-12 ? gm : 1e-12);
+      IterRec rec;
+      rec.iteration = 0; rec.step_is_valid = 0; rec.step_is_successful = 0; rec.pad = 0;
+      rec.cost = st->initial_cost; rec.cost_change = 0; rec.gradient_max_norm = gm; rec.step_norm = 0;
+      rec.relative_decrease = 0; rec.trust_region_radius = st->radius; rec.model_cost_change = 0;
+      if (!isfinite(st->cost)) st->status = 4;
+      else if (gm <= st->abs_grad_tol) st->status = 1;
+      else { p.trace[st->ntrace++] = rec; if (pol.max_num_iterations <= 0) st->status = 0; }
+    }
+    return;
+  } else if (ngc) {
+    if (tid == 0) {
+      st->grad_max = gm; st->need_grad_check = 0;
+      if (st->ntrace > 0 && st->ntrace <= kMaxTrace) p.trace[st->ntrace - 1].gradient_max_norm = gm;
+      if (gm <= st->abs_grad_tol) st->status = 1;
+    }
+    __syncthreads();
+    if (st->status != kRunning) return;
+  }
+  const double radius = st->radius;
+  for (int i = tid; i < p.n; i += 256) {
+    const double d2 = fmin(fmax(p.H[(long long)i * p.ld + i], pol.min_lm_diagonal), pol.max_lm_diagonal) / radius;
+    p.d2[i] = d2;
+    p.H[(long long)i * p.ld + i] += d2;
+    p.y[i] = p.g[i];
+  }
+  if (tid == 0) { p.flags[0] = 0; p.scal[kPoCandCost] = 0.0; }
+}
+
+// ---- blocked Cholesky, block size 64 --------------------------------------------------------
+enum { kNB = 64, kLdT = 66 };   // LDS tile leading dimension: 132 dwords == 4 (mod 64), conflict-free b64 reads
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// Factor the diagonal block A[k0:k0+nb, k0:k0+nb] in LDS, write L11 back and its inverse to linv.
+__global__ __launch_bounds__(256) void k_po_potrf_diag(PoPtrs p, int k0) {
+  if (p.st->status != kRunning) return;
+  __shared__ double T[kNB * kLdT];
+  __shared__ double Li[kNB * kLdT];
+  const int tid = threadIdx.x;
+  const int nb = min(kNB, p.n - k0);
+  for (int q = tid; q < kNB * kNB; q += 256) {
+    const int r = q / kNB, c = q - r * kNB;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < nb && c <= r) v = p.H[(long long)(k0 + r) * p.ld + k0 + c];
+    T[r * kLdT + c] = (c <= r) ? v : 0.0;
+  }
+  __syncthreads();
+  int fail = 0;
+  for (int j = 0; j < kNB; ++j) {
+    // column j: rows r >= j handled by threads r (r < 64)
+    double s = 0.0;
+    const int r = tid;
+    if (r < kNB && r >= j) {
+      s = T[r * kLdT + j];
+      for (int k = 0; k < j; ++k) s -= T[r * kLdT + k] * T[j * kLdT + k];
+    }
+    __syncthreads();
+    if (r == j) { if (!(s > 0.0) || !isfinite(s)) { s = 1.0; fail = 1; } T[j * kLdT + j] = sqrt(s); }
+    __syncthreads();
+    const double dj = T[j * kLdT + j];
+    if (r < kNB && r > j) T[r * kLdT + j] = s / dj;
+    __syncthreads();
+  }
+  if (__syncthreads_or(fail)) { if (tid == 0) p.flags[0] = 1; }
+  // inverse of the lower-triangular block: thread c solves L x = e_c
+  if (tid < kNB) {
+    const int c = tid;
+    for (int r = 0; r < kNB; ++r) {
+      double s = (r == c) ? 1.0 : 0.0;
+      if (r < c) { Li[r * kLdT + c] = 0.0; continue; }
+      for (int k = c; k < r; ++k) s -= T[r * kLdT + k] * Li[k * kLdT + c];
+      Li[r * kLdT + c] = s / T[r * kLdT + r];
+    }
+  }
+  __syncthreads();
+  for (int q = tid; q < kNB * kNB; q += 256) {
+    const int r = q / kNB, c = q - r * kNB;
+    p.linv[q] = Li[r * kLdT + c];
+    if (r < nb && c <= r) p.H[(long long)(k0 + r) * p.ld + k0 + c] = T[r * kLdT + c];
+  }
+}
+
+// C(64x64) = B(64xK=64) * M(64xK=64)^T on v_mfma_f64_16x16x4_f64; 4 waves, wave w owns tile row w.
+// acc[tc] holds the 16x16 tile (tile row = wave, tile column tc): element (row = (lane>>4) + 4*i,
+// col = lane & 15) in acc[tc][i].
+__device__ __forceinline__ void tile_mul_bt(const double* Bs, const double* Ms, int wave, int lane, v4f64 acc[4]) {
+  for (int tc = 0; tc < 4; ++tc) acc[tc] = (v4f64){ 0.0, 0.0, 0.0, 0.0 };
+  const int rr = lane & 15, kk = lane >> 4;
+  for (int k4 = 0; k4 < kNB / 4; ++k4) {
+    const double a = Bs[(wave * 16 + rr) * kLdT + k4 * 4 + kk];
+#pragma unroll
+    for (int tc = 0; tc < 4; ++tc) {
+      const double b = Ms[(tc * 16 + rr) * kLdT + k4 * 4 + kk];
+      acc[tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[tc], 0, 0, 0);
+    }
+  }
+}
+
+// mode 0 (TRSM):  A[rows_i, k0:k0+64] <- A[rows_i, k0:k0+64] * inv(L11)^T        grid.x = row blocks
+// mode 1 (SYRK):  A[rows_i, rows_j]   -= L[rows_i, k0:] * L[rows_j, k0:]^T        grid.x = lower tile pairs
+__global__ __launch_bounds__(256) void k_po_panel_update(PoPtrs p, int k0, int mode) {
+  if (p.st->status != kRunning) return;
+  __shared__ double Bs[kNB * kLdT];
+  __shared__ double Ms[kNB * kLdT];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int t0 = k0 + kNB;                       // first trailing row
+  int bi, bj = 0;
+  if (mode == 0) bi = blockIdx.x;
+  else {                                          // unpack lower-triangular pair index
+    int t = blockIdx.x;
+    bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((bi * (bi + 1)) / 2 > t) --bi;
+    while (((bi + 1) * (bi + 2)) / 2 <= t) ++bi;
+    bj = t - (bi * (bi + 1)) / 2;
+  }
+  const int ri = t0 + bi * kNB, rj = t0 + bj * kNB;
+  for (int q = tid; q < kNB * kNB; q += 256) {
+    const int r = q / kNB, c = q - r * kNB;
+    const bool cin = k0 + c < p.n;
+    Bs[r * kLdT + c] = (ri + r < p.n && cin) ? p.H[(long long)(ri + r) * p.ld + k0 + c] : 0.0;
+    if (mode == 0) Ms[r * kLdT + c] = p.linv[q];
+    else Ms[r * kLdT + c] = (rj + r < p.n && cin) ? p.H[(long long)(rj + r) * p.ld + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  v4f64 acc[4];
+  tile_mul_bt(Bs, Ms, wave, lane, acc);
+  const int col = lane & 15, rbase = lane >> 4;
+  for (int tc = 0; tc < 4; ++tc)
+    for (int i = 0; i < 4; ++i) {
+      const int r = ri + wave * 16 + rbase + 4 * i;
+      if (r >= p.n) continue;
+      if (mode == 0) {
+        const int c = k0 + tc * 16 + col;
+        if (c < p.n) p.H[(long long)r * p.ld + c] = acc[tc][i];
+      } else {
+        const int c = rj + tc * 16 + col;
+        if (c < p.n && c <= r) p.H[(long long)r * p.ld + c] -= acc[tc][i];
+      }
+    }
+}
+
+// forward then backward substitution with the factor in H; one workgroup.
+__global__ __launch_bounds__(256) void k_po_trisolve(PoPtrs p) {
+  if (p.st->status != kRunning) return;
+  __shared__ double yb[kNB];
+  const int tid = threadIdx.x;
+  const int n = p.n;
+  for (int k0 = 0; k0 < n; k0 += kNB) {
+    const int nb = min(kNB, n - k0);
+    // diagonal block: serial in the pivot
+    for (int j = 0; j < nb; ++j) {
+      __syncthreads();
+      const double yj = p.y[k0 + j] / p.H[(long long)(k0 + j) * p.ld + k0 + j];
+      __syncthreads();
+      if (tid == 0) { p.y[k0 + j] = yj; yb[j] = yj; }
+      const int r = k0 + j + 1 + tid;
+      if (r < k0 + nb) p.y[r] -= p.H[(long long)r * p.ld + k0 + j] * yj;
+    }
+    __syncthreads();
+    for (int r = k0 + nb + tid; r < n; r += 256) {
+      double s = 0.0;
+      for (int j = 0; j < nb; ++j) s += p.H[(long long)r * p.ld + k0 + j] * yb[j];
+      p.y[r] -= s;
+    }
+    __syncthreads();
+  }
+  const int nblk = (n + kNB - 1) / kNB;
+  for (int bk = nblk - 1; bk >= 0; --bk) {
+    const int k0 = bk * kNB, nb = min(kNB, n - k0);
+    for (int j = nb - 1; j >= 0; --j) {
+      __syncthreads();
+      const double yj = p.y[k0 + j] / p.H[(long long)(k0 + j) * p.ld + k0 + j];
+      __syncthreads();
+      if (tid == 0) { p.y[k0 + j] = yj; yb[j] = yj; }
+      const int r = k0 + tid;
+      if (tid < j) p.y[r] -= p.H[(long long)(k0 + j) * p.ld + r] * yj;
+    }
+    __syncthreads();
+    for (int r = tid; r < k0; r += 256) {
+      double s = 0.0;
+      for (int j = 0; j < nb; ++j) s += p.H[(long long)(k0 + j) * p.ld + r] * yb[j];
+      p.y[r] -= s;
+    }
+    __syncthreads();
+  }
+}
+
+// candidate poses and step statistics; one workgroup.
+__global__ __launch_bounds__(256) void k_po_candidate(PoPtrs p) {
+  LMState* st = p.st;
+  if (st->status != kRunning) return;
+  __shared__ double red[3][256];
+  const int tid = threadIdx.x;
+  const double* X = p.x + (long long)st->cur * 6 * p.N;
+  double* Xc = p.x + (long long)(1 - st->cur) * 6 * p.N;
+  double model = 0.0, dn2 = 0.0, xn2 = 0.0;
+  int bad = 0;
+  for (int k = tid; k < p.N; k += 256) {
+    const int s = p.slot[k];
+    for (int i = 0; i < 6; ++i) {
+      double v = X[6 * k + i];
+      if (s >= 0) {
+        const double y = p.y[s + i];
+        if (!isfinite(y)) bad = 1;
+        model += 0.5 * y * (p.g[s + i] + p.d2[s + i] * y);
+        const double xn = v - y * p.scale[s + i];
+        const double dd = v - xn;
+        dn2 += dd * dd; xn2 += xn * xn;
+        v = xn;
+      }
+      Xc[6 * k + i] = v;
+    }
+  }
+  red[0][tid] = model; red[1][tid] = dn2; red[2][tid] = xn2;
+  const int any_bad = __syncthreads_or(bad);
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) for (int q = 0; q < 3; ++q) red[q][tid] += red[q][tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    p.scal[kPoModel] = red[0][0]; p.scal[kPoDn2] = red[1][0]; p.scal[kPoXn2] = red[2][0];
+    st->solve_failed = (any_bad || p.flags[0]) ? 1 : 0;
+  }
+}
+
+// trust-region bookkeeping (one thread); same policy as k_lm_update.
+__global__ void k_po_update(PoPtrs p, Policy pol) {
+  LMState* st = p.st;
+  if (st->status != kRunning || threadIdx.x != 0 || blockIdx.x != 0) return;
+  double new_cost = p.scal[kPoCandCost];
+  const double model = p.scal[kPoModel], cost = st->cost;
+  IterRec rec;
+  rec.pad = 0; rec.iteration = st->iter + 1; rec.step_is_valid = 0; rec.step_is_successful = 0;
+  rec.model_cost_change = model; rec.cost_change = 0; rec.step_norm = 0; rec.relative_decrease = 0;
+  rec.gradient_max_norm = st->grad_max;
+  const bool valid = !st->solve_failed && !(model < 0.0);
+  if (!isfinite(new_cost)) new_cost = 1.7976931348623157e308;
+  if (!valid) {
+    if (++st->n_invalid >= pol.max_invalid) { st->status = 4; return; }
+  } else {
+    st->n_invalid = 0;
+    rec.step_is_valid = 1;
+    rec.step_norm = sqrt(p.scal[kPoDn2]);
+    if (rec.step_norm <= pol.parameter_tolerance * (st->x_norm + pol.parameter_tolerance)) { st->status = 3; return; }
+    rec.cost_change = cost - new_cost;
+    if (fabs(rec.cost_change) < pol.function_tolerance * cost) { st->status = 2; return; }
+    rec.relative_decrease = rec.cost_change / model;
+    rec.step_is_successful = rec.relative_decrease > pol.min_relative_decrease;
+  }
+  if (rec.step_is_successful) {
+    st->n_success++;
+    const double q = 2.0 * rec.relative_decrease - 1.0;
+    double f = 1.0 - q * q * q;
+    if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+    st->radius = fmin(st->radius / f, pol.max_radius);
+    st->decrease_factor = 2.0;
+    st->cur = 1 - st->cur;
+    st->cost = new_cost;
+    st->x_norm = sqrt(p.scal[kPoXn2]);
+    st->need_grad_check = 1;
+  } else {
+    st->n_unsuccess++;
+    if (rec.step_is_valid) { st->radius = st->radius / st->decrease_factor; st->decrease_factor *= 2.0; }
+    else st->radius *= 0.5;
+  }
+  rec.cost = st->cost + st->fixed_cost;
+  rec.trust_region_radius = st->radius;
+  if (rec.cost < st->min_cost) st->min_cost = rec.cost;
+  if (st->ntrace < kMaxTrace) p.trace[st->ntrace] = rec;
+  st->ntrace++;
+  st->iter = rec.iteration;
+  if (st->radius < pol.min_radius) { st->status = 5; return; }
+  if (st->iter >= pol.max_num_iterations) { st->status = 0; return; }
+}
+
+}  // namespace slslam
+#endif  // SLSLAM_PO_KERNELS_H_

@@ -1,0 +1,93 @@
+"""GPU parity tests of the pose-graph optimisation (slslam_po_solve) against the oracle and the
+committed scipy optimum.  Needs a real MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from slslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _trace_parity(t0, t1, n=None, tol=1e-8):
+    assert len(t0) == len(t1)
+    for a, b in list(zip(t0, t1))[:n]:
+        assert a["iteration"] == b["iteration"] and a["step_is_successful"] == b["step_is_successful"]
+        assert abs(a["cost"] - b["cost"]) <= tol * abs(a["cost"]) + 1e-18
+        assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-5 * a["trust_region_radius"]
+
+
+@pytest.mark.parametrize("seed,n,loops", [(1, 12, 1), (2, 40, 3), (3, 75, 4)])
+def test_po_matches_oracle(hip, oracle, seed, n, loops):
+    """Dual-number Jacobians on the device, dense MFMA Cholesky: cost trace and poses vs the oracle
+    (Jet<12> + dense Cholesky).  n = 12/40/75 poses -> 66/234/444 unknowns: one, four and seven
+    64-blocks, exercising the ragged last block of the blocked factorisation."""
+    g = synth.make_pose_graph(seed, num_poses=n, num_loops=loops)
+    x0, s0, t0 = oracle.po_solve(g)
+    x1, s1, t1 = hip.po_solve(g)
+    _trace_parity(t0, t1, n=3)
+    assert s0["num_successful_steps"] == s1["num_successful_steps"]
+    assert s0["termination_type"] == s1["termination_type"]
+    assert abs(s0["initial_cost"] - s1["initial_cost"]) <= 1e-12 * s0["initial_cost"]
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-7 * s0["final_cost"]
+    assert np.abs(x0 - x1).max() < 1e-6
+    assert np.array_equal(x1[:6], g["parameters"][:6])              # pose1 of edge 0 is constant (po_problem.cpp:62-63)
+    assert s1["num_free_parameters"] == 6 * (n - 1) and s1["num_residual_blocks"] == len(g["pose_index_1"])
+
+
+def test_po_golden_optimum(hip):
+    z = np.load(os.path.join(GOLD, "po_optimum.npz"))
+    g = {k: z[k] for k in z.files}
+    g["num_poses"] = int(z["num_poses"])
+    x, s, t = hip.po_solve(g, max_num_iterations=60, function_tolerance=1e-16, parameter_tolerance=1e-14, gradient_tolerance=1e-16)
+    assert abs(s["initial_cost"] - float(z["initial_cost"])) < 1e-12 * float(z["initial_cost"])
+    assert abs(s["final_cost"] - float(z["optimum_cost"])) < 1e-8 * float(z["optimum_cost"])
+    assert np.abs(x - z["optimum"]).max() < 1e-5
+
+
+def test_po_consistent_graph_and_edge_cases(hip):
+    g = synth.make_pose_graph(4, num_poses=30, num_loops=2)
+    truth = g["true_parameters"].reshape(-1, 6)
+    cons = []
+    for a, b in zip(g["pose_index_1"], g["pose_index_2"]):
+        Ra, ta = synth.wt_to_rt(truth[a]); Rb, tb = synth.wt_to_rt(truth[b])
+        Rrel = Rb @ Ra.T
+        cons.append(synth.rt_to_wt(Rrel, tb - Rrel @ ta))
+    g0 = dict(g, constraints=np.array(cons), parameters=g["true_parameters"])
+    x, s, t = hip.po_solve(g0)                       # Te = identity on every edge: zero cost, nothing to do
+    assert s["initial_cost"] < 1e-25 and np.abs(x - g["true_parameters"]).max() < 1e-12
+    # zero iterations / no edges
+    x, s, t = hip.po_solve(g, max_num_iterations=0)
+    assert np.array_equal(x, g["parameters"])
+    ge = dict(num_poses=3, pose_index_1=np.zeros(0, np.int32), pose_index_2=np.zeros(0, np.int32),
+              constraints=np.zeros((0, 6)), parameters=np.arange(18.0))
+    x, s, t = hip.po_solve(ge)
+    assert np.array_equal(x, np.arange(18.0))
+    # an unreferenced pose stays untouched; a bad index is rejected
+    g2 = dict(g, num_poses=31, parameters=np.concatenate([g["parameters"], np.arange(6.0)]))
+    x, s, t = hip.po_solve(g2)
+    assert np.array_equal(x[-6:], np.arange(6.0)) and s["num_free_parameters"] == 6 * 29
+    bad = dict(g, pose_index_2=g["pose_index_2"].copy()); bad["pose_index_2"][1] = 99
+    with pytest.raises(hip.SlslamError):
+        hip.po_solve(bad)
+
+
+def test_po_full_size_loop_closure(hip, oracle):
+    """BASELINE config 5: ~260 poses with loop closures, 10 iterations (slam.cpp:1283)."""
+    g = synth.make_pose_graph(7, num_poses=260, num_loops=8)
+    x1, s1, t1 = hip.po_solve(g)
+    assert s1["num_free_parameters"] == 1554
+    costs = [r["cost"] for r in t1]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
+    assert s1["final_cost"] < 0.05 * s1["initial_cost"]
+    # loop closure pulls the dead-reckoned trajectory back towards the truth
+    c_true = synth.camera_centers(g["true_parameters"])
+    e0 = np.linalg.norm(synth.camera_centers(g["parameters"]) - c_true, axis=1)
+    e1 = np.linalg.norm(synth.camera_centers(x1) - c_true, axis=1)
+    assert np.sqrt((e1 ** 2).mean()) < 0.7 * np.sqrt((e0 ** 2).mean())
+    x0, s0, t0 = oracle.po_solve(g)
+    _trace_parity(t0, t1, n=3)
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-6 * s0["final_cost"]
+    assert np.abs(x0 - x1).max() < 1e-5
