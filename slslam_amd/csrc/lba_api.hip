@@ -123,7 +123,7 @@ struct slslam_lba_batch {
   DevBuf<double> d_cam_x, d_cam_x0, d_cam_scale; DevBuf<int> d_cam_cf, d_cam_win;
   DevBuf<double> d_line_x, d_line_x0, d_line_scale; DevBuf<int> d_line_ptr, d_line_flags, d_line_win, d_line_orig;
   DevBuf<double> d_ob; DevBuf<int> d_ob_cam, d_ob_orig;
-  DevBuf<double> d_slab, d_bs_part, d_cost_part, d_ysys, d_params_out;
+  DevBuf<double> d_slab, d_bs_part, d_cost_part, d_ysys, d_params_out, d_fstore, d_line_elim;
   DevBuf<LMState> d_state; DevBuf<IterRec> d_trace; DevBuf<long long> d_param_off;
   BatchPtrs ptrs;
   int nchunk = 0, nline = 0, ncam = 0;
@@ -146,6 +146,7 @@ struct slslam_lba_batch {
     d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release();
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
     d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release();
+    d_fstore.release(); d_line_elim.release();
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     if (capture_stream) { (void)hipStreamDestroy(capture_stream); capture_stream = nullptr; }
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -253,7 +254,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     }
     for (int o = 0; o < P.M; ++o) {
       ob_cam.push_back(P.ob_cam[o]); ob_orig.push_back(P.ob_orig[o]);
-      for (int q = 0; q < 8; ++q) ob[(size_t)q * (size_t)nobs + (size_t)(obs_cursor + o)] = P.ob[(size_t)q * P.M + o];
+      for (int q = 0; q < 8; ++q)   // planes of (x,y) pairs: ob[((q/2) * nobs + o) * 2 + (q & 1)]
+        ob[((size_t)(q >> 1) * (size_t)nobs + (size_t)(obs_cursor + o)) * 2 + (q & 1)] = P.ob[(size_t)q * P.M + o];
     }
     ncam += P.C; nline += P.L; obs_cursor += P.M; sys += wd.n;
   }
@@ -303,6 +305,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if ((rc = b->d_bs_part.alloc(std::max<size_t>(1, (size_t)b->nchunk * kBsStride)))) return rc;
   if ((rc = b->d_cost_part.alloc(std::max<size_t>(1, (size_t)b->nchunk)))) return rc;
   if ((rc = b->d_ysys.alloc(std::max<size_t>(1, (size_t)sys)))) return rc;
+  if ((rc = b->d_fstore.alloc((size_t)24 * (size_t)std::max<long long>(1, nobs)))) return rc;
+  if ((rc = b->d_line_elim.alloc(std::max<size_t>(1, (size_t)nline * kLineElim)))) return rc;
   if ((rc = b->d_params_out.alloc(std::max<size_t>(1, (size_t)param_off)))) return rc;
   if ((rc = b->d_state.upload(b->h_state0))) return rc;
   if ((rc = b->d_trace.alloc(std::max<size_t>(1, (size_t)B * kMaxTrace)))) return rc;
@@ -320,6 +324,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.line_flags = b->d_line_flags.p; p.line_win = b->d_line_win.p;
   p.ob = b->d_ob.p; p.ob_cam = b->d_ob_cam.p; p.ob_stride = std::max<long long>(1, nobs);
   p.slab = b->d_slab.p; p.bs_part = b->d_bs_part.p; p.cost_part = b->d_cost_part.p; p.ysys = b->d_ysys.p;
+  p.fstore = b->d_fstore.p; p.line_elim = b->d_line_elim.p;
   p.state = b->d_state.p; p.trace = b->d_trace.p;
   p.iter_counter = b->d_iter_counter.p; p.cam_x0 = b->d_cam_x0.p; p.line_u0 = b->d_line_x0.p;
   p.nwin = B; p.nchunk = b->nchunk; p.nline = b->nline; p.ncam = b->ncam;

@@ -32,8 +32,23 @@ enum { kCamTab = 29 };   // doubles per camera in LDS: R[9] JL[9] t[3] scale[6] 
 
 __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 2 + c; }  // r >= c
 
+// Sum over a 2^g-lane group, result in every lane of the group (bitwise identical across the
+// group).  Widths up to 16 stay on the VALU with DPP (quad_perm / row_half_mirror / row_mirror);
+// only the rare 32- and 64-lane groups go through ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double group_sum(double v, int width) {
-  for (int o = 1; o < width; o <<= 1) v += __shfl_xor(v, o);
+  v += dpp_move<0xB1>(v);                    // quad_perm [1,0,3,2]
+  if (width > 2) v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
+  if (width > 4) v += dpp_move<0x141>(v);    // row_half_mirror: lane i <-> 7 - i
+  if (width > 8) v += dpp_move<0x140>(v);    // row_mirror: lane i <-> 15 - i
+  if (width > 16) v += __shfl_xor(v, 16);
+  if (width > 32) v += __shfl_xor(v, 32);
   return v;
 }
 __device__ __forceinline__ double wave_sum(double v) {
@@ -60,24 +75,47 @@ struct LaneLin {
   bool valid, kept, line_free;
 };
 
+// What a lane needs to know before it can touch its observation: fetched one tile AHEAD so that
+// the dependent chain  tile descriptor -> line_ptr -> observation  is off the critical path.
+struct TileCtx {
+  int glog2, ls, j, o0, k, lflags, nitems, item_off;
+  bool line_ok;
+};
+__device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_end, int lane) {
+  TileCtx c;
+  c.glog2 = 1; c.ls = 0; c.j = 0; c.o0 = 0; c.k = 0; c.lflags = 1; c.nitems = 0; c.item_off = 0; c.line_ok = false;
+  if (t < t_end) {
+    const Tile tl = p.tiles[t];
+    c.glog2 = tl.glog2; c.nitems = tl.nitems; c.item_off = tl.item_off;
+    const int lsub = lane >> tl.glog2;
+    c.j = lane & ((1 << tl.glog2) - 1);
+    c.ls = tl.line_begin + lsub;
+    c.line_ok = lsub < tl.nlines;
+    if (c.line_ok) { c.o0 = p.line_ptr[c.ls]; c.k = p.line_ptr[c.ls + 1] - c.o0; c.lflags = p.line_flags[c.ls]; }
+  }
+  return c;
+}
+
 // Load one observation + its line record and linearise it.  cur selects the parameter buffer.
 // SCALED: apply the Jacobi column scaling (false for the initial evaluation and the test hook).
 template <bool SCALED>
 __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy& pol, const double* camtab,
                                                const int* camcf, int ls, int j, int k, int o0, bool line_ok,
-                                               int cur, int safe_obs, LaneLin& L) {
+                                               int lflags, int cur, int safe_obs, LaneLin& L) {
   L.valid = line_ok && j < k;
   const int o = L.valid ? o0 + j : safe_obs;
   double ob[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) ob[q] = p.ob[(long long)q * p.ob_stride + o];
+  for (int q = 0; q < 4; ++q) {     // (x,y) endpoint pairs: one 16-byte load per plane
+    const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
+    ob[2 * q] = e.x; ob[2 * q + 1] = e.y;
+  }
   L.cam = p.ob_cam[o];
   const int lsafe = line_ok ? ls : 0;
   const double* lrec = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
   double trig[7];
 #pragma unroll
   for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
-  const int lflags = p.line_flags[lsafe];
   L.line_free = line_ok && !(lflags & 1);
   const double* ct = camtab + L.cam * kCamTab;
   double R[9], JL[9], t[3];
@@ -144,19 +182,19 @@ __device__ __forceinline__ bool chol4_inverse(const double H[10], const double D
   const double a00 = H[0] + D2[0], a10 = H[1], a11 = H[2] + D2[1], a20 = H[3], a21 = H[4],
                a22 = H[5] + D2[2], a30 = H[6], a31 = H[7], a32 = H[8], a33 = H[9] + D2[3];
   bool ok = a00 > 0.0;
-  const double i0 = 1.0 / sqrt(a00);
+  const double i0 = inv_sqrt<double>(a00);
   const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
   const double d1 = a11 - l10 * l10;
   ok = ok && d1 > 0.0;
-  const double i1 = 1.0 / sqrt(d1);
+  const double i1 = inv_sqrt<double>(d1);
   const double l21 = (a21 - l20 * l10) * i1, l31 = (a31 - l30 * l10) * i1;
   const double d2 = a22 - l20 * l20 - l21 * l21;
   ok = ok && d2 > 0.0;
-  const double i2 = 1.0 / sqrt(d2);
+  const double i2 = inv_sqrt<double>(d2);
   const double l32 = (a32 - l30 * l20 - l31 * l21) * i2;
   const double d3 = a33 - l30 * l30 - l31 * l31 - l32 * l32;
   ok = ok && d3 > 0.0;
-  const double i3 = 1.0 / sqrt(d3);
+  const double i3 = inv_sqrt<double>(d3);
   // inverse of the lower-triangular factor (diagonal of Lc is 1/i_k)
   K[0] = i0; K[2] = i1; K[5] = i2; K[9] = i3;
   K[1] = -l10 * K[0] * i1;
@@ -243,16 +281,15 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
 
   double acc_cost = 0.0, acc_fixed = 0.0, acc_gmax = 0.0, acc_xn2 = 0.0;
   int fail = 0;
+  TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
-    const Tile tl = p.tiles[t];
-    const int width = 1 << tl.glog2;
-    const int lsub = lane >> tl.glog2, j = lane & (width - 1);
-    const int ls = tl.line_begin + lsub;
-    const bool line_ok = lsub < tl.nlines;
-    int o0 = 0, k = 0;
-    if (line_ok) { o0 = p.line_ptr[ls]; k = p.line_ptr[ls + 1] - o0; }
+    const TileCtx tc = nxt;
+    nxt = fetch_tile(p, t + 1, ck.tile_end, lane);      // in flight while this tile is processed
+    const int width = 1 << tc.glog2;
+    const int j = tc.j, ls = tc.ls, o0 = tc.o0, k = tc.k;
+    const bool line_ok = tc.line_ok;
     LaneLin L;
-    lane_linearise<!INIT>(p, pol, camtab, camcf, ls, j, k, o0, line_ok, cur, wd.obs_off, L);
+    lane_linearise<!INIT>(p, pol, camtab, camcf, ls, j, k, o0, line_ok, tc.lflags, cur, wd.obs_off, L);
     if (L.kept) acc_cost += L.cost;
     if (INIT && L.valid && !L.kept) acc_fixed += L.cost;
 
@@ -303,6 +340,21 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     const bool elim = cam_free && L.line_free;       // this observation couples a free camera to a free line
     if (elim) lane_F(L, K, F);
     else { for (int q = 0; q < 24; ++q) F[q] = 0.0; }
+    // keep what the back-substitution needs (24 doubles per coupled observation, 22 per line) so
+    // that it does not have to linearise again
+    if (elim) {
+      const long long o = (long long)o0 + j;
+#pragma unroll
+      for (int q = 0; q < 12; ++q)
+        reinterpret_cast<double2*>(p.fstore)[(long long)q * p.ob_stride + o] = make_double2(F[2 * q], F[2 * q + 1]);
+    }
+    if (line_active && j == 0) {
+      double* le = p.line_elim + (long long)ls * kLineElim;
+#pragma unroll
+      for (int q = 0; q < 10; ++q) le[q] = K[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { le[10 + q] = u[q]; le[14 + q] = D2[q]; le[18 + q] = g[q]; }
+    }
 
     if (cam_free) {
       const int base = 6 * L.cf;
@@ -328,11 +380,11 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     }
 
     // ---- off-diagonal camera pairs of the tile, balanced over the lanes
-    for (int base_it = 0; base_it < tl.nitems; base_it += 64) {
+    for (int base_it = 0; base_it < tc.nitems; base_it += 64) {
       const int it = base_it + lane;
-      const bool has = it < tl.nitems;
+      const bool has = it < tc.nitems;
       int li = 0, lj = 0;
-      if (has) { li = p.items[2 * (long long)(tl.item_off + it)]; lj = p.items[2 * (long long)(tl.item_off + it) + 1]; }
+      if (has) { li = p.items[2 * (long long)(tc.item_off + it)]; lj = p.items[2 * (long long)(tc.item_off + it) + 1]; }
       double Fi[24], Fj[24];
 #pragma unroll
       for (int q = 0; q < 24; ++q) { Fi[q] = __shfl(F[q], li); Fj[q] = __shfl(F[q], lj); }
@@ -398,18 +450,23 @@ __global__ __launch_bounds__(64) void k_reduced_solve(BatchPtrs p, Policy pol) {
   const int need_grad_check = st->need_grad_check;
   const double abs_grad_tol = st->abs_grad_tol;
 
-  // ordered (bitwise reproducible) reduction over the window's chunk partials
-  for (int r = 0; r < n; ++r)
-    for (int c = lane; c <= r; c += 64) {
-      const int q = tri_index(r, c);
-      double s = 0.0;
-      for (int k = 0; k < wd.nchunks; ++k) s += p.slab[p.chunks[wd.chunk_off + k].slab_off + q];
-      A[r * ld + c] = s;
-    }
-  for (int q = lane; q < 3 * n; q += 64) {
+  // ordered (bitwise reproducible) reduction over the window's chunk partials; the slabs of one
+  // window are consecutive with a uniform stride, so the loads of the chunk loop are independent
+  const long long slab0 = p.chunks[wd.chunk_off].slab_off;
+  const long long sstride = (long long)ntri + 3 * n + kSlabScalars;
+  for (int q = lane; q < ntri + 3 * n; q += 64) {
+    const double* src = p.slab + slab0 + q;
     double s = 0.0;
-    for (int k = 0; k < wd.nchunks; ++k) s += p.slab[p.chunks[wd.chunk_off + k].slab_off + ntri + q];
-    bvec[q] = s;
+#pragma unroll 8
+    for (int k = 0; k < wd.nchunks; ++k) s += src[k * sstride];
+    if (q < ntri) {
+      int r = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+      while (tri_index(r, 0) > q) --r;
+      while (tri_index(r + 1, 0) <= q) ++r;
+      A[r * ld + (q - tri_index(r, 0))] = s;
+    } else {
+      bvec[q - ntri] = s;
+    }
   }
   double gmax_line = 0.0;
   int fail = 0;
@@ -528,9 +585,10 @@ __global__ __launch_bounds__(64) void k_reduced_solve(BatchPtrs p, Policy pol) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel 3: back-substitution  y_l = A^-1 (g_l - sum_i H_cl,i^T y_c)  = K^T (u - K w),
-// candidate line parameters, line part of the step statistics.
-__host__ __device__ inline int lds_doubles_backsub(int C, int n) { return C * kCamTab + n + (C + 1) / 2 + 2; }
+// Kernel 3: back-substitution  y_l = A^-1 (g_l - sum_i H_cl,i^T y_c) = K^T (u - sum_i F_i^T y_c,i),
+// candidate line parameters, line part of the step statistics.  Streams the F blocks and the
+// per-line factors the elimination kernel left in HBM: no second linearisation.
+__host__ __device__ inline int lds_doubles_backsub(int C, int n) { return n + (C + 1) / 2 + 2; }
 
 __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -540,13 +598,11 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
   const LMState* st = p.state + ck.win;
   if (st->status != kRunning) return;
   const int cur = st->cur;
-  const double radius = st->radius;
   const int n = wd.n;
-  double* camtab = smem;
-  double* yc = camtab + wd.C * kCamTab;
+  double* yc = smem;
   int* camcf = (int*)(yc + n);
-  load_cam_table<true, false>(p, wd, cur, lane, camtab, camcf);
   for (int q = lane; q < n; q += 64) yc[q] = p.ysys[wd.sys_off + q];
+  for (int c = lane; c < wd.C; c += 64) camcf[c] = p.cam_cf[wd.cam_off + c];
   __syncthreads();
 
   double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0;
@@ -556,58 +612,54 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
     const int lsub = lane >> tl.glog2, j = lane & (width - 1);
     const int ls = tl.line_begin + lsub;
     const bool line_ok = lsub < tl.nlines;
-    int o0 = 0, k = 0;
-    if (line_ok) { o0 = p.line_ptr[ls]; k = p.line_ptr[ls + 1] - o0; }
-    LaneLin L;
-    lane_linearise<true>(p, pol, camtab, camcf, ls, j, k, o0, line_ok, cur, wd.obs_off, L);
-    double H[10], g[4];
-    line_block(L, width, H, g);
-    const bool line_active = L.line_free && k > 0;
-    // w = sum_i (Jc_i^T Jl_i)^T y_c[cam_i] = sum_i Jl_i^T (Jc_i y_c)
-    double wv[4] = { 0, 0, 0, 0 };
-    if (L.valid && L.cf >= 0 && L.line_free) {
-      double jy[4];
+    int o0 = 0, k = 0, lflags = 1;
+    if (line_ok) { o0 = p.line_ptr[ls]; k = p.line_ptr[ls + 1] - o0; lflags = p.line_flags[ls]; }
+    const bool line_active = line_ok && !(lflags & 1) && k > 0;
+    const bool valid = line_ok && j < k;
+    double v[4] = { 0, 0, 0, 0 };
+    if (valid && line_active) {
+      const long long o = (long long)o0 + j;
+      const int cf = camcf[p.ob_cam[o]];
+      if (cf >= 0) {
+        const double* y = yc + 6 * cf;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double s = 0.0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) s += L.Jc[6 * r + a] * yc[6 * L.cf + a];
-        jy[r] = s;
+        for (int a = 0; a < 6; ++a) {
+          const double ya = y[a];
+          const double2 f01 = reinterpret_cast<const double2*>(p.fstore)[(long long)(2 * a) * p.ob_stride + o];
+          const double2 f23 = reinterpret_cast<const double2*>(p.fstore)[(long long)(2 * a + 1) * p.ob_stride + o];
+          v[0] += f01.x * ya; v[1] += f01.y * ya; v[2] += f23.x * ya; v[3] += f23.y * ya;
+        }
       }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) wv[a] = L.Jl[a] * jy[0] + L.Jl[4 + a] * jy[1] + L.Jl[8 + a] * jy[2] + L.Jl[12 + a] * jy[3];
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a) wv[a] = group_sum(wv[a], width);
+    for (int m = 0; m < 4; ++m) v[m] = group_sum(v[m], width);
     if (line_ok && j == 0) {
       const double* xl = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
       double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
       double xn[4] = { xl[0], xl[1], xl[2], xl[3] };
       if (line_active) {
-        double D2[4], K[10];
-        lm_diag4(H, pol, radius, D2);
-        chol4_inverse(H, D2, K);
-        // z = K (g - w);  y = K^T z
-        const double e0 = g[0] - wv[0], e1 = g[1] - wv[1], e2 = g[2] - wv[2], e3 = g[3] - wv[3];
-        const double z0 = K[0] * e0;
-        const double z1 = K[1] * e0 + K[2] * e1;
-        const double z2 = K[3] * e0 + K[4] * e1 + K[5] * e2;
-        const double z3 = K[6] * e0 + K[7] * e1 + K[8] * e2 + K[9] * e3;
+        const double* le = p.line_elim + (long long)ls * kLineElim;
+        double K[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) K[q] = le[q];
+        const double z0 = le[10] - v[0], z1 = le[11] - v[1], z2 = le[12] - v[2], z3 = le[13] - v[3];
         double y[4];
         y[0] = K[0] * z0 + K[1] * z1 + K[3] * z2 + K[6] * z3;
         y[1] = K[2] * z1 + K[4] * z2 + K[7] * z3;
         y[2] = K[5] * z2 + K[8] * z3;
         y[3] = K[9] * z3;
         const double* lsc = p.line_scale + (long long)ls * 4;
+#pragma unroll
         for (int a = 0; a < 4; ++a) {
-          acc_model += 0.5 * y[a] * (g[a] + D2[a] * y[a]);
-          const double v = xn[a] - y[a] * lsc[a];
-          const double dd = xn[a] - v;
+          acc_model += 0.5 * y[a] * (le[18 + a] + le[14 + a] * y[a]);
+          const double vv = xn[a] - y[a] * lsc[a];
+          const double dd = xn[a] - vv;
           acc_dn2 += dd * dd;
-          acc_xn2 += v * v;
-          xn[a] = v;
+          acc_xn2 += vv * vv;
+          xn[a] = vv;
         }
       }
+#pragma unroll
       for (int a = 0; a < 4; ++a) xc[a] = xn[a];
     }
   }
@@ -662,7 +714,10 @@ __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) 
     const int o = valid ? o0 + j : wd.obs_off;
     double ob[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) ob[q] = p.ob[(long long)q * p.ob_stride + o];
+    for (int q = 0; q < 4; ++q) {
+      const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
+      ob[2 * q] = e.x; ob[2 * q + 1] = e.y;
+    }
     const int cam = p.ob_cam[o];
     const int lsafe = line_ok ? ls : 0;
     const double* lrec = p.line_x + ((long long)lsafe * 2 + cand) * kLineRec;
@@ -817,7 +872,7 @@ __global__ __launch_bounds__(64) void k_debug_linearise(BatchPtrs p, Policy pol,
     for (int j0 = 0; j0 < k; j0 += 64) {
       const int j = j0 + lane;
       LaneLin L;
-      lane_linearise<false>(p, pol, camtab, camcf, ls, j, k, o0, true, cur, wd.obs_off, L);
+      lane_linearise<false>(p, pol, camtab, camcf, ls, j, k, o0, true, p.line_flags[ls], cur, wd.obs_off, L);
       if (L.valid) {
         const int orig = ob_orig[o0 + j];
         for (int q = 0; q < 4; ++q) out_r[4 * (long long)orig + q] = L.rs[q];

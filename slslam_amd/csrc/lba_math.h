@@ -30,6 +30,17 @@
 
 namespace slslam {
 
+// 1/sqrt(x): one v_rsq_f64 + refinement on the device instead of a full-precision sqrt followed by a
+// full-precision divide (~30 fp64 instructions).
+template <typename T>
+SLS_HD T inv_sqrt(T x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return rsqrt(x);
+#else
+  return T(1) / sqrt(x);
+#endif
+}
+
 // Rotation matrix (row-major) of the angle-axis w and the left Jacobian of SO(3),
 //   d(R(w) p)/dw = -[R p]x JL(w),   JL = (sin t/t) I + ((1-cos t)/t) [u]x + (1 - sin t/t) u u^T.
 // Value follows ceres::AngleAxisRotatePoint as used at lba_problem.h:75-76:
@@ -148,7 +159,7 @@ SLS_HD void obs_residual(const T R[9], const T t[3], const T cp[3], const T dv[3
     const T n0 = P[1] * dc[2] - P[2] * dc[1];
     const T n1 = P[2] * dc[0] - P[0] * dc[2];
     const T n2 = P[0] * dc[1] - P[1] * dc[0];
-    const T is = T(1) / sqrt(n0 * n0 + n1 * n1);
+    const T is = inv_sqrt<T>(n0 * n0 + n1 * n1);
     const T m0 = n0 * is, m1 = n1 * is, m2 = n2 * is;
     r[2 * k] = -(ob[4 * k] * m0 + ob[4 * k + 1] * m1 + m2);
     r[2 * k + 1] = -(ob[4 * k + 2] * m0 + ob[4 * k + 3] * m1 + m2);
@@ -171,7 +182,7 @@ SLS_HD void obs_linearise(const T R[9], const T JL[9], const T t[3],
     const T n0 = P[1] * dc[2] - P[2] * dc[1];
     const T n1 = P[2] * dc[0] - P[0] * dc[2];
     const T n2 = P[0] * dc[1] - P[1] * dc[0];
-    const T is = T(1) / sqrt(n0 * n0 + n1 * n1);
+    const T is = inv_sqrt<T>(n0 * n0 + n1 * n1);
     const T m0 = n0 * is, m1 = n1 * is, m2 = n2 * is;
     for (int e = 0; e < 2; ++e) {
       const int row = 2 * k + e;
@@ -208,9 +219,10 @@ SLS_HD void obs_linearise(const T R[9], const T JL[9], const T t[3],
 template <typename T>
 SLS_HD T huber_scale(T s, T a, T* cost) {
   if (a > T(0) && s > a * a) {
-    const T rn = sqrt(s);
-    *cost = T(0.5) * (T(2) * a * rn - a * a);
-    return sqrt(a / rn);
+    const T t = inv_sqrt<T>(s);                 // 1 / ||r||
+    *cost = T(0.5) * (T(2) * a * (s * t) - a * a);
+    const T q = a * t;                          // rho' = a / ||r||
+    return q * inv_sqrt<T>(q);                  // sqrt(rho')
   }
   *cost = T(0.5) * s;
   return T(1);

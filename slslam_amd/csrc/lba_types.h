@@ -13,6 +13,7 @@ namespace slslam {
 enum { kRunning = -1 };                 // LMState.status while the window is still iterating
 enum { kMaxTrace = 64 };                // iteration records kept per window
 enum { kLineRec = 12 };                 // doubles per line record: u[4], trig[7], pad
+enum { kLineElim = 22 };               // doubles per line kept by the elimination: K[10], u[4], D2[4], g[4]
 enum { kCamRec = 6 };                   // doubles per camera record: w[3], t[3]
 enum { kSlabScalars = 8 };              // per-chunk scalars written by the linearise kernel
 enum { kMaxCams = 64, kMaxFreeCams = 20 };
@@ -106,7 +107,7 @@ struct BatchPtrs {
   const int* line_flags;      // [nline] bit0: constant
   const int* line_win;        // [nline]
   // observations (sorted, structure of arrays)
-  const double* ob;           // [8][ob_stride]
+  const double* ob;           // [4][ob_stride] double2: (x,y) of the four observed endpoints
   const int* ob_cam;          // [nobs] window-local camera id
   long long ob_stride;
   // per-chunk / per-window work areas
@@ -114,6 +115,8 @@ struct BatchPtrs {
   double* bs_part;            // [nchunk][kBsStride]
   double* cost_part;          // [nchunk]
   double* ysys;               // y_c per window (sys_off)
+  double* fstore;             // [12][ob_stride] double2: F = (Jc^T Jl) K^T (6x4, row-major) of every coupled observation
+  double* line_elim;          // [nline][kLineElim]
   LMState* state;
   IterRec* trace;             // [nwin][kMaxTrace]
   unsigned long long* iter_counter;   // LM iterations executed by the batch since the counter was cleared
