@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--lines", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph (no per-kernel events)")
+    ap.add_argument("--chunks", type=int, default=0, help="waves cooperating on one window (0 = library default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,7 +87,7 @@ def main():
     batch = capi.LBABatch(device=local_rank)
     for w in windows:
         batch.add(w)
-    batch.finalize(use_graph=1 if args.graph else 0)
+    batch.finalize(use_graph=1 if args.graph else 0, chunks_per_window=args.chunks)
     batch.set_profiling(not args.graph)
     stream = torch.cuda.current_stream().cuda_stream
     counts = [(w["num_cameras"], w["num_free_cameras"], w["num_lines"], len(w["camera_index"])) for w in windows]

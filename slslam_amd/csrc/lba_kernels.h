@@ -42,14 +42,32 @@ __device__ __forceinline__ double dpp_move(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double group_sum(double v, int width) {
-  v += dpp_move<0xB1>(v);                    // quad_perm [1,0,3,2]
-  if (width > 2) v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
-  if (width > 4) v += dpp_move<0x141>(v);    // row_half_mirror: lane i <-> 7 - i
-  if (width > 8) v += dpp_move<0x140>(v);    // row_mirror: lane i <-> 15 - i
-  if (width > 16) v += __shfl_xor(v, 16);
-  if (width > 32) v += __shfl_xor(v, 32);
-  return v;
+// N values at once, step-major: one wave-uniform branch per reduction step for the whole batch
+// (value-major order made the compiler emit a branch ladder and a drained wait per value).
+template <int N>
+__device__ __forceinline__ void group_sum_n(double (&v)[N], int width) {
+#pragma unroll
+  for (int q = 0; q < N; ++q) v[q] += dpp_move<0xB1>(v[q]);                    // quad_perm [1,0,3,2]
+  if (width > 2) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] += dpp_move<0x4E>(v[q]);                  // quad_perm [2,3,0,1]
+  }
+  if (width > 4) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] += dpp_move<0x141>(v[q]);                 // row_half_mirror: i <-> 7 - i
+  }
+  if (width > 8) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] += dpp_move<0x140>(v[q]);                 // row_mirror: i <-> 15 - i
+  }
+  if (width > 16) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] += __shfl_xor(v[q], 16);
+  }
+  if (width > 32) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] += __shfl_xor(v[q], 32);
+  }
 }
 __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -158,6 +176,7 @@ __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy&
 // ends with the same values): H = sum Jl^T Jl (lower triangle, 10 values), g = sum Jl^T r.
 __device__ __forceinline__ void line_block(const LaneLin& L, int width, double H[10], double g[4]) {
   const bool m = L.valid && L.line_free;
+  double v[14];
   int q = 0;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -166,13 +185,21 @@ __device__ __forceinline__ void line_block(const LaneLin& L, int width, double H
       double h = 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) h += L.Jl[4 * r + a] * L.Jl[4 * r + b];
-      H[q++] = group_sum(m ? h : 0.0, width);
+      v[q++] = m ? h : 0.0;
     }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
     double ga = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) ga += L.Jl[4 * r + a] * L.rs[r];
-    g[a] = group_sum(m ? ga : 0.0, width);
+    v[10 + a] = m ? ga : 0.0;
   }
+  group_sum_n<14>(v, width);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) H[i] = v[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) g[i] = v[10 + i];
 }
 
 // A = H + diag(D2), A = Lc Lc^T, K = Lc^-1 (lower, 10 values, same packing as H).
@@ -342,7 +369,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     else { for (int q = 0; q < 24; ++q) F[q] = 0.0; }
     // keep what the back-substitution needs (24 doubles per coupled observation, 22 per line) so
     // that it does not have to linearise again
-    if (elim) {
+    if (elim && !(pol.pad & 4)) {
       const long long o = (long long)o0 + j;
 #pragma unroll
       for (int q = 0; q < 12; ++q)
@@ -356,7 +383,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       for (int q = 0; q < 4; ++q) { le[10 + q] = u[q]; le[14 + q] = D2[q]; le[18 + q] = g[q]; }
     }
 
-    if (cam_free) {
+    if (cam_free && !(pol.pad & 2)) {
       const int base = 6 * L.cf;
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
@@ -380,7 +407,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     }
 
     // ---- off-diagonal camera pairs of the tile, balanced over the lanes
-    for (int base_it = 0; base_it < tc.nitems; base_it += 64) {
+    for (int base_it = 0; base_it < ((pol.pad & 1) ? 0 : tc.nitems); base_it += 64) {
       const int it = base_it + lane;
       const bool has = it < tc.nitems;
       int li = 0, lj = 0;
@@ -631,8 +658,7 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
         }
       }
     }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) v[m] = group_sum(v[m], width);
+    group_sum_n<4>(v, width);
     if (line_ok && j == 0) {
       const double* xl = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
       double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
