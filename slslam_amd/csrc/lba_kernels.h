@@ -27,8 +27,9 @@
 
 namespace slslam {
 
-enum { kCamTab = 29 };   // doubles per camera in LDS: R[9] JL[9] t[3] scale[6] + 2 pad (odd stride:
-                         // 58 dwords, conflict-free ds_read_b64 across cameras)
+enum { kCamTab = 27 };   // doubles per camera in LDS: R[9] JL[9] t[3] scale[6]; odd stride (54 dwords):
+                         // conflict-free ds_read_b64 across cameras.  With the int8 free-index table the
+                         // linearise kernel needs 20 424 B for 20 cameras / 10 free -> 8 workgroups per CU
 
 __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 2 + c; }  // r >= c
 
@@ -118,7 +119,7 @@ __device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_e
 // SCALED: apply the Jacobi column scaling (false for the initial evaluation and the test hook).
 template <bool SCALED>
 __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy& pol, const double* camtab,
-                                               const int* camcf, int ls, int j, int k, int o0, bool line_ok,
+                                               const signed char* camcf, int ls, int j, int k, int o0, bool line_ok,
                                                int lflags, int cur, int safe_obs, LaneLin& L) {
   L.valid = line_ok && j < k;
   const int o = L.valid ? o0 + j : safe_obs;
@@ -262,7 +263,7 @@ __device__ __forceinline__ void lane_F(const LaneLin& L, const double K[10], dou
 // Camera table of one window in LDS.  WITH_JAC: R and JL at buffer `buf`; else R only.
 template <bool WITH_JAC, bool UNIT_SCALE>
 __device__ __forceinline__ void load_cam_table(const BatchPtrs& p, const WinDesc& wd, int buf, int lane,
-                                               double* camtab, int* camcf) {
+                                               double* camtab, signed char* camcf) {
   for (int c = lane; c < wd.C; c += 64) {
     const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + buf) * kCamRec;
     double w[3] = { x[0], x[1], x[2] }, R[9], JL[9];
@@ -272,13 +273,13 @@ __device__ __forceinline__ void load_cam_table(const BatchPtrs& p, const WinDesc
     for (int q = 0; q < 9; ++q) { ct[q] = R[q]; ct[9 + q] = JL[q]; }
     ct[18] = x[3]; ct[19] = x[4]; ct[20] = x[5];
     for (int a = 0; a < 6; ++a) ct[21 + a] = UNIT_SCALE ? 1.0 : p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
-    camcf[c] = p.cam_cf[wd.cam_off + c];
+    camcf[c] = (signed char)p.cam_cf[wd.cam_off + c];
   }
 }
 
 __host__ __device__ inline int lds_doubles_linearise(int C, int n) {
-  // camtab + S tri + b + g + hdiag ; camcf ints appended (C ints -> (C+1)/2 doubles)
-  return C * kCamTab + (n * (n + 1)) / 2 + 3 * n + (C + 1) / 2 + 2;
+  // camtab + S tri + b + g + hdiag ; free-index bytes appended
+  return C * kCamTab + (n * (n + 1)) / 2 + 3 * n + (C + 7) / 8;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
   double* bvec = S + ntri;
   double* gvec = bvec + n;
   double* hvec = gvec + n;
-  int* camcf = (int*)(hvec + n);
+  signed char* camcf = (signed char*)(hvec + n);
   load_cam_table<true, INIT>(p, wd, cur, lane, camtab, camcf);
   for (int q = lane; q < ntri + 3 * n; q += 64) S[q] = 0.0;
   __syncthreads();
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256) void k_line_trig(BatchPtrs p, int which) {
 
 // ------------------------------------------------------------------------------------------
 // Kernel 5: cost of the reduced program at the candidate point (residuals only).
-__host__ __device__ inline int lds_doubles_cost(int C) { return C * kCamTab + (C + 1) / 2 + 2; }
+__host__ __device__ inline int lds_doubles_cost(int C) { return C * kCamTab + (C + 7) / 8; }
 
 __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) 
   if (st->status != kRunning) return;
   const int cand = 1 - st->cur;
   double* camtab = smem;
-  int* camcf = (int*)(camtab + wd.C * kCamTab);
+  signed char* camcf = (signed char*)(camtab + wd.C * kCamTab);
   load_cam_table<false, true>(p, wd, cand, lane, camtab, camcf);
   __syncthreads();
   double acc = 0.0;
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(64) void k_debug_linearise(BatchPtrs p, Policy pol,
   const LMState* st = p.state + w;
   const int cur = st->cur;
   double* camtab = smem;
-  int* camcf = (int*)(camtab + wd.C * kCamTab);
+  signed char* camcf = (signed char*)(camtab + wd.C * kCamTab);
   load_cam_table<true, true>(p, wd, cur, lane, camtab, camcf);
   __syncthreads();
   double acc = 0.0;
