@@ -79,3 +79,54 @@ def test_drop_in_lba_and_po_on_gpu(tmp_path, hip, oracle):
     xp = np.fromfile(tmp_path / "po_out.bin")[:-5]
     xq, sq, _ = oracle.po_solve(g)
     assert np.abs(xp - xq).max() < 1e-6
+
+
+def test_gc_boundary_encodings_match_numpy_restatement():
+    """gc_lite (C++ host library) against the numpy restatements in slslam_amd/synth.py and the
+    oracle's copy: pose <-> (w,t), SE(3) algebra, line transforms, orthonormal encode/decode."""
+    import ctypes as C
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    lib = C.CDLL(os.path.join(LIBDIR, "libslslam_host.so"))
+
+    class Pose(C.Structure):
+        _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3)]
+    dp = C.POINTER(C.c_double)
+
+    def p(a):
+        return a.ctypes.data_as(dp)
+    rng = np.random.default_rng(5)
+    for scale in (0.0, 1e-9, 0.3, 2.5, 3.1):
+        wt = np.concatenate([rng.normal(size=3), rng.normal(size=3)])
+        wt[:3] *= scale / max(np.linalg.norm(wt[:3]), 1e-300) if scale > 0 else 0.0
+        T = Pose()
+        lib.slslam_gc_wt_to_Rt(p(wt), C.byref(T))
+        R = np.array(T.R).reshape(3, 3)
+        assert np.abs(R - synth.rodrigues(wt[:3])).max() < 1e-14
+        back = np.zeros(6)
+        lib.slslam_gc_Rt_to_wt(C.byref(T), p(back))
+        assert np.abs(back - wt).max() < 1e-9
+        Ti, I2 = Pose(), Pose()
+        lib.slslam_gc_T_inv(C.byref(T), C.byref(Ti))
+        lib.slslam_gc_T_20(C.byref(T), C.byref(Ti), C.byref(I2))
+        assert np.abs(np.array(I2.R).reshape(3, 3) - np.eye(3)).max() < 1e-14 and np.abs(np.array(I2.t)).max() < 1e-14
+        T2 = Pose()
+        wt2 = rng.normal(size=6)
+        lib.slslam_gc_wt_to_Rt(p(wt2), C.byref(T2))
+        T21 = Pose()
+        lib.slslam_gc_T_21(C.byref(T2), C.byref(T), C.byref(T21))       # T21 = T2 * T^-1
+        chk = Pose()
+        lib.slslam_gc_T_20(C.byref(T21), C.byref(T), C.byref(chk))
+        assert np.abs(np.array(chk.R) - np.array(T2.R)).max() < 1e-13 and np.abs(np.array(chk.t) - np.array(T2.t)).max() < 1e-13
+        # lines
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        pt = rng.normal(size=3) * 3
+        av = np.concatenate([pt - (pt @ d) * d, d])
+        orth, av2 = np.zeros(4), np.zeros(6)
+        lib.slslam_gc_av_to_orth(p(av), p(orth))
+        lib.slslam_gc_orth_to_av(p(orth), p(av2))
+        assert np.abs(orth - synth.av_to_orth(av)).max() < 1e-14 and np.abs(av2 - av).max() < 1e-12
+        lc, lw = np.zeros(6), np.zeros(6)
+        lib.slslam_gc_line_to_pose(p(av), C.byref(T), p(lc))
+        assert np.abs(lc[:3] - (R @ av[:3] + wt[3:])).max() < 1e-14 and np.abs(lc[3:] - R @ av[3:]).max() < 1e-14
+        lib.slslam_gc_line_from_pose(p(lc), C.byref(T), p(lw))
+        assert np.abs(lw - av).max() < 1e-13
