@@ -66,6 +66,9 @@ typedef struct slslam_solver_options {
   int    jacobi_scaling;                /* 1     */
   int    use_graph;                     /* 1: replay the LM iteration as a captured hipGraph    */
   int    chunks_per_window;             /* 0 = auto; waves cooperating on one window            */
+  int    reuse_elimination;             /* 0: the back-substitution re-linearises (HBM traffic ==
+                                           algorithmic); 1: it streams Jacobian blocks the elimination
+                                           spilled to HBM (+192 B per coupled observation)         */
 } slslam_solver_options;
 
 /* Fills every field with the configuration the reference runs (robust loss on, 10 iterations). */

@@ -43,6 +43,7 @@ extern "C" void slslam_default_options(slslam_solver_options* o) {
   o->jacobi_scaling = 1;
   o->use_graph = 1;
   o->chunks_per_window = 0;
+  o->reuse_elimination = 0;
 }
 
 extern "C" int slslam_device_count(void) {
@@ -96,6 +97,7 @@ Policy make_policy(const slslam_solver_options& o) {
   p.parameter_tolerance = o.parameter_tolerance;
   p.max_num_iterations = o.max_num_iterations; p.max_invalid = o.max_num_consecutive_invalid_steps;
   p.jacobi_scaling = o.jacobi_scaling; p.pad = 0;
+  p.store_f = o.reuse_elimination ? 1 : 0; p.pad2 = 0;
   return p;
 }
 
@@ -129,7 +131,7 @@ struct slslam_lba_batch {
   BatchPtrs ptrs;
   int nchunk = 0, nline = 0, ncam = 0;
   long long nobs = 0;
-  size_t lds_lin = 0, lds_solve = 0, lds_bs = 0, lds_cost = 0;
+  size_t lds_lin = 0, lds_solve = 0, lds_bs = 0, lds_bs_stream = 0, lds_cost = 0;
   // graph
   hipGraphExec_t graph_exec = nullptr;
   hipStream_t capture_stream = nullptr;
@@ -307,8 +309,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if ((rc = b->d_bs_part.alloc(std::max<size_t>(1, (size_t)b->nchunk * kBsStride)))) return rc;
   if ((rc = b->d_cost_part.alloc(std::max<size_t>(1, (size_t)b->nchunk)))) return rc;
   if ((rc = b->d_ysys.alloc(std::max<size_t>(1, (size_t)sys)))) return rc;
-  if ((rc = b->d_fstore.alloc((size_t)24 * (size_t)std::max<long long>(1, nobs)))) return rc;
-  if ((rc = b->d_line_elim.alloc(std::max<size_t>(1, (size_t)nline * kLineElim)))) return rc;
+  if ((rc = b->d_fstore.alloc(b->opt.reuse_elimination ? (size_t)24 * (size_t)std::max<long long>(1, nobs) : 2))) return rc;
+  if ((rc = b->d_line_elim.alloc(b->opt.reuse_elimination ? std::max<size_t>(1, (size_t)nline * kLineElim) : 1))) return rc;
   if ((rc = b->d_params_out.alloc(std::max<size_t>(1, (size_t)param_off)))) return rc;
   if ((rc = b->d_state.upload(b->h_state0))) return rc;
   if ((rc = b->d_trace.alloc(std::max<size_t>(1, (size_t)B * kMaxTrace)))) return rc;
@@ -334,6 +336,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   b->lds_lin = sizeof(double) * (size_t)lds_doubles_linearise(maxC, maxn);
   b->lds_solve = sizeof(double) * (size_t)lds_doubles_solve(maxn);
   b->lds_bs = sizeof(double) * (size_t)lds_doubles_backsub(maxC, maxn);
+  b->lds_bs_stream = sizeof(double) * (size_t)lds_doubles_backsub_stream(maxC, maxn);
   b->lds_cost = sizeof(double) * (size_t)lds_doubles_cost(maxC);
   const size_t lds_max = std::max(std::max(b->lds_lin, b->lds_solve), std::max(b->lds_bs, b->lds_cost));
   if (lds_max > 160 * 1024) return SLSLAM_ERR_UNSUPPORTED;
@@ -395,7 +398,10 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof) {
   for (int it = 0; it < pol.max_num_iterations; ++it) {
     if (b->nchunk > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_linearise_schur<false>, g_chunk, blk64, b->lds_lin, s, p, pol));
     LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve, g_win, blk64, b->lds_solve, s, p, pol));
-    if (b->nchunk > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub, g_chunk, blk64, b->lds_bs, s, p, pol));
+    if (b->nchunk > 0) {
+      if (pol.store_f) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub_stream, g_chunk, blk64, b->lds_bs_stream, s, p, pol));
+      else LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub, g_chunk, blk64, b->lds_bs, s, p, pol));
+    }
     if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 1));
     if (b->nchunk > 0) LAUNCH(FAM_COST, hipLaunchKernelGGL(k_candidate_cost, g_chunk, blk64, b->lds_cost, s, p, pol));
     LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol, 1));

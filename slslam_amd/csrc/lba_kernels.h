@@ -370,13 +370,13 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     else { for (int q = 0; q < 24; ++q) F[q] = 0.0; }
     // keep what the back-substitution needs (24 doubles per coupled observation, 22 per line) so
     // that it does not have to linearise again
-    if (elim && !(pol.pad & 4)) {
+    if (pol.store_f && elim && !(pol.pad & 4)) {
       const long long o = (long long)o0 + j;
 #pragma unroll
       for (int q = 0; q < 12; ++q)
         reinterpret_cast<double2*>(p.fstore)[(long long)q * p.ob_stride + o] = make_double2(F[2 * q], F[2 * q + 1]);
     }
-    if (line_active && j == 0) {
+    if (pol.store_f && line_active && j == 0) {
       double* le = p.line_elim + (long long)ls * kLineElim;
 #pragma unroll
       for (int q = 0; q < 10; ++q) le[q] = K[q];
@@ -613,12 +613,105 @@ __global__ __launch_bounds__(64) void k_reduced_solve(BatchPtrs p, Policy pol) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel 3: back-substitution  y_l = A^-1 (g_l - sum_i H_cl,i^T y_c) = K^T (u - sum_i F_i^T y_c,i),
-// candidate line parameters, line part of the step statistics.  Streams the F blocks and the
-// per-line factors the elimination kernel left in HBM: no second linearisation.
-__host__ __device__ inline int lds_doubles_backsub(int C, int n) { return n + (C + 1) / 2 + 2; }
+// Kernel 3, variant A (default): back-substitution  y_l = A^-1 (g_l - sum_i H_cl,i^T y_c) = K^T K (g_l - w),
+// candidate line parameters, line part of the step statistics.  Re-linearises the chunk (the second
+// of the three algorithmically necessary observation sweeps) instead of spilling
+// Jacobian blocks to HBM.
+__host__ __device__ inline int lds_doubles_backsub(int C, int n) { return C * kCamTab + n + (C + 7) / 8; }
 
 __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const Chunk ck = p.chunks[blockIdx.x];
+  const WinDesc wd = p.wins[ck.win];
+  const LMState* st = p.state + ck.win;
+  if (st->status != kRunning) return;
+  const int cur = st->cur;
+  const double radius = st->radius;
+  const int n = wd.n;
+  double* camtab = smem;
+  double* yc = camtab + wd.C * kCamTab;
+  signed char* camcf = (signed char*)(yc + n);
+  load_cam_table<true, false>(p, wd, cur, lane, camtab, camcf);
+  for (int q = lane; q < n; q += 64) yc[q] = p.ysys[wd.sys_off + q];
+  __syncthreads();
+
+  double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0;
+  TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
+  for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
+    const TileCtx tc = nxt;
+    nxt = fetch_tile(p, t + 1, ck.tile_end, lane);
+    const int width = 1 << tc.glog2;
+    const int j = tc.j, ls = tc.ls, k = tc.k;
+    const bool line_ok = tc.line_ok;
+    LaneLin L;
+    lane_linearise<true>(p, pol, camtab, camcf, ls, j, k, tc.o0, line_ok, tc.lflags, cur, wd.obs_off, L);
+    double H[10], g[4];
+    line_block(L, width, H, g);
+    const bool line_active = L.line_free && k > 0;
+    // w = sum_i (Jc_i^T Jl_i)^T y_c[cam_i] = sum_i Jl_i^T (Jc_i y_c)
+    double wv[4] = { 0, 0, 0, 0 };
+    if (L.valid && L.cf >= 0 && L.line_free) {
+      double jy[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) s += L.Jc[6 * r + a] * yc[6 * L.cf + a];
+        jy[r] = s;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wv[a] = L.Jl[a] * jy[0] + L.Jl[4 + a] * jy[1] + L.Jl[8 + a] * jy[2] + L.Jl[12 + a] * jy[3];
+    }
+    group_sum_n<4>(wv, width);
+    if (line_ok && j == 0) {
+      const double* xl = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
+      double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
+      double xn[4] = { xl[0], xl[1], xl[2], xl[3] };
+      if (line_active) {
+        double D2[4], K[10];
+        lm_diag4(H, pol, radius, D2);
+        chol4_inverse(H, D2, K);
+        // z = K (g - w);  y = K^T z
+        const double e0 = g[0] - wv[0], e1 = g[1] - wv[1], e2 = g[2] - wv[2], e3 = g[3] - wv[3];
+        const double z0 = K[0] * e0;
+        const double z1 = K[1] * e0 + K[2] * e1;
+        const double z2 = K[3] * e0 + K[4] * e1 + K[5] * e2;
+        const double z3 = K[6] * e0 + K[7] * e1 + K[8] * e2 + K[9] * e3;
+        double y[4];
+        y[0] = K[0] * z0 + K[1] * z1 + K[3] * z2 + K[6] * z3;
+        y[1] = K[2] * z1 + K[4] * z2 + K[7] * z3;
+        y[2] = K[5] * z2 + K[8] * z3;
+        y[3] = K[9] * z3;
+        const double* lsc = p.line_scale + (long long)ls * 4;
+        for (int a = 0; a < 4; ++a) {
+          acc_model += 0.5 * y[a] * (g[a] + D2[a] * y[a]);
+          const double v = xn[a] - y[a] * lsc[a];
+          const double dd = xn[a] - v;
+          acc_dn2 += dd * dd;
+          acc_xn2 += v * v;
+          xn[a] = v;
+        }
+      }
+      for (int a = 0; a < 4; ++a) xc[a] = xn[a];
+    }
+  }
+  const double m = wave_sum(acc_model), d = wave_sum(acc_dn2), x = wave_sum(acc_xn2);
+  if (lane == 0) {
+    double* bp = p.bs_part + (long long)blockIdx.x * kBsStride;
+    bp[kBsModel] = m; bp[kBsDn2] = d; bp[kBsXn2] = x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 3, variant B (Policy.store_f = 1): back-substitution from the F blocks and per-line factors
+// the elimination kernel spilled to HBM,  y_l = K^T (u - sum_i F_i^T y_c,i).  No second
+// linearisation, but +192 B per coupled observation written and read back: HBM traffic of the
+// dominant kernel becomes ~4x its algorithmic bytes.  Measured (profiles/): a wash in wall time
+// against variant A, so A (recompute, traffic == algorithmic) is the default.
+__host__ __device__ inline int lds_doubles_backsub_stream(int C, int n) { return n + (C + 1) / 2 + 2; }
+
+__global__ __launch_bounds__(64) void k_backsub_stream(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const Chunk ck = p.chunks[blockIdx.x];

@@ -88,6 +88,7 @@ struct Policy {             // numeric policy, by value into every kernel that n
   double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
   double function_tolerance, gradient_tolerance, parameter_tolerance;
   int max_num_iterations, max_invalid, jacobi_scaling, pad;
+  int store_f, pad2;           // 1: spill F blocks for the streaming back-substitution (variant B)
 };
 
 // Everything the kernels need, passed by value.

@@ -176,6 +176,19 @@ def test_batch_equals_single_and_is_reproducible(hip, oracle):
     b.close()
 
 
+def test_spilled_elimination_variant(hip, oracle):
+    """reuse_elimination = 1: the back-substitution streams the F blocks the elimination kernel
+    spilled instead of re-linearising; same algebra, so the same solve to round-off."""
+    w = synth.make_window(31, num_lines=250)
+    xa, sa, ta = hip.lba_solve(w)
+    xb, sb, tb = hip.lba_solve(w, reuse_elimination=1)
+    _assert_trace_parity(ta, tb, n=4)
+    assert sa["num_successful_steps"] == sb["num_successful_steps"]
+    assert np.abs(xa - xb).max() < 1e-7
+    xo, so, _ = oracle.lba_solve(w, linear_solver=1)
+    assert np.abs(xb - xo).max() < 1e-5
+
+
 def test_graph_replay_equals_eager_launches(hip):
     w = [synth.make_window(40 + i, num_lines=100) for i in range(4)]
     out = []

@@ -11,12 +11,13 @@ nb, lines = int(sys.argv[1]), int(sys.argv[2])
 kv = dict(a.split("=") for a in sys.argv[3:])
 chunks = [int(x) for x in kv.get("chunks", "0").split(",")]
 steps = int(kv.get("steps", 3))
+reuse = int(kv.get("reuse", 0))
 ws = [synth.make_window(100 + i, num_lines=lines) for i in range(nb)]
 for c in chunks:
     b = capi.LBABatch()
     for w in ws:
         b.add(w)
-    b.finalize(use_graph=0, chunks_per_window=c)
+    b.finalize(use_graph=0, chunks_per_window=c, reuse_elimination=reuse)
     b.reset(); b.solve(); b.download()
     b.set_profiling(True)
     b.iterations(clear=True)
