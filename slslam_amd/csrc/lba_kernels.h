@@ -39,8 +39,8 @@ __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);   // every lane has a valid source: no `old` operand needed
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // N values at once, step-major: one wave-uniform branch per reduction step for the whole batch
