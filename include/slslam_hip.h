@@ -69,6 +69,8 @@ typedef struct slslam_solver_options {
   int    reuse_elimination;             /* 0: the back-substitution re-linearises (HBM traffic ==
                                            algorithmic); 1: it streams Jacobian blocks the elimination
                                            spilled to HBM (+192 B per coupled observation)         */
+  int    po_factor_fp32;                /* pose graph only: 1 = factor the normal matrix in fp32 (MFMA f32);
+                                           residuals, gradient, costs and LM bookkeeping stay fp64    */
 } slslam_solver_options;
 
 /* Fills every field with the configuration the reference runs (robust loss on, 10 iterations). */

@@ -44,6 +44,7 @@ extern "C" void slslam_default_options(slslam_solver_options* o) {
   o->use_graph = 1;
   o->chunks_per_window = 0;
   o->reuse_elimination = 0;
+  o->po_factor_fp32 = 0;
 }
 
 extern "C" int slslam_device_count(void) {

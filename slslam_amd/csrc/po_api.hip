@@ -67,7 +67,9 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   PoPtrs p;
   std::memset(&p, 0, sizeof(p));
   int *d_p1 = nullptr, *d_p2 = nullptr, *d_slot = nullptr;
-  double* d_cons = nullptr;
+  double *d_cons = nullptr, *d_linv = nullptr;
+  float *d_Hf = nullptr, *d_linvf = nullptr;
+  const bool f32 = opt.po_factor_fp32 != 0;
   LMState hst;
   std::vector<IterRec> htrace(kMaxTrace);
   std::vector<double> x2((size_t)12 * N), ones((size_t)(n > 0 ? n : 1), 1.0);
@@ -85,7 +87,11 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   PO_TRY(hipMalloc((void**)&p.g, sizeof(double) * ones.size()));
   PO_TRY(hipMalloc((void**)&p.d2, sizeof(double) * ones.size()));
   PO_TRY(hipMalloc((void**)&p.y, sizeof(double) * ones.size()));
-  PO_TRY(hipMalloc((void**)&p.linv, sizeof(double) * kNB * kNB));
+  PO_TRY(hipMalloc((void**)&d_linv, sizeof(double) * kNB * kNB));
+  if (f32) {
+    PO_TRY(hipMalloc((void**)&d_Hf, sizeof(float) * (size_t)(n > 0 ? n : 1) * ld));
+    PO_TRY(hipMalloc((void**)&d_linvf, sizeof(float) * kNB * kNB));
+  }
   PO_TRY(hipMalloc((void**)&p.scal, sizeof(double) * 8));
   PO_TRY(hipMalloc((void**)&p.flags, sizeof(int) * 2));
   PO_TRY(hipMalloc((void**)&p.st, sizeof(LMState)));
@@ -119,17 +125,27 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     PO_TRY(hipMemsetAsync(p.scal, 0, sizeof(double), 0));            // kPoCost
     hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 0);
     hipLaunchKernelGGL(k_po_prepare, dim3(1), dim3(256), 0, 0, p, pol, 0);
+    if (f32) hipLaunchKernelGGL(k_po_to_f32, dim3(256), dim3(256), 0, 0, p, d_Hf);
     for (int bk = 0; bk < nblk; ++bk) {
       const int k0 = bk * kNB;
-      hipLaunchKernelGGL(k_po_potrf_diag, dim3(1), dim3(256), 0, 0, p, k0);
       const int rem = n - (k0 + kNB);
-      if (rem > 0) {
-        const int tb = (rem + kNB - 1) / kNB;
-        hipLaunchKernelGGL(k_po_panel_update, dim3((unsigned)tb), dim3(256), 0, 0, p, k0, 0);
-        hipLaunchKernelGGL(k_po_panel_update, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, p, k0, 1);
+      const int tb = rem > 0 ? (rem + kNB - 1) / kNB : 0;
+      if (f32) {
+        hipLaunchKernelGGL(k_po_potrf_diag<float>, dim3(1), dim3(256), 0, 0, p, d_Hf, d_linvf, k0);
+        if (tb > 0) {
+          hipLaunchKernelGGL(k_po_panel_update<float>, dim3((unsigned)tb), dim3(256), 0, 0, p, d_Hf, (const float*)d_linvf, k0, 0);
+          hipLaunchKernelGGL(k_po_panel_update<float>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, p, d_Hf, (const float*)d_linvf, k0, 1);
+        }
+      } else {
+        hipLaunchKernelGGL(k_po_potrf_diag<double>, dim3(1), dim3(256), 0, 0, p, p.H, d_linv, k0);
+        if (tb > 0) {
+          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)tb), dim3(256), 0, 0, p, p.H, (const double*)d_linv, k0, 0);
+          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, p, p.H, (const double*)d_linv, k0, 1);
+        }
       }
     }
-    hipLaunchKernelGGL(k_po_trisolve, dim3(1), dim3(256), 0, 0, p);
+    if (f32) hipLaunchKernelGGL(k_po_trisolve<float>, dim3(1), dim3(256), 0, 0, p, (const float*)d_Hf);
+    else hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(256), 0, 0, p, (const double*)p.H);
     hipLaunchKernelGGL(k_po_candidate, dim3(1), dim3(256), 0, 0, p);
     hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 1);
     hipLaunchKernelGGL(k_po_update, dim3(1), dim3(64), 0, 0, p, pol);
@@ -165,7 +181,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
 done:
   (void)hipFree(d_p1); (void)hipFree(d_p2); (void)hipFree(d_slot); (void)hipFree(d_cons);
   (void)hipFree(p.x); (void)hipFree(p.scale); (void)hipFree(p.H); (void)hipFree(p.g); (void)hipFree(p.d2);
-  (void)hipFree(p.y); (void)hipFree(p.linv); (void)hipFree(p.scal); (void)hipFree(p.flags);
+  (void)hipFree(p.y); (void)hipFree(d_linv); (void)hipFree(d_Hf); (void)hipFree(d_linvf); (void)hipFree(p.scal); (void)hipFree(p.flags);
   (void)hipFree(p.st); (void)hipFree(p.trace);
   return rc;
 }

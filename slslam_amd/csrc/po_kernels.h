@@ -138,7 +138,6 @@ struct PoPtrs {
   double* g;                         // [n] scaled gradient J'^T r
   double* d2;                        // [n] LM damping
   double* y;                         // [n] rhs -> solution
-  double* linv;                      // [64 x 64] inverse of the current diagonal block
   double* scal;                      // [8] 0 cost, 1 candidate cost, 2 model, 3 dn2, 4 xn2, 5 fixed cost
   int* flags;                        // [2] 0: factorisation failure
   LMState* st;
@@ -269,81 +268,107 @@ __global__ __launch_bounds__(256) void k_po_prepare(PoPtrs p, Policy pol, int fi
 }
 
 // ---- blocked Cholesky, block size 64 --------------------------------------------------------
-enum { kNB = 64, kLdT = 66 };   // LDS tile leading dimension: 132 dwords == 4 (mod 64), conflict-free b64 reads
+// Templated on the factorisation type: double (default; v_mfma_f64_16x16x4_f64) or float
+// (v_mfma_f32_16x16x4_f32) for the fp32-vs-fp64 tolerance study of BASELINE config 5.  In the float
+// variant only the factor is single precision: residuals, Jacobians, gradient, costs and the LM
+// bookkeeping stay fp64, so a less accurate step is caught by the gain ratio like any other.
+enum { kNB = 64, kLdT = 66 };   // LDS tile leading dimension (f64: 132 dwords == 4 mod 64, conflict-free b64 reads)
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+  typedef v4f64 acc_t;
+  static __device__ __forceinline__ acc_t zero() { return (acc_t){ 0.0, 0.0, 0.0, 0.0 }; }
+  static __device__ __forceinline__ acc_t mac(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int i) { return (lane >> 4) + 4 * i; }     // f64 C/D map
+};
+template <> struct Mfma<float> {
+  typedef v4f32 acc_t;
+  static __device__ __forceinline__ acc_t zero() { return (acc_t){ 0.f, 0.f, 0.f, 0.f }; }
+  static __device__ __forceinline__ acc_t mac(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int i) { return (lane >> 4) * 4 + i; }     // standard C/D map
+};
+
+// fp64 normal matrix (lower triangle) -> float copy for the single-precision factorisation
+__global__ __launch_bounds__(256) void k_po_to_f32(PoPtrs p, float* Hf) {
+  if (p.st->status != kRunning) return;
+  const long long total = (long long)p.n * p.ld;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x)
+    Hf[q] = (float)p.H[q];
+}
 
 // Factor the diagonal block A[k0:k0+nb, k0:k0+nb] in LDS, write L11 back and its inverse to linv.
-__global__ __launch_bounds__(256) void k_po_potrf_diag(PoPtrs p, int k0) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_po_potrf_diag(PoPtrs p, T* A, T* linv, int k0) {
   if (p.st->status != kRunning) return;
-  __shared__ double T[kNB * kLdT];
-  __shared__ double Li[kNB * kLdT];
+  __shared__ T Tt[kNB * kLdT];
+  __shared__ T Li[kNB * kLdT];
   const int tid = threadIdx.x;
-  const int nb = min(kNB, p.n - k0);
+  const int nb = min((int)kNB, p.n - k0);
   for (int q = tid; q < kNB * kNB; q += 256) {
     const int r = q / kNB, c = q - r * kNB;
-    double v = (r == c) ? 1.0 : 0.0;
-    if (r < nb && c <= r) v = p.H[(long long)(k0 + r) * p.ld + k0 + c];
-    T[r * kLdT + c] = (c <= r) ? v : 0.0;
+    T v = (r == c) ? T(1) : T(0);
+    if (r < nb && c <= r) v = A[(long long)(k0 + r) * p.ld + k0 + c];
+    Tt[r * kLdT + c] = (c <= r) ? v : T(0);
   }
   __syncthreads();
   int fail = 0;
   for (int j = 0; j < kNB; ++j) {
-    // column j: rows r >= j handled by threads r (r < 64)
-    double s = 0.0;
+    T s = T(0);
     const int r = tid;
     if (r < kNB && r >= j) {
-      s = T[r * kLdT + j];
-      for (int k = 0; k < j; ++k) s -= T[r * kLdT + k] * T[j * kLdT + k];
+      s = Tt[r * kLdT + j];
+      for (int k = 0; k < j; ++k) s -= Tt[r * kLdT + k] * Tt[j * kLdT + k];
     }
     __syncthreads();
-    if (r == j) { if (!(s > 0.0) || !isfinite(s)) { s = 1.0; fail = 1; } T[j * kLdT + j] = sqrt(s); }
+    if (r == j) { if (!(s > T(0)) || !isfinite(s)) { s = T(1); fail = 1; } Tt[j * kLdT + j] = sqrt(s); }
     __syncthreads();
-    const double dj = T[j * kLdT + j];
-    if (r < kNB && r > j) T[r * kLdT + j] = s / dj;
+    const T dj = Tt[j * kLdT + j];
+    if (r < kNB && r > j) Tt[r * kLdT + j] = s / dj;
     __syncthreads();
   }
   if (__syncthreads_or(fail)) { if (tid == 0) p.flags[0] = 1; }
-  // inverse of the lower-triangular block: thread c solves L x = e_c
-  if (tid < kNB) {
+  if (tid < kNB) {     // inverse of the lower-triangular block: thread c solves L x = e_c
     const int c = tid;
     for (int r = 0; r < kNB; ++r) {
-      double s = (r == c) ? 1.0 : 0.0;
-      if (r < c) { Li[r * kLdT + c] = 0.0; continue; }
-      for (int k = c; k < r; ++k) s -= T[r * kLdT + k] * Li[k * kLdT + c];
-      Li[r * kLdT + c] = s / T[r * kLdT + r];
+      T s = (r == c) ? T(1) : T(0);
+      if (r < c) { Li[r * kLdT + c] = T(0); continue; }
+      for (int k = c; k < r; ++k) s -= Tt[r * kLdT + k] * Li[k * kLdT + c];
+      Li[r * kLdT + c] = s / Tt[r * kLdT + r];
     }
   }
   __syncthreads();
   for (int q = tid; q < kNB * kNB; q += 256) {
     const int r = q / kNB, c = q - r * kNB;
-    p.linv[q] = Li[r * kLdT + c];
-    if (r < nb && c <= r) p.H[(long long)(k0 + r) * p.ld + k0 + c] = T[r * kLdT + c];
+    linv[q] = Li[r * kLdT + c];
+    if (r < nb && c <= r) A[(long long)(k0 + r) * p.ld + k0 + c] = Tt[r * kLdT + c];
   }
 }
 
-// C(64x64) = B(64xK=64) * M(64xK=64)^T on v_mfma_f64_16x16x4_f64; 4 waves, wave w owns tile row w.
-// acc[tc] holds the 16x16 tile (tile row = wave, tile column tc): element (row = (lane>>4) + 4*i,
-// col = lane & 15) in acc[tc][i].
-__device__ __forceinline__ void tile_mul_bt(const double* Bs, const double* Ms, int wave, int lane, v4f64 acc[4]) {
-  for (int tc = 0; tc < 4; ++tc) acc[tc] = (v4f64){ 0.0, 0.0, 0.0, 0.0 };
+// C(64x64) = B(64x64) * M(64x64)^T on the 16x16x4 MFMA of T; 4 waves, wave w owns tile row w.
+template <typename T>
+__device__ __forceinline__ void tile_mul_bt(const T* Bs, const T* Ms, int wave, int lane, typename Mfma<T>::acc_t acc[4]) {
+  for (int tc = 0; tc < 4; ++tc) acc[tc] = Mfma<T>::zero();
   const int rr = lane & 15, kk = lane >> 4;
   for (int k4 = 0; k4 < kNB / 4; ++k4) {
-    const double a = Bs[(wave * 16 + rr) * kLdT + k4 * 4 + kk];
+    const T a = Bs[(wave * 16 + rr) * kLdT + k4 * 4 + kk];
 #pragma unroll
     for (int tc = 0; tc < 4; ++tc) {
-      const double b = Ms[(tc * 16 + rr) * kLdT + k4 * 4 + kk];
-      acc[tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[tc], 0, 0, 0);
+      const T b = Ms[(tc * 16 + rr) * kLdT + k4 * 4 + kk];
+      acc[tc] = Mfma<T>::mac(a, b, acc[tc]);
     }
   }
 }
 
 // mode 0 (TRSM):  A[rows_i, k0:k0+64] <- A[rows_i, k0:k0+64] * inv(L11)^T        grid.x = row blocks
 // mode 1 (SYRK):  A[rows_i, rows_j]   -= L[rows_i, k0:] * L[rows_j, k0:]^T        grid.x = lower tile pairs
-__global__ __launch_bounds__(256) void k_po_panel_update(PoPtrs p, int k0, int mode) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_po_panel_update(PoPtrs p, T* A, const T* linv, int k0, int mode) {
   if (p.st->status != kRunning) return;
-  __shared__ double Bs[kNB * kLdT];
-  __shared__ double Ms[kNB * kLdT];
+  __shared__ T Bs[kNB * kLdT];
+  __shared__ T Ms[kNB * kLdT];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int t0 = k0 + kNB;                       // first trailing row
   int bi, bj = 0;
@@ -359,68 +384,68 @@ __global__ __launch_bounds__(256) void k_po_panel_update(PoPtrs p, int k0, int m
   for (int q = tid; q < kNB * kNB; q += 256) {
     const int r = q / kNB, c = q - r * kNB;
     const bool cin = k0 + c < p.n;
-    Bs[r * kLdT + c] = (ri + r < p.n && cin) ? p.H[(long long)(ri + r) * p.ld + k0 + c] : 0.0;
-    if (mode == 0) Ms[r * kLdT + c] = p.linv[q];
-    else Ms[r * kLdT + c] = (rj + r < p.n && cin) ? p.H[(long long)(rj + r) * p.ld + k0 + c] : 0.0;
+    Bs[r * kLdT + c] = (ri + r < p.n && cin) ? A[(long long)(ri + r) * p.ld + k0 + c] : T(0);
+    if (mode == 0) Ms[r * kLdT + c] = linv[q];
+    else Ms[r * kLdT + c] = (rj + r < p.n && cin) ? A[(long long)(rj + r) * p.ld + k0 + c] : T(0);
   }
   __syncthreads();
-  v4f64 acc[4];
-  tile_mul_bt(Bs, Ms, wave, lane, acc);
-  const int col = lane & 15, rbase = lane >> 4;
+  typename Mfma<T>::acc_t acc[4];
+  tile_mul_bt<T>(Bs, Ms, wave, lane, acc);
+  const int col = lane & 15;
   for (int tc = 0; tc < 4; ++tc)
     for (int i = 0; i < 4; ++i) {
-      const int r = ri + wave * 16 + rbase + 4 * i;
+      const int r = ri + wave * 16 + Mfma<T>::row(lane, i);
       if (r >= p.n) continue;
       if (mode == 0) {
         const int c = k0 + tc * 16 + col;
-        if (c < p.n) p.H[(long long)r * p.ld + c] = acc[tc][i];
+        if (c < p.n) A[(long long)r * p.ld + c] = acc[tc][i];
       } else {
         const int c = rj + tc * 16 + col;
-        if (c < p.n && c <= r) p.H[(long long)r * p.ld + c] -= acc[tc][i];
+        if (c < p.n && c <= r) A[(long long)r * p.ld + c] -= acc[tc][i];
       }
     }
 }
 
-// forward then backward substitution with the factor in H; one workgroup.
-__global__ __launch_bounds__(256) void k_po_trisolve(PoPtrs p) {
+// forward then backward substitution with the factor in A (rhs / solution stay fp64); one workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void k_po_trisolve(PoPtrs p, const T* A) {
   if (p.st->status != kRunning) return;
   __shared__ double yb[kNB];
   const int tid = threadIdx.x;
   const int n = p.n;
   for (int k0 = 0; k0 < n; k0 += kNB) {
-    const int nb = min(kNB, n - k0);
-    // diagonal block: serial in the pivot
-    for (int j = 0; j < nb; ++j) {
+    const int nb = min((int)kNB, n - k0);
+    for (int j = 0; j < nb; ++j) {     // diagonal block: serial in the pivot
       __syncthreads();
-      const double yj = p.y[k0 + j] / p.H[(long long)(k0 + j) * p.ld + k0 + j];
+      const double yj = p.y[k0 + j] / (double)A[(long long)(k0 + j) * p.ld + k0 + j];
       __syncthreads();
       if (tid == 0) { p.y[k0 + j] = yj; yb[j] = yj; }
       const int r = k0 + j + 1 + tid;
-      if (r < k0 + nb) p.y[r] -= p.H[(long long)r * p.ld + k0 + j] * yj;
+      if (r < k0 + nb) p.y[r] -= (double)A[(long long)r * p.ld + k0 + j] * yj;
     }
     __syncthreads();
     for (int r = k0 + nb + tid; r < n; r += 256) {
       double s = 0.0;
-      for (int j = 0; j < nb; ++j) s += p.H[(long long)r * p.ld + k0 + j] * yb[j];
+      for (int j = 0; j < nb; ++j) s += (double)A[(long long)r * p.ld + k0 + j] * yb[j];
       p.y[r] -= s;
     }
     __syncthreads();
   }
   const int nblk = (n + kNB - 1) / kNB;
   for (int bk = nblk - 1; bk >= 0; --bk) {
-    const int k0 = bk * kNB, nb = min(kNB, n - k0);
+    const int k0 = bk * kNB, nb = min((int)kNB, n - k0);
     for (int j = nb - 1; j >= 0; --j) {
       __syncthreads();
-      const double yj = p.y[k0 + j] / p.H[(long long)(k0 + j) * p.ld + k0 + j];
+      const double yj = p.y[k0 + j] / (double)A[(long long)(k0 + j) * p.ld + k0 + j];
       __syncthreads();
       if (tid == 0) { p.y[k0 + j] = yj; yb[j] = yj; }
       const int r = k0 + tid;
-      if (tid < j) p.y[r] -= p.H[(long long)(k0 + j) * p.ld + r] * yj;
+      if (tid < j) p.y[r] -= (double)A[(long long)(k0 + j) * p.ld + r] * yj;
     }
     __syncthreads();
     for (int r = tid; r < k0; r += 256) {
       double s = 0.0;
-      for (int j = 0; j < nb; ++j) s += p.H[(long long)(k0 + j) * p.ld + r] * yb[j];
+      for (int j = 0; j < nb; ++j) s += (double)A[(long long)(k0 + j) * p.ld + r] * yb[j];
       p.y[r] -= s;
     }
     __syncthreads();

@@ -91,3 +91,27 @@ def test_po_full_size_loop_closure(hip, oracle):
     _trace_parity(t0, t1, n=3)
     assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-6 * s0["final_cost"]
     assert np.abs(x0 - x1).max() < 1e-5
+
+
+def test_po_fp32_factorisation_tolerance(hip):
+    """BASELINE config 5 'fp32 vs fp64 tolerance check': the same 260-pose loop-closure graph solved
+    with the normal matrix factored in fp32 (v_mfma_f32_16x16x4_f32) and in fp64.  Only the factor is
+    single precision (residuals, gradient, cost and LM bookkeeping stay fp64), so the iterates differ
+    by the fp32 step error and the solves agree within the STATED tolerance:
+    final cost rel 1e-4, poses 1e-4 (rad / m)."""
+    g = synth.make_pose_graph(7, num_poses=260, num_loops=8)
+    x64, s64, t64 = hip.po_solve(g)
+    x32, s32, t32 = hip.po_solve(g, po_factor_fp32=1)
+    assert s32["termination_type"] in (0, 2, 3) and s32["num_successful_steps"] >= 1
+    assert abs(s32["initial_cost"] - s64["initial_cost"]) <= 1e-13 * s64["initial_cost"]
+    assert abs(s32["final_cost"] - s64["final_cost"]) <= 1e-4 * s64["final_cost"]
+    d = np.abs(x32 - x64).reshape(-1, 6)
+    print("fp32-vs-fp64 factorisation: max |dw| %.3e rad, max |dt| %.3e m, final cost %.9e vs %.9e, steps %d vs %d" % (
+        d[:, :3].max(), d[:, 3:].max(), s32["final_cost"], s64["final_cost"],
+        s32["num_successful_steps"], s64["num_successful_steps"]))
+    assert d.max() < 1e-4
+    # small graph: one ragged block
+    g2 = synth.make_pose_graph(1, num_poses=12, num_loops=1)
+    a, sa, _ = hip.po_solve(g2)
+    b, sb, _ = hip.po_solve(g2, po_factor_fp32=1)
+    assert np.abs(a - b).max() < 1e-5 and abs(sa["final_cost"] - sb["final_cost"]) <= 1e-5 * sa["final_cost"]
