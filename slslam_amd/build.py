@@ -11,6 +11,8 @@ SOURCES = ["lba_api.hip", "lba_pack.cpp", "po_api.hip"]
 HEADERS = ["lba_kernels.h", "lba_math.h", "lba_types.h", "lba_pack.h", "po_kernels.h",
            os.path.join("..", "..", "include", "slslam_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
+import os as _os
+FLAGS += _os.environ.get("SLSLAM_EXTRA_FLAGS", "").split()
 
 
 def _stale():

@@ -124,6 +124,7 @@ struct slslam_lba_batch {
   // device
   DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<uint8_t> d_items;
   DevBuf<unsigned long long> d_iter_counter;
+  DevBuf<unsigned int> d_active;
   DevBuf<double> d_cam_x, d_cam_x0, d_cam_scale; DevBuf<int> d_cam_cf, d_cam_win;
   DevBuf<double> d_line_x, d_line_x0, d_line_scale; DevBuf<int> d_line_ptr, d_line_flags, d_line_win, d_line_orig;
   DevBuf<double> d_ob; DevBuf<int> d_ob_cam, d_ob_orig;
@@ -149,7 +150,7 @@ struct slslam_lba_batch {
     d_line_x.release(); d_line_x0.release(); d_line_scale.release(); d_line_ptr.release(); d_line_flags.release();
     d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release();
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
-    d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release();
+    d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release(); d_active.release();
     d_fstore.release(); d_line_elim.release();
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     if (capture_stream) { (void)hipStreamDestroy(capture_stream); capture_stream = nullptr; }
@@ -195,7 +196,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (b->finalized) return SLSLAM_ERR_STATE;
   if (opt) b->opt = *opt;
-  if (b->opt.max_num_iterations < 0 || b->opt.max_num_iterations > kMaxTrace - 2) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (b->opt.max_num_iterations < 0 || b->opt.max_num_iterations > 100000) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (!(b->opt.initial_trust_region_radius > 0.0) || !(b->opt.baseline == b->opt.baseline)) return SLSLAM_ERR_INVALID_ARGUMENT;
   b->pol = make_policy(b->opt);
   if (const char* dbg = std::getenv("SLSLAM_DEBUG_SKIP")) b->pol.pad = std::atoi(dbg);   // timing experiments only (wrong results)
@@ -318,6 +319,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if ((rc = b->d_param_off.upload(b->h_param_off))) return rc;
   if ((rc = b->d_iter_counter.alloc(1))) return rc;
   HIP_TRY(hipMemset(b->d_iter_counter.p, 0, sizeof(unsigned long long)));
+  if ((rc = b->d_active.alloc(1))) return rc;
+  HIP_TRY(hipMemset(b->d_active.p, 0, sizeof(unsigned int)));
   HIP_TRY(hipMemset(b->d_trace.p, 0, b->d_trace.n * sizeof(IterRec)));
   HIP_TRY(hipMemset(b->d_cam_scale.p, 0, b->d_cam_scale.n * sizeof(double)));
   HIP_TRY(hipMemset(b->d_line_scale.p, 0, b->d_line_scale.n * sizeof(double)));
@@ -331,7 +334,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.slab = b->d_slab.p; p.bs_part = b->d_bs_part.p; p.cost_part = b->d_cost_part.p; p.ysys = b->d_ysys.p;
   p.fstore = b->d_fstore.p; p.line_elim = b->d_line_elim.p;
   p.state = b->d_state.p; p.trace = b->d_trace.p;
-  p.iter_counter = b->d_iter_counter.p; p.cam_x0 = b->d_cam_x0.p; p.line_u0 = b->d_line_x0.p;
+  p.iter_counter = b->d_iter_counter.p; p.active_counter = b->d_active.p; p.cam_x0 = b->d_cam_x0.p; p.line_u0 = b->d_line_x0.p;
   p.nwin = B; p.nchunk = b->nchunk; p.nline = b->nline; p.ncam = b->ncam;
 
   b->lds_lin = sizeof(double) * (size_t)lds_doubles_linearise(maxC, maxn);
@@ -377,7 +380,7 @@ struct Launcher {
   }
 };
 
-int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof) {
+int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing = false) {
   const BatchPtrs& p = b->ptrs;
   const Policy& pol = b->pol;
   const int B = p.nwin;
@@ -397,6 +400,15 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof) {
   if (b->nchunk > 0) LAUNCH(FAM_INIT, hipLaunchKernelGGL(k_linearise_schur<true>, g_chunk, blk64, b->lds_lin, s, p, pol));
   LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol, 0));
   for (int it = 0; it < pol.max_num_iterations; ++it) {
+    // long solves (the reference's max_num_iter = 1000 study): every 16 iterations ask the device
+    // whether any window is still iterating and stop enqueueing when none is
+    if (!capturing && it > 0 && (it % 16) == 0) {
+      unsigned int active = 0;
+      HIP_TRY(hipMemcpyAsync(&active, b->d_active.p, sizeof(active), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (active == 0) break;
+    }
+    if (!capturing && ((it + 1) % 16) == 0) HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
     if (b->nchunk > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_linearise_schur<false>, g_chunk, blk64, b->lds_lin, s, p, pol));
     LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve, g_win, blk64, b->lds_solve, s, p, pol));
     if (b->nchunk > 0) {
@@ -421,12 +433,12 @@ extern "C" int slslam_lba_batch_solve(slslam_lba_batch* b, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   b->downloaded = false;
   if (b->profiling) return enqueue_solve(b, s, true);   // events accumulate until set_profiling()
-  if (!b->opt.use_graph) return enqueue_solve(b, s, false);
+  if (!b->opt.use_graph || b->opt.max_num_iterations > 16) return enqueue_solve(b, s, false);
   if (!b->graph_exec) {
     // capture the whole solve (3 + 6 * max_iter launches) once; replay costs one host call
     HIP_TRY(hipStreamCreateWithFlags(&b->capture_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamBeginCapture(b->capture_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_solve(b, b->capture_stream, false);
+    const int rc = enqueue_solve(b, b->capture_stream, false, true);
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(b->capture_stream, &g);
     if (rc != SLSLAM_OK) { if (g) (void)hipGraphDestroy(g); return rc; }

@@ -970,6 +970,7 @@ __global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol, int p
   atomicAdd(p.iter_counter, 1ULL);   // one trust-region step (successful or not), as slam.cpp:949-950 counts
   if (st->radius < pol.min_radius) { st->status = 5; return; }
   if (st->iter >= pol.max_num_iterations) { st->status = 0; return; }
+  atomicAdd(p.active_counter, 1u);    // still running: lets the host stop enqueueing long solves early
 }
 
 // ------------------------------------------------------------------------------------------

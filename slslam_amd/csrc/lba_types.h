@@ -121,6 +121,7 @@ struct BatchPtrs {
   LMState* state;
   IterRec* trace;             // [nwin][kMaxTrace]
   unsigned long long* iter_counter;   // LM iterations executed by the batch since the counter was cleared
+  unsigned int* active_counter;       // windows still iterating after the last k_lm_update (host early-out)
   const double* cam_x0;       // [ncam][6] initial camera poses (reset)
   const double* line_u0;      // [nline][4] initial line parameters (reset)
   int nwin, nchunk, nline, ncam;

@@ -32,7 +32,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   if (N > 0 && !g->parameters) return SLSLAM_ERR_INVALID_ARGUMENT;
   slslam_solver_options opt;
   if (opt_in) opt = *opt_in; else slslam_default_options(&opt);
-  if (opt.max_num_iterations < 0 || opt.max_num_iterations > kMaxTrace - 2) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (opt.max_num_iterations < 0 || opt.max_num_iterations > 100000) return SLSLAM_ERR_INVALID_ARGUMENT;
   for (int e = 0; e < E; ++e) {
     const int a = g->pose_index_1[e], b = g->pose_index_2[e];
     if (a < 0 || a >= N || b < 0 || b >= N || a == b) return SLSLAM_ERR_INVALID_ARGUMENT;
@@ -120,6 +120,11 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   hipLaunchKernelGGL(k_po_prepare, dim3(1), dim3(256), 0, 0, p, pol, 1);
   // ---- LM iterations, enqueued without host synchronisation; finished solves early-out on device
   for (int it = 0; it < pol.max_num_iterations && n > 0; ++it) {
+    if (it > 0 && (it % 8) == 0) {      // long solves: stop enqueueing once the device reports termination
+      PO_TRY(hipMemcpyAsync(&hst, p.st, sizeof(hst), hipMemcpyDeviceToHost, 0));
+      PO_TRY(hipStreamSynchronize(0));
+      if (hst.status != kRunning) break;
+    }
     PO_TRY(hipMemsetAsync(p.H, 0, hbytes, 0));
     PO_TRY(hipMemsetAsync(p.g, 0, sizeof(double) * ones.size(), 0));
     PO_TRY(hipMemsetAsync(p.scal, 0, sizeof(double), 0));            // kPoCost

@@ -148,6 +148,18 @@ def test_golden_optimum(hip):
     assert abs(s["initial_cost"] - float(z["initial_cost"])) < 1e-13 * float(z["initial_cost"])
 
 
+def test_long_solve_stops_early_like_the_reference_study(hip, oracle):
+    """max_num_iter = 1000 (the reference's *_maxnumiter1000 runs): the solve terminates by a
+    tolerance long before the cap and the host stops enqueueing iterations."""
+    w = synth.make_window(17, num_lines=120)
+    x0, s0, t0 = oracle.lba_solve(w, linear_solver=1, max_num_iterations=1000)
+    x1, s1, t1 = hip.lba_solve(w, max_num_iterations=1000)
+    assert s0["termination_type"] == s1["termination_type"] != 0
+    assert abs(s0["num_successful_steps"] - s1["num_successful_steps"]) <= 1
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-6 * s0["final_cost"]
+    assert np.abs(x0 - x1).max() < 1e-4
+
+
 def test_batch_equals_single_and_is_reproducible(hip, oracle):
     """Windows are independent: a window solved inside a ragged batch gives the same result as
     alone; two runs of the same batch are bitwise identical (ordered reductions)."""
