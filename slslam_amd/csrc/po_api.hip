@@ -87,10 +87,10 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   PO_TRY(hipMalloc((void**)&p.g, sizeof(double) * ones.size()));
   PO_TRY(hipMalloc((void**)&p.d2, sizeof(double) * ones.size()));
   PO_TRY(hipMalloc((void**)&p.y, sizeof(double) * ones.size()));
-  PO_TRY(hipMalloc((void**)&d_linv, sizeof(double) * kNB * kNB));
+  PO_TRY(hipMalloc((void**)&d_linv, sizeof(double) * kNB * kNB * (size_t)(nblk > 0 ? nblk : 1)));
   if (f32) {
     PO_TRY(hipMalloc((void**)&d_Hf, sizeof(float) * (size_t)(n > 0 ? n : 1) * ld));
-    PO_TRY(hipMalloc((void**)&d_linvf, sizeof(float) * kNB * kNB));
+    PO_TRY(hipMalloc((void**)&d_linvf, sizeof(float) * kNB * kNB * (size_t)(nblk > 0 ? nblk : 1)));
   }
   PO_TRY(hipMalloc((void**)&p.scal, sizeof(double) * 8));
   PO_TRY(hipMalloc((void**)&p.flags, sizeof(int) * 2));
@@ -136,21 +136,21 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
       const int rem = n - (k0 + kNB);
       const int tb = rem > 0 ? (rem + kNB - 1) / kNB : 0;
       if (f32) {
-        hipLaunchKernelGGL(k_po_potrf_diag<float>, dim3(1), dim3(256), 0, 0, p, d_Hf, d_linvf, k0);
+        hipLaunchKernelGGL(k_po_potrf_diag<float>, dim3(1), dim3(256), 0, 0, p, d_Hf, d_linvf + (size_t)bk * kNB * kNB, k0);
         if (tb > 0) {
-          hipLaunchKernelGGL(k_po_panel_update<float>, dim3((unsigned)tb), dim3(256), 0, 0, p, d_Hf, (const float*)d_linvf, k0, 0);
-          hipLaunchKernelGGL(k_po_panel_update<float>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, p, d_Hf, (const float*)d_linvf, k0, 1);
+          hipLaunchKernelGGL(k_po_panel_update<float>, dim3((unsigned)tb), dim3(256), 0, 0, p, d_Hf, (const float*)(d_linvf + (size_t)bk * kNB * kNB), k0, 0);
+          hipLaunchKernelGGL(k_po_panel_update<float>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, p, d_Hf, (const float*)(d_linvf + (size_t)bk * kNB * kNB), k0, 1);
         }
       } else {
-        hipLaunchKernelGGL(k_po_potrf_diag<double>, dim3(1), dim3(256), 0, 0, p, p.H, d_linv, k0);
+        hipLaunchKernelGGL(k_po_potrf_diag<double>, dim3(1), dim3(256), 0, 0, p, p.H, d_linv + (size_t)bk * kNB * kNB, k0);
         if (tb > 0) {
-          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)tb), dim3(256), 0, 0, p, p.H, (const double*)d_linv, k0, 0);
-          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, p, p.H, (const double*)d_linv, k0, 1);
+          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)tb), dim3(256), 0, 0, p, p.H, (const double*)(d_linv + (size_t)bk * kNB * kNB), k0, 0);
+          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, p, p.H, (const double*)(d_linv + (size_t)bk * kNB * kNB), k0, 1);
         }
       }
     }
-    if (f32) hipLaunchKernelGGL(k_po_trisolve<float>, dim3(1), dim3(256), 0, 0, p, (const float*)d_Hf);
-    else hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(256), 0, 0, p, (const double*)p.H);
+    if (f32) hipLaunchKernelGGL(k_po_trisolve<float>, dim3(1), dim3(256), 0, 0, p, (const float*)d_Hf, (const float*)d_linvf);
+    else hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(256), 0, 0, p, (const double*)p.H, (const double*)d_linv);
     hipLaunchKernelGGL(k_po_candidate, dim3(1), dim3(256), 0, 0, p);
     hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 1);
     hipLaunchKernelGGL(k_po_update, dim3(1), dim3(64), 0, 0, p, pol);

@@ -330,14 +330,19 @@ __global__ __launch_bounds__(256) void k_po_potrf_diag(PoPtrs p, T* A, T* linv, 
     __syncthreads();
   }
   if (__syncthreads_or(fail)) { if (tid == 0) p.flags[0] = 1; }
-  if (tid < kNB) {     // inverse of the lower-triangular block: thread c solves L x = e_c
+  if (tid < kNB) {     // inverse of the lower-triangular block: thread c solves L x = e_c.
+    // The column lives in registers (fully unrolled, static indices); rows of L are LDS broadcasts.
     const int c = tid;
+    T x[kNB];
+#pragma unroll
     for (int r = 0; r < kNB; ++r) {
       T s = (r == c) ? T(1) : T(0);
-      if (r < c) { Li[r * kLdT + c] = T(0); continue; }
-      for (int k = c; k < r; ++k) s -= Tt[r * kLdT + k] * Li[k * kLdT + c];
-      Li[r * kLdT + c] = s / Tt[r * kLdT + r];
+#pragma unroll
+      for (int k = 0; k < r; ++k) s -= Tt[r * kLdT + k] * x[k];
+      x[r] = s / Tt[r * kLdT + r];
     }
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) Li[r * kLdT + c] = x[r];
   }
   __syncthreads();
   for (int q = tid; q < kNB * kNB; q += 256) {
@@ -406,46 +411,56 @@ __global__ __launch_bounds__(256) void k_po_panel_update(PoPtrs p, T* A, const T
     }
 }
 
-// forward then backward substitution with the factor in A (rhs / solution stay fp64); one workgroup.
+// forward then backward substitution with the factor in A and the inverted diagonal blocks in
+// linv_all (one 64x64 block per block column, kept by k_po_potrf_diag): every step is a parallel
+// matrix-vector product - no serial pivot loop.  rhs / solution stay fp64.  One workgroup.
 template <typename T>
-__global__ __launch_bounds__(256) void k_po_trisolve(PoPtrs p, const T* A) {
+__global__ __launch_bounds__(256) void k_po_trisolve(PoPtrs p, const T* A, const T* linv_all) {
   if (p.st->status != kRunning) return;
-  __shared__ double yb[kNB];
+  __shared__ double yb[kNB], yn[kNB];
+  __shared__ T Ls[kNB * (kNB + 1)];
   const int tid = threadIdx.x;
   const int n = p.n;
-  for (int k0 = 0; k0 < n; k0 += kNB) {
-    const int nb = min((int)kNB, n - k0);
-    for (int j = 0; j < nb; ++j) {     // diagonal block: serial in the pivot
-      __syncthreads();
-      const double yj = p.y[k0 + j] / (double)A[(long long)(k0 + j) * p.ld + k0 + j];
-      __syncthreads();
-      if (tid == 0) { p.y[k0 + j] = yj; yb[j] = yj; }
-      const int r = k0 + j + 1 + tid;
-      if (r < k0 + nb) p.y[r] -= (double)A[(long long)r * p.ld + k0 + j] * yj;
+  const int nblk = (n + kNB - 1) / kNB;
+  // forward: y_k <- inv(L_kk) y_k ;  y_r -= L[r, k] y_k for the rows below
+  for (int bk = 0; bk < nblk; ++bk) {
+    const int k0 = bk * kNB, nb = min((int)kNB, n - k0);
+    const T* Li = linv_all + (size_t)bk * kNB * kNB;
+    for (int q = tid; q < kNB * kNB; q += 256) Ls[(q / kNB) * (kNB + 1) + (q % kNB)] = Li[q];    // coalesced
+    if (tid < kNB) yb[tid] = tid < nb ? p.y[k0 + tid] : 0.0;
+    __syncthreads();
+    if (tid < nb) {
+      double s = 0.0;
+      for (int j = 0; j <= tid; ++j) s += (double)Ls[tid * (kNB + 1) + j] * yb[j];
+      yn[tid] = s;
+      p.y[k0 + tid] = s;
     }
     __syncthreads();
     for (int r = k0 + nb + tid; r < n; r += 256) {
       double s = 0.0;
-      for (int j = 0; j < nb; ++j) s += (double)A[(long long)r * p.ld + k0 + j] * yb[j];
+      for (int j = 0; j < nb; ++j) s += (double)A[(long long)r * p.ld + k0 + j] * yn[j];
       p.y[r] -= s;
     }
     __syncthreads();
   }
-  const int nblk = (n + kNB - 1) / kNB;
+  // backward: y_k <- inv(L_kk)^T y_k ;  y_r -= L[k, r]^T y_k for the rows above
   for (int bk = nblk - 1; bk >= 0; --bk) {
     const int k0 = bk * kNB, nb = min((int)kNB, n - k0);
-    for (int j = nb - 1; j >= 0; --j) {
-      __syncthreads();
-      const double yj = p.y[k0 + j] / (double)A[(long long)(k0 + j) * p.ld + k0 + j];
-      __syncthreads();
-      if (tid == 0) { p.y[k0 + j] = yj; yb[j] = yj; }
-      const int r = k0 + tid;
-      if (tid < j) p.y[r] -= (double)A[(long long)(k0 + j) * p.ld + r] * yj;
+    const T* Li = linv_all + (size_t)bk * kNB * kNB;
+    __syncthreads();
+    for (int q = tid; q < kNB * kNB; q += 256) Ls[(q / kNB) * (kNB + 1) + (q % kNB)] = Li[q];
+    if (tid < kNB) yb[tid] = tid < nb ? p.y[k0 + tid] : 0.0;
+    __syncthreads();
+    if (tid < nb) {
+      double s = 0.0;
+      for (int j = tid; j < nb; ++j) s += (double)Ls[j * (kNB + 1) + tid] * yb[j];
+      yn[tid] = s;
+      p.y[k0 + tid] = s;
     }
     __syncthreads();
     for (int r = tid; r < k0; r += 256) {
       double s = 0.0;
-      for (int j = 0; j < nb; ++j) s += (double)A[(long long)(k0 + j) * p.ld + r] * yb[j];
+      for (int j = 0; j < nb; ++j) s += (double)A[(long long)(k0 + j) * p.ld + r] * yn[j];
       p.y[r] -= s;
     }
     __syncthreads();
