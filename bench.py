@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph (no per-kernel events)")
     ap.add_argument("--chunks", type=int, default=0, help="waves cooperating on one window (0 = library default)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="the rank's windows are split into this many batches on separate HIP streams, so that the "
+                         "latency-bound kernels of one batch (reduced solve, LM update) overlap the sweeps of the other")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,13 +87,24 @@ def main():
     # ---- synthetic inputs of the named shape, distinct per rank, resident in HBM before timing
     B = args.windows
     windows = [synth.make_window(1_000_000 * rank + i, num_lines=args.lines) for i in range(B)]
-    batch = capi.LBABatch(device=local_rank)
-    for w in windows:
-        batch.add(w)
-    batch.finalize(use_graph=1 if args.graph else 0, chunks_per_window=args.chunks)
-    batch.set_profiling(not args.graph)
-    stream = torch.cuda.current_stream().cuda_stream
+    ns = max(1, min(args.streams, B))
+    bstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
+    batches, owner = [], []
+    for si in range(ns):
+        bt = capi.LBABatch(device=local_rank)
+        for wi in range(si, B, ns):
+            bt.add(windows[wi])
+            owner.append((wi, si, len(bt.sizes) - 1))
+        bt.finalize(use_graph=1 if args.graph else 0, chunks_per_window=args.chunks)
+        bt.set_profiling(not args.graph)
+        batches.append(bt)
+    where = {wi: (si, li) for wi, si, li in owner}
     counts = [(w["num_cameras"], w["num_free_cameras"], w["num_lines"], len(w["camera_index"])) for w in windows]
+
+    def run_step():
+        for bt, st in zip(batches, bstreams):
+            bt.reset(st.cuda_stream)
+            bt.solve(st.cuda_stream)
 
     def barrier():
         if world > 1:
@@ -98,18 +112,17 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        batch.reset(stream)
-        batch.solve(stream)
+        run_step()
     torch.cuda.synchronize()
-    batch.iterations(stream, clear=True)
-    batch.set_profiling(not args.graph)          # drop warm-up events
+    for bt, st in zip(batches, bstreams):
+        bt.iterations(st.cuda_stream, clear=True)
+        bt.set_profiling(not args.graph)          # drop warm-up events
 
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.reset(stream)
-        batch.solve(stream)
-    iters_local = batch.iterations(stream)        # synchronises the stream
+        run_step()
+    iters_local = sum(bt.iterations(st.cuda_stream) for bt, st in zip(batches, bstreams))   # synchronises the streams
     iters_total, _, _ = allreduce_summary(iters_local, 0.0, 0.0, device=dev)
     barrier()
     dt_local = time.perf_counter() - t0
@@ -119,8 +132,9 @@ def main():
     elapsed = float(t.item())
 
     # ---- results of the last step (outside the timed region)
-    batch.download(stream)
-    summaries = [batch.summary(i) for i in range(B)]
+    for bt, st in zip(batches, bstreams):
+        bt.download(st.cuda_stream)
+    summaries = [batches[where[i][0]].summary(where[i][1]) for i in range(B)]
     init_cost = sum(s["initial_cost"] for s in summaries)
     final_cost = sum(s["final_cost"] for s in summaries)
 
@@ -137,22 +151,24 @@ def main():
                                    "full LM solve (Huber, <=10 iterations, Schur + back-substitution)" % (
                                        args.lines, int(np.mean([c[3] for c in counts]))),
                        "windows_per_gpu": B, "lines": args.lines, "parallelism": "windows sharded over %d GPU(s)" % world,
-                       "launch": "hipGraph replay" if args.graph else "eager + hipEvents"},
+                       "launch": "hipGraph replay" if args.graph else "eager + hipEvents", "hip_streams": ns},
             "lm_iterations": iters_total,
             "sum_initial_cost_rank0": init_cost, "sum_final_cost_rank0": final_cost,
         }
-        kt = batch.kernel_times()
+        kts = [bt.kernel_times() for bt in batches]
+        kt = {k: (sum(x[k][0] for x in kts), sum(x[k][1] for x in kts)) for k in kts[0]}
         ms, n = kt["linearise_schur"]
         if n > 0:
-            bytes_launch = algorithmic_bytes_linearise(counts)
+            # one launch covers the windows of ONE stream's batch
+            bytes_launch = algorithmic_bytes_linearise(counts) / ns
             achieved = bytes_launch / (ms / n * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    if tj.get("windows") == B and tj.get("lines") == args.lines:
-                        traffic = tj.get("hbm_bytes_per_launch")
+                    if tj.get("lines") == args.lines:
+                        traffic = tj.get("hbm_bytes_per_launch") * (B / ns) / tj.get("windows")
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": "k_linearise_schur", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -166,14 +182,15 @@ def main():
             # trajectory error of the GPU solve against the oracle solve of the same windows
             err = []
             for i, xo in enumerate(outs):
-                xg = batch.parameters(i)
+                xg = batches[where[i][0]].parameters(where[i][1])
                 nf = 6 * windows[i]["num_free_cameras"]
                 err.append(np.linalg.norm(synth.camera_centers(xg[:nf]) - synth.camera_centers(xo[:nf]), axis=1))
             err = np.concatenate(err)
             out["traj_error_vs_oracle"] = {"rms_m": float(np.sqrt((err ** 2).mean())), "mean_m": float(err.mean()),
                                            "keyframes": int(err.size)}
         print(json.dumps(out))
-    batch.close()
+    for bt in batches:
+        bt.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
