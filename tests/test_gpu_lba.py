@@ -245,3 +245,22 @@ def test_full_size_window_properties(hip, oracle):
     assert np.sqrt((e1 ** 2).mean()) < np.sqrt((e0 ** 2).mean())
     eo = np.linalg.norm(synth.camera_centers(x1[:60]) - synth.camera_centers(x0[:60]), axis=1)
     assert np.sqrt((eo ** 2).mean()) < 1e-6                              # trajectory RMS vs the oracle solve
+
+
+def test_batched_motion_only(hip, oracle):
+    """motion_only_ba (reference src/slam.cpp:578-675) batched over frames.  Same
+    kernels, degenerate shape: one free camera, every line constant, 6x6 reduced system."""
+    ws = [synth.make_motion_only(500 + i, num_lines=60 + (i % 7) * 10) for i in range(96)]
+    b = hip.LBABatch()
+    for w in ws:
+        b.add(w)
+    b.finalize()
+    b.solve(); b.download()
+    for i in (0, 1, 17, 50, 95):
+        xo, so, to = oracle.lba_solve(ws[i])
+        x, s = b.parameters(i), b.summary(i)
+        assert s["num_free_parameters"] == 6 and s["fixed_cost"] > 0
+        assert s["num_successful_steps"] == so["num_successful_steps"]
+        assert abs(s["final_cost"] - so["final_cost"]) <= 1e-9 * so["final_cost"]
+        assert np.abs(x[:6] - xo[:6]).max() < 1e-9 and np.array_equal(x[6:], ws[i]["parameters"][6:])
+    b.close()
