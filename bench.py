@@ -78,11 +78,21 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
+    # one process per GPU; SLSLAM_BENCH_SHARE_GPU=1 lets several ranks share a device (dry runs of the
+    # multi-rank flow on a 1-GPU box, together with SLSLAM_BENCH_BACKEND=gloo)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and not os.environ.get("SLSLAM_BENCH_SHARE_GPU"):
+        raise SystemExit("LOCAL_RANK %d but only %d HIP device(s) visible" % (local_rank, ndev))
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("SLSLAM_BENCH_BACKEND", "nccl")      # "nccl" is RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- synthetic inputs of the named shape, distinct per rank, resident in HBM before timing
     B = args.windows
