@@ -193,6 +193,29 @@ typedef struct slslam_po_graph {
 int slslam_po_solve(const slslam_po_graph* graph, const slslam_solver_options* opt,
                     slslam_summary* summary, slslam_iteration* trace, int trace_cap, int* trace_len);
 
+/* ------------------------------------------------------------------ RANSAC hypothesis scoring
+ * (the per-frame cost centre next to the hot path.)
+ * Replaces: the scoring loop of SLAM::ransac_motion (reference src/slam.cpp:396-413) with
+ * SLAM::reprojection_error (src/slam.cpp:691-726) as its body: for every motion hypothesis and every
+ * common line, the mean absolute endpoint-to-line distance in both stereo images, an inlier when it is
+ * below error_thr = 5 / focal_length (src/parameter.h:56); hypotheses with |t| > 1 are skipped
+ * (src/slam.cpp:398-399) and score -1 here.  The reference's float/double mix (float `sql`, float
+ * error accumulator) is reproduced exactly, so scores and inlier sets are bit-identical.
+ * Hypothesis generation (vo_angle_axis_approx) and the adaptive trial loop stay on the host. */
+typedef struct slslam_ransac_frame {
+  int num_hypotheses;             /* motions to score                                           */
+  int num_lines;                  /* comm_size: lines visible in both frames                    */
+  const double* poses;            /* [12 H]: R row-major (9) then t (3) of each motion pose_t    */
+  const double* observations;     /* [8 K]: obs1 of each common line (current frame)            */
+  const double* lines;            /* [6 K]: (closest point, direction) of each line, world frame */
+} slslam_ransac_frame;
+
+/* scores[H]: inlier count per hypothesis (-1 when skipped);
+ * inlier_bits[H * ((K + 63) / 64)]: bit k of word k / 64 set when line k is an inlier (may be NULL).
+ * Synchronous; host pointers. */
+int slslam_ransac_score(const slslam_ransac_frame* frame, double baseline, double error_thr,
+                        int* scores, unsigned long long* inlier_bits);
+
 /* ------------------------------------------------------------------ misc */
 int         slslam_device_count(void);          /* 0 when no HIP device is usable */
 const char* slslam_version(void);

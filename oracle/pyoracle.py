@@ -17,7 +17,7 @@ def build(force=False):
     """Compile the C restatement with gcc (building the checker is not using it)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("lm_core.c", "lba_oracle.c", "po_oracle.c", "jet_impl.h", "lm_core.h", "slslam_oracle.h")):
+            for f in ("lm_core.c", "lba_oracle.c", "po_oracle.c", "ransac_oracle.c", "jet_impl.h", "lm_core.h", "slslam_oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -91,6 +91,7 @@ def lib():
         _lib.oracle_po_cost.restype = C.c_double
         _lib.oracle_po_solve.argtypes = [C.POINTER(POProblem), C.POINTER(LMOptions), dp,
                                          C.POINTER(Summary), C.POINTER(Iteration), C.c_int, ip]
+        _lib.oracle_ransac_score.argtypes = [C.c_int, dp, C.c_int, dp, dp, C.c_double, C.c_double, ip, C.POINTER(C.c_ubyte)]
         _lib.oracle_av_to_orth.argtypes = [dp, dp]
         _lib.oracle_orth_to_av.argtypes = [dp, dp]
     return _lib
@@ -231,3 +232,14 @@ def orth_to_av(orth):
     o = np.zeros(6)
     lib().oracle_orth_to_av(_dp(orth), _dp(o))
     return o
+
+
+def ransac_score(poses, observations, lines, baseline=0.12, error_thr=5.0 / 406.05):
+    poses = _f64(poses).reshape(-1, 12)
+    obs, ln = _f64(observations).reshape(-1, 8), _f64(lines).reshape(-1, 6)
+    h, k = len(poses), len(obs)
+    scores = np.zeros(max(h, 1), dtype=np.int32)
+    inl = np.zeros(max(h * k, 1), dtype=np.uint8)
+    lib().oracle_ransac_score(h, _dp(poses), k, _dp(obs), _dp(ln), float(baseline), float(error_thr), _ip(scores),
+                              inl.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return scores[:h], inl[:h * k].reshape(h, k).astype(bool)

@@ -59,6 +59,11 @@ class LBAWindow(C.Structure):
                 ("parameters", C.POINTER(C.c_double))]
 
 
+class RansacFrame(C.Structure):
+    _fields_ = [("num_hypotheses", C.c_int), ("num_lines", C.c_int), ("poses", C.POINTER(C.c_double)),
+                ("observations", C.POINTER(C.c_double)), ("lines", C.POINTER(C.c_double))]
+
+
 class POGraph(C.Structure):
     _fields_ = [("num_poses", C.c_int), ("num_edges", C.c_int),
                 ("pose_index_1", C.POINTER(C.c_int)), ("pose_index_2", C.POINTER(C.c_int)),
@@ -72,7 +77,7 @@ EXPORTS = [
     "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
-    "slslam_po_solve", "slslam_device_count", "slslam_version", "slslam_status_string",
+    "slslam_po_solve", "slslam_ransac_score", "slslam_device_count", "slslam_version", "slslam_status_string",
 ]
 
 _lib = None
@@ -110,6 +115,7 @@ def lib():
     L.slslam_lba_batch_linearise.argtypes = [vp, C.c_int, dp, dp, dp, dp]
     L.slslam_po_solve.argtypes = [C.POINTER(POGraph), C.POINTER(SolverOptions), C.POINTER(Summary),
                                   C.POINTER(Iteration), C.c_int, ip]
+    L.slslam_ransac_score.argtypes = [C.POINTER(RansacFrame), C.c_double, C.c_double, ip, C.POINTER(C.c_ulonglong)]
     L.slslam_device_count.restype = C.c_int
     L.slslam_version.restype = C.c_char_p
     L.slslam_status_string.argtypes = [C.c_int]
@@ -293,3 +299,27 @@ def po_solve(g, params=None, trace_cap=64, **opt):
     n = C.c_int(0)
     _check(lib().slslam_po_solve(C.byref(cg), C.byref(o), C.byref(s), tr, trace_cap, C.byref(n)), "slslam_po_solve")
     return x, _summary_dict(s), _trace_list(tr, min(n.value, trace_cap))
+
+
+def ransac_score(poses, observations, lines, baseline=0.12, error_thr=5.0 / 406.05):
+    """Scores motion hypotheses against the common lines (slslam_ransac_score).
+    poses [H,12] (R row-major, t), observations [K,8], lines [K,6] -> (scores [H], inlier mask [H,K] bool)."""
+    poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 12)
+    obs = np.ascontiguousarray(observations, dtype=np.float64).reshape(-1, 8)
+    ln = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 6)
+    if len(ln) != len(obs):
+        raise ValueError("observations and lines must have the same length")
+    h, k = len(poses), len(obs)
+    words = (k + 63) // 64
+    scores = np.zeros(max(h, 1), dtype=np.int32)
+    bits = np.zeros(max(h * words, 1), dtype=np.uint64)
+    fr = RansacFrame(h, k, _dp(poses), _dp(obs), _dp(ln))
+    _check(lib().slslam_ransac_score(C.byref(fr), float(baseline), float(error_thr), _ip(scores),
+                                     bits.ctypes.data_as(C.POINTER(C.c_ulonglong))), "slslam_ransac_score")
+    mask = np.zeros((h, k), dtype=bool)
+    if h and k:
+        b = bits[:h * words].reshape(h, words)
+        for w in range(words):
+            n = min(64, k - 64 * w)
+            mask[:, 64 * w:64 * w + n] = ((b[:, w:w + 1] >> np.arange(n, dtype=np.uint64)) & np.uint64(1)).astype(bool)
+    return scores[:h], mask

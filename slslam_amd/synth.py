@@ -362,3 +362,28 @@ def camera_centers(cams):
     reference matlab_script/calc_traj_err.m:28-40)."""
     cams = np.asarray(cams, dtype=np.float64).reshape(-1, 6)
     return np.array([-(rodrigues(c[:3]).T @ c[3:]) for c in cams])
+
+
+def make_ransac_frame(seed, num_lines=150, num_hypotheses=256, noise_px=0.5):
+    """Inputs of the RANSAC scoring loop (reference src/slam.cpp:396-413): the lines common to two
+    frames in the previous keyframe's frame (world), their observations in the CURRENT frame, and a
+    set of motion hypotheses around the true motion (some exact, some perturbed, some with |t| > 1
+    which the reference skips).  Returns (poses [H,12] = R row-major | t, observations [K,8], lines [K,6],
+    true_pose [12])."""
+    rng = np.random.default_rng(np.random.SeedSequence([6, int(seed)]))
+    w = make_window(seed, num_lines=num_lines, num_kf=2, num_free=2, noise_px=noise_px, mean_track=50.0)
+    prm = w["true_parameters"]
+    lines = orth_to_av(prm[12:].reshape(-1, 4))
+    sel = w["camera_index"] == 0                      # camera 0 = the moving (current) frame, camera 1 = identity
+    obs = np.zeros((num_lines, 8))
+    has = np.zeros(num_lines, dtype=bool)
+    obs[w["line_index"][sel]] = w["observations"][sel]
+    has[w["line_index"][sel]] = True
+    R, t = wt_to_rt(prm[:6])
+    poses = []
+    for h in range(num_hypotheses):
+        s = [0.0, 1e-3, 1e-2, 0.1, 2.0][h % 5] * (1.0 if h < 5 else rng.uniform(0.2, 1.5))
+        Rh = rodrigues(rng.normal(size=3) * 0.3 * s) @ R
+        th = t + rng.normal(size=3) * s
+        poses.append(np.concatenate([Rh.reshape(-1), th]))
+    return np.array(poses), obs[has], lines[has], np.concatenate([R.reshape(-1), t])
