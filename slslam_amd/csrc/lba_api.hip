@@ -199,7 +199,6 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if (b->opt.max_num_iterations < 0 || b->opt.max_num_iterations > 100000) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (!(b->opt.initial_trust_region_radius > 0.0) || !(b->opt.baseline == b->opt.baseline)) return SLSLAM_ERR_INVALID_ARGUMENT;
   b->pol = make_policy(b->opt);
-  if (const char* dbg = std::getenv("SLSLAM_DEBUG_SKIP")) b->pol.pad = std::atoi(dbg);   // timing experiments only (wrong results)
   HIP_TRY(hipSetDevice(b->device));
   const int B = (int)b->wins.size();
 

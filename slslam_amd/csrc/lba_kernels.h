@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     else { for (int q = 0; q < 24; ++q) F[q] = 0.0; }
     // keep what the back-substitution needs (24 doubles per coupled observation, 22 per line) so
     // that it does not have to linearise again
-    if (pol.store_f && elim && !(pol.pad & 4)) {
+    if (pol.store_f && elim) {
       const long long o = (long long)o0 + j;
 #pragma unroll
       for (int q = 0; q < 12; ++q)
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       for (int q = 0; q < 4; ++q) { le[10 + q] = u[q]; le[14 + q] = D2[q]; le[18 + q] = g[q]; }
     }
 
-    if (cam_free && !(pol.pad & 2)) {
+    if (cam_free) {
       const int base = 6 * L.cf;
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     }
 
     // ---- off-diagonal camera pairs of the tile, balanced over the lanes
-    for (int base_it = 0; base_it < ((pol.pad & 1) ? 0 : tc.nitems); base_it += 64) {
+    for (int base_it = 0; base_it < tc.nitems; base_it += 64) {
       const int it = base_it + lane;
       const bool has = it < tc.nitems;
       int li = 0, lj = 0;
