@@ -1,0 +1,65 @@
+// slslam_amd/host/window_packer.h — the array packer around the LBA hot path (SURVEY.md 8a row 7,
+// 8f rank 2): what SLAM::bundle_adjustment does before and after ceres::Solve, on plain structs.
+//   pack    reference src/slam.cpp:811-921   map -> camera_index / line_index / fixed_index / observations / parameters
+//   unpack  reference src/slam.cpp:957-972   parameters -> keyframe poses and landmark lines
+// Ordering rules kept from the reference (its containers are std::map, i.e. ascending ids):
+//   * free cameras = keyframes of ba_kfs with rank < W, in ascending keyframe id (:811-832);
+//   * a landmark enters iff it is a member of >= 2 free keyframes (:838-840), landmarks in ascending id;
+//   * of each landmark, every observation whose keyframe is in ba_kfs, in obs_vec order (:848-882);
+//     keyframes of rank >= W are appended as constant cameras when first met (:855-864);
+//   * line parameter = gc_av_to_orth(gc_line_from_pose(lm->line, init_kf->T)) (:884-886); lines are never
+//     constant (fixed_index[2i+1] = 0, :908-909);
+//   * write-back: every camera incl. the constant ones (:957-962), lines back into the init keyframe's frame
+//     with its UPDATED pose (:964-972).
+// The arrays are allocated with new[] so that ceres::LBAProblem can take ownership as in the reference.
+#ifndef SLSLAM_WINDOW_PACKER_H_
+#define SLSLAM_WINDOW_PACKER_H_
+
+#include "gc_lite.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slslam_keyframe {
+  int id;
+  int ba_rank;                 /* ba_kfs[id] (rank by path length from the newest keyframe); < 0: not in ba_kfs */
+  slslam_pose T;               /* world -> camera */
+  const int* member_lms;       /* landmark ids tracked in this keyframe (keyframe_t::member_lms) */
+  int num_member_lms;
+} slslam_keyframe;
+
+typedef struct slslam_observation { int kf_id; double obs[8]; } slslam_observation;   /* obs_t */
+
+typedef struct slslam_landmark {
+  int id;
+  double line[6];              /* (closest point, direction) in the frame of keyframe init_kf_id */
+  int init_kf_id;
+  const slslam_observation* obs;
+  int num_obs;
+} slslam_landmark;
+
+typedef struct slslam_packed_window {
+  int num_cameras, num_lines, num_observations, num_parameters;
+  int* camera_index;           /* new[]-allocated, as the reference allocates them (slam.cpp:899-903) */
+  int* line_index;
+  int* fixed_index;
+  double* observations;
+  double* parameters;
+  int* camera_kf_id;           /* [C] keyframe id of each camera slot (vec_kfs) */
+  int* line_lm_id;             /* [L] landmark id of each line slot (vec_lms)  */
+} slslam_packed_window;
+
+/* Returns 0, or 1 on inconsistent input (unknown keyframe / landmark ids). */
+int slslam_pack_window(const slslam_keyframe* kfs, int num_kfs, const slslam_landmark* lms, int num_lms,
+                       int window_size, slslam_packed_window* out);
+/* Writes the solved parameters back: kfs[].T and lms[].line are updated in place. */
+int slslam_unpack_window(const slslam_packed_window* w, slslam_keyframe* kfs, int num_kfs,
+                         slslam_landmark* lms, int num_lms);
+/* Frees whatever pack allocated and the caller has not handed to an LBAProblem (pass NULL-ed pointers otherwise). */
+void slslam_free_packed_window(slslam_packed_window* w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -130,3 +130,110 @@ def test_gc_boundary_encodings_match_numpy_restatement():
         assert np.abs(lc[:3] - (R @ av[:3] + wt[3:])).max() < 1e-14 and np.abs(lc[3:] - R @ av[3:]).max() < 1e-14
         lib.slslam_gc_line_from_pose(p(lc), C.byref(T), p(lw))
         assert np.abs(lw - av).max() < 1e-13
+
+
+def _map_from_window(w, lib, C):
+    """A keyframe / landmark map (the reference's kfs / lms / ba_kfs) that should pack to window w."""
+    class Pose(C.Structure):
+        _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3)]
+
+    class KF(C.Structure):
+        _fields_ = [("id", C.c_int), ("ba_rank", C.c_int), ("T", Pose), ("member_lms", C.POINTER(C.c_int)), ("num_member_lms", C.c_int)]
+
+    class Obs(C.Structure):
+        _fields_ = [("kf_id", C.c_int), ("obs", C.c_double * 8)]
+
+    class LM(C.Structure):
+        _fields_ = [("id", C.c_int), ("line", C.c_double * 6), ("init_kf_id", C.c_int), ("obs", C.POINTER(Obs)), ("num_obs", C.c_int)]
+
+    class Packed(C.Structure):
+        _fields_ = [("num_cameras", C.c_int), ("num_lines", C.c_int), ("num_observations", C.c_int), ("num_parameters", C.c_int),
+                    ("camera_index", C.POINTER(C.c_int)), ("line_index", C.POINTER(C.c_int)), ("fixed_index", C.POINTER(C.c_int)),
+                    ("observations", C.POINTER(C.c_double)), ("parameters", C.POINTER(C.c_double)),
+                    ("camera_kf_id", C.POINTER(C.c_int)), ("line_lm_id", C.POINTER(C.c_int))]
+    nk, nf, L = w["num_cameras"], w["num_free_cameras"], w["num_lines"]
+    prm = w["parameters"]
+    # camera slot c of the synthetic window is keyframe id: free slots 0..nf-1 -> ids nk-nf..nk-1, fixed -> 0..nk-nf-1
+    slot_to_kf = list(range(nk - nf, nk)) + list(range(0, nk - nf))
+    kf_to_slot = {k: s for s, k in enumerate(slot_to_kf)}
+    keep = []
+    kfs = (KF * nk)()
+    members = {k: [] for k in range(nk)}
+    for i, (c, l) in enumerate(zip(w["camera_index"], w["line_index"])):
+        members[slot_to_kf[c]].append(int(l))
+    for k in range(nk):
+        kfs[k].id = k
+        kfs[k].ba_rank = nk - 1 - k                     # newest keyframe has rank 0; rank < W <=> free
+        wt = np.ascontiguousarray(prm[6 * kf_to_slot[k]:6 * kf_to_slot[k] + 6])
+        lib.slslam_gc_wt_to_Rt(wt.ctypes.data_as(C.POINTER(C.c_double)), C.byref(kfs[k].T))
+        arr = (C.c_int * max(1, len(members[k])))(*sorted(set(members[k])))
+        keep.append(arr)
+        kfs[k].member_lms = arr
+        kfs[k].num_member_lms = len(set(members[k]))
+    lms = (LM * L)()
+    for l in range(L):
+        sel = np.nonzero(w["line_index"] == l)[0]
+        sel = sel[np.argsort([slot_to_kf[w["camera_index"][i]] for i in sel], kind="stable")]   # obs_vec is in time order
+        obs = (Obs * len(sel))()
+        for j, i in enumerate(sel):
+            obs[j].kf_id = slot_to_kf[w["camera_index"][i]]
+            obs[j].obs[:] = list(w["observations"][i])
+        keep.append(obs)
+        lms[l].id = 1000 + l
+        lms[l].init_kf_id = obs[0].kf_id
+        line_w = np.ascontiguousarray(synth.orth_to_av(prm[6 * nk + 4 * l:6 * nk + 4 * l + 4]))
+        lc = np.zeros(6)
+        lib.slslam_gc_line_to_pose(line_w.ctypes.data_as(C.POINTER(C.c_double)), C.byref(kfs[lms[l].init_kf_id].T),
+                                   lc.ctypes.data_as(C.POINTER(C.c_double)))
+        lms[l].line[:] = list(lc)
+        lms[l].obs = obs
+        lms[l].num_obs = len(sel)
+    for k in range(nk):                                  # member ids must be landmark ids
+        arr = (C.c_int * max(1, len(members[k])))(*[1000 + x for x in sorted(set(members[k]))])
+        keep.append(arr)
+        kfs[k].member_lms = arr
+    return kfs, lms, Packed, keep, slot_to_kf
+
+
+def test_window_packer_reproduces_the_array_contract(oracle):
+    """slslam_pack_window (SLAM::bundle_adjustment pre, slam.cpp:811-921) on a map built from a synthetic
+    window gives the same problem (same solve), and slslam_unpack_window (slam.cpp:957-972) writes the
+    result back into the map."""
+    import ctypes as C
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    lib = C.CDLL(os.path.join(LIBDIR, "libslslam_host.so"))
+    w = synth.make_window(8, num_lines=60, num_kf=12, num_free=5)
+    kfs, lms, Packed, keep, slot_to_kf = _map_from_window(w, lib, C)
+    pk = Packed()
+    assert lib.slslam_pack_window(kfs, len(kfs), lms, len(lms), 5, C.byref(pk)) == 0
+    Cn, L, M = pk.num_cameras, pk.num_lines, pk.num_observations
+    assert (Cn, L, M) == (w["num_cameras"], w["num_lines"], len(w["camera_index"]))
+    cam_kf = [pk.camera_kf_id[c] for c in range(Cn)]
+    assert cam_kf[:5] == slot_to_kf[:5]                                  # free keyframes in ascending id
+    assert sorted(cam_kf[5:]) == sorted(slot_to_kf[5:])
+    w2 = dict(num_cameras=Cn, num_lines=L,
+              camera_index=np.array([pk.camera_index[i] for i in range(M)]), line_index=np.array([pk.line_index[i] for i in range(M)]),
+              fixed_index=np.array([pk.fixed_index[i] for i in range(2 * M)]),
+              observations=np.array([pk.observations[i] for i in range(8 * M)]).reshape(M, 8),
+              parameters=np.array([pk.parameters[i] for i in range(pk.num_parameters)]))
+    assert np.all(w2["fixed_index"][1::2] == 0)
+    assert np.array_equal(w2["fixed_index"][0::2], (w2["camera_index"] >= 5).astype(int))
+    # same problem up to the camera-slot permutation of the constant keyframes: identical optimum
+    x1, s1, _ = oracle.lba_solve(w, linear_solver=1)
+    x2, s2, _ = oracle.lba_solve(w2, linear_solver=1)
+    assert abs(s1["initial_cost"] - s2["initial_cost"]) < 1e-9 * s1["initial_cost"]
+    assert abs(s1["final_cost"] - s2["final_cost"]) < 1e-7 * s1["final_cost"]
+    slot_of = {k: s for s, k in enumerate(slot_to_kf)}
+    for c in range(Cn):
+        assert np.abs(x2[6 * c:6 * c + 6] - x1[6 * slot_of[cam_kf[c]]:6 * slot_of[cam_kf[c]] + 6]).max() < 1e-6
+    # write-back
+    for i in range(pk.num_parameters):
+        pk.parameters[i] = x2[i]
+    assert lib.slslam_unpack_window(C.byref(pk), kfs, len(kfs), lms, len(lms)) == 0
+    back = np.zeros(6)
+    lib.slslam_gc_Rt_to_wt(C.byref(kfs[cam_kf[0]].T), back.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.abs(back - x2[:6]).max() < 1e-9
+    lw = np.zeros(6)
+    lib.slslam_gc_line_from_pose((C.c_double * 6)(*lms[0].line), C.byref(kfs[lms[0].init_kf_id].T), lw.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.abs(lw - synth.orth_to_av(x2[6 * Cn:6 * Cn + 4])).max() < 1e-9
+    lib.slslam_free_packed_window(C.byref(pk))
