@@ -414,8 +414,10 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       if (pol.store_f) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub_stream, g_chunk, blk64, b->lds_bs_stream, s, p, pol));
       else LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub, g_chunk, blk64, b->lds_bs, s, p, pol));
     }
-    if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 1));
-    if (b->nchunk > 0) LAUNCH(FAM_COST, hipLaunchKernelGGL(k_candidate_cost, g_chunk, blk64, b->lds_cost, s, p, pol));
+    if (pol.store_f) {   // the streaming variant has no observation in registers: separate sin/cos and cost sweeps
+      if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 1));
+      if (b->nchunk > 0) LAUNCH(FAM_COST, hipLaunchKernelGGL(k_candidate_cost, g_chunk, blk64, b->lds_cost, s, p, pol));
+    }
     LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol, 1));
   }
 #undef LAUNCH

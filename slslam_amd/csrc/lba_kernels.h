@@ -7,9 +7,8 @@
 //   k_reduced_solve    one wave per window: ordered reduction of the chunk partials, LM damping,
 //                      in-LDS Cholesky of the (6 Cf)^2 system, candidate camera poses
 //   k_backsub          same sweep as the first kernel, back-substitutes every line, writes the
-//                      candidate line parameters and the step statistics
-//   k_line_trig        lane <-> line: sin/cos table of the candidate lines (the only trig)
-//   k_candidate_cost   residual-only sweep at the candidate point
+//                      candidate line parameters (+ their sin/cos table) and the step statistics and,
+//                      with the observation still in registers, the cost at the candidate point
 //   k_lm_update        per window: gain ratio, accept/reject, radius update, convergence tests
 //
 // What this replaces: everything ceres::Solve does for the problem LBAProblem::build wires up
@@ -120,10 +119,9 @@ __device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_e
 template <bool SCALED>
 __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy& pol, const double* camtab,
                                                const signed char* camcf, int ls, int j, int k, int o0, bool line_ok,
-                                               int lflags, int cur, int safe_obs, LaneLin& L) {
+                                               int lflags, int cur, int safe_obs, LaneLin& L, double (&ob)[8]) {
   L.valid = line_ok && j < k;
   const int o = L.valid ? o0 + j : safe_obs;
-  double ob[8];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {     // (x,y) endpoint pairs: one 16-byte load per plane
     const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
@@ -317,7 +315,8 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     const int j = tc.j, ls = tc.ls, o0 = tc.o0, k = tc.k;
     const bool line_ok = tc.line_ok;
     LaneLin L;
-    lane_linearise<!INIT>(p, pol, camtab, camcf, ls, j, k, o0, line_ok, tc.lflags, cur, wd.obs_off, L);
+    double ob[8];
+    lane_linearise<!INIT>(p, pol, camtab, camcf, ls, j, k, o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob);
     if (L.kept) acc_cost += L.cost;
     if (INIT && L.valid && !L.kept) acc_fixed += L.cost;
 
@@ -614,10 +613,38 @@ __global__ __launch_bounds__(64) void k_reduced_solve(BatchPtrs p, Policy pol) {
 
 // ------------------------------------------------------------------------------------------
 // Kernel 3, variant A (default): back-substitution  y_l = A^-1 (g_l - sum_i H_cl,i^T y_c) = K^T K (g_l - w),
-// candidate line parameters, line part of the step statistics.  Re-linearises the chunk (the second
-// of the three algorithmically necessary observation sweeps) instead of spilling
-// Jacobian blocks to HBM.
-__host__ __device__ inline int lds_doubles_backsub(int C, int n) { return C * kCamTab + n + (C + 7) / 8; }
+// candidate line parameters, line part of the step statistics AND the cost at the candidate point.
+// Re-linearises the chunk (the second of the algorithmically necessary observation sweeps,
+// SURVEY.md 8d) instead of spilling Jacobian blocks to HBM; because the observation is still in
+// registers when the line's candidate parameters become known, the candidate residual is
+// evaluated right here: no third sweep over the observations and no separate sin/cos pass.
+enum { kCandTab = 13 };   // doubles per camera of the candidate table: R[9] t[3]; odd stride in 8-byte units
+__host__ __device__ inline int lds_doubles_backsub(int C, int n) { return C * (kCamTab + kCandTab) + n + (C + 7) / 8; }
+
+// sin/cos table of a candidate line, computed cooperatively: every lane of a line's group holds the
+// same u[4]; lane (j & 3) evaluates the sin/cos of angle (j & 3) and the quad shares the results
+// (DPP quad_perm).  Groups of two lanes need two rounds.  Same expressions as line_trig().
+__device__ __forceinline__ void group_line_trig(const double u[4], int lane, int width, double trig[7]) {
+  double s3, c3;
+  if (width >= 4) {
+    const int a = lane & 3;
+    const double ang = a == 0 ? u[0] : a == 1 ? u[1] : a == 2 ? u[2] : u[3];
+    const double sv = sin(ang), cv = cos(ang);
+    trig[0] = dpp_move<0x00>(sv); trig[1] = dpp_move<0x00>(cv);     // quad_perm [0,0,0,0]
+    trig[2] = dpp_move<0x55>(sv); trig[3] = dpp_move<0x55>(cv);     // quad_perm [1,1,1,1]
+    trig[4] = dpp_move<0xAA>(sv); trig[5] = dpp_move<0xAA>(cv);     // quad_perm [2,2,2,2]
+    s3 = dpp_move<0xFF>(sv); c3 = dpp_move<0xFF>(cv);               // quad_perm [3,3,3,3]
+  } else {
+    const int a = lane & 1;
+    const double a0 = a ? u[1] : u[0], a1 = a ? u[3] : u[2];
+    const double sv0 = sin(a0), cv0 = cos(a0), sv1 = sin(a1), cv1 = cos(a1);
+    trig[0] = dpp_move<0xA0>(sv0); trig[1] = dpp_move<0xA0>(cv0);   // quad_perm [0,0,2,2]
+    trig[2] = dpp_move<0xF5>(sv0); trig[3] = dpp_move<0xF5>(cv0);   // quad_perm [1,1,3,3]
+    trig[4] = dpp_move<0xA0>(sv1); trig[5] = dpp_move<0xA0>(cv1);
+    s3 = dpp_move<0xF5>(sv1); c3 = dpp_move<0xF5>(cv1);
+  }
+  trig[6] = c3 / s3;
+}
 
 __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -630,13 +657,22 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
   const double radius = st->radius;
   const int n = wd.n;
   double* camtab = smem;
-  double* yc = camtab + wd.C * kCamTab;
+  double* candtab = camtab + wd.C * kCamTab;
+  double* yc = candtab + wd.C * kCandTab;
   signed char* camcf = (signed char*)(yc + n);
   load_cam_table<true, false>(p, wd, cur, lane, camtab, camcf);
+  for (int c = lane; c < wd.C; c += 64) {     // candidate camera poses (written by k_reduced_solve)
+    const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + (1 - cur)) * kCamRec;
+    double w[3] = { x[0], x[1], x[2] }, R[9];
+    cam_rotation<double>(w, R);
+    double* ct = candtab + c * kCandTab;
+    for (int q = 0; q < 9; ++q) ct[q] = R[q];
+    ct[9] = x[3]; ct[10] = x[4]; ct[11] = x[5];
+  }
   for (int q = lane; q < n; q += 64) yc[q] = p.ysys[wd.sys_off + q];
   __syncthreads();
 
-  double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0;
+  double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0, acc_cost = 0.0;
   TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
     const TileCtx tc = nxt;
@@ -645,7 +681,8 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
     const int j = tc.j, ls = tc.ls, k = tc.k;
     const bool line_ok = tc.line_ok;
     LaneLin L;
-    lane_linearise<true>(p, pol, camtab, camcf, ls, j, k, tc.o0, line_ok, tc.lflags, cur, wd.obs_off, L);
+    double ob[8];
+    lane_linearise<true>(p, pol, camtab, camcf, ls, j, k, tc.o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob);
     double H[10], g[4];
     line_block(L, width, H, g);
     const bool line_active = L.line_free && k > 0;
@@ -664,42 +701,64 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
       for (int a = 0; a < 4; ++a) wv[a] = L.Jl[a] * jy[0] + L.Jl[4 + a] * jy[1] + L.Jl[8 + a] * jy[2] + L.Jl[12 + a] * jy[3];
     }
     group_sum_n<4>(wv, width);
-    if (line_ok && j == 0) {
-      const double* xl = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
-      double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
-      double xn[4] = { xl[0], xl[1], xl[2], xl[3] };
-      if (line_active) {
-        double D2[4], K[10];
-        lm_diag4(H, pol, radius, D2);
-        chol4_inverse(H, D2, K);
-        // z = K (g - w);  y = K^T z
-        const double e0 = g[0] - wv[0], e1 = g[1] - wv[1], e2 = g[2] - wv[2], e3 = g[3] - wv[3];
-        const double z0 = K[0] * e0;
-        const double z1 = K[1] * e0 + K[2] * e1;
-        const double z2 = K[3] * e0 + K[4] * e1 + K[5] * e2;
-        const double z3 = K[6] * e0 + K[7] * e1 + K[8] * e2 + K[9] * e3;
-        double y[4];
-        y[0] = K[0] * z0 + K[1] * z1 + K[3] * z2 + K[6] * z3;
-        y[1] = K[2] * z1 + K[4] * z2 + K[7] * z3;
-        y[2] = K[5] * z2 + K[8] * z3;
-        y[3] = K[9] * z3;
-        const double* lsc = p.line_scale + (long long)ls * 4;
-        for (int a = 0; a < 4; ++a) {
+    // every lane of the group holds the same H, g, w: all of them take the step (the candidate
+    // parameters are needed by every lane below); lane 0 of the group writes and accumulates
+    const int lsafe = line_ok ? ls : 0;
+    const double* xl = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
+    double xn[4] = { xl[0], xl[1], xl[2], xl[3] };
+    const bool head = line_ok && j == 0;
+    if (line_active) {
+      double D2[4], K[10];
+      lm_diag4(H, pol, radius, D2);
+      chol4_inverse(H, D2, K);
+      // z = K (g - w);  y = K^T z
+      const double e0 = g[0] - wv[0], e1 = g[1] - wv[1], e2 = g[2] - wv[2], e3 = g[3] - wv[3];
+      const double z0 = K[0] * e0;
+      const double z1 = K[1] * e0 + K[2] * e1;
+      const double z2 = K[3] * e0 + K[4] * e1 + K[5] * e2;
+      const double z3 = K[6] * e0 + K[7] * e1 + K[8] * e2 + K[9] * e3;
+      double y[4];
+      y[0] = K[0] * z0 + K[1] * z1 + K[3] * z2 + K[6] * z3;
+      y[1] = K[2] * z1 + K[4] * z2 + K[7] * z3;
+      y[2] = K[5] * z2 + K[8] * z3;
+      y[3] = K[9] * z3;
+      const double* lsc = p.line_scale + (long long)lsafe * 4;
+      for (int a = 0; a < 4; ++a) {
+        const double v = xn[a] - y[a] * lsc[a];
+        const double dd = xn[a] - v;
+        if (head) {
           acc_model += 0.5 * y[a] * (g[a] + D2[a] * y[a]);
-          const double v = xn[a] - y[a] * lsc[a];
-          const double dd = xn[a] - v;
           acc_dn2 += dd * dd;
           acc_xn2 += v * v;
-          xn[a] = v;
         }
+        xn[a] = v;
       }
+    }
+    double trig[7];
+    group_line_trig(xn, lane, width, trig);
+    if (head) {
+      double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
       for (int a = 0; a < 4; ++a) xc[a] = xn[a];
+      for (int a = 0; a < 7; ++a) xc[4 + a] = trig[a];
+    }
+    // cost of this observation at the candidate point (cameras from the reduced solve, line from above)
+    {
+      const double* ct = candtab + L.cam * kCandTab;
+      double R[9], tt[3], cp[3], dv[3], r[4], c;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) R[q] = ct[q];
+      tt[0] = ct[9]; tt[1] = ct[10]; tt[2] = ct[11];
+      line_points<double>(trig, cp, dv);
+      obs_residual<double>(R, tt, cp, dv, ob, pol.baseline, r);
+      huber_scale<double>(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], pol.huber_delta, &c);
+      if (L.kept) acc_cost += c;
     }
   }
-  const double m = wave_sum(acc_model), d = wave_sum(acc_dn2), x = wave_sum(acc_xn2);
+  const double m = wave_sum(acc_model), d = wave_sum(acc_dn2), x = wave_sum(acc_xn2), cs = wave_sum(acc_cost);
   if (lane == 0) {
     double* bp = p.bs_part + (long long)blockIdx.x * kBsStride;
     bp[kBsModel] = m; bp[kBsDn2] = d; bp[kBsXn2] = x;
+    p.cost_part[blockIdx.x] = cs;
   }
 }
 
@@ -993,7 +1052,8 @@ __global__ __launch_bounds__(64) void k_debug_linearise(BatchPtrs p, Policy pol,
     for (int j0 = 0; j0 < k; j0 += 64) {
       const int j = j0 + lane;
       LaneLin L;
-      lane_linearise<false>(p, pol, camtab, camcf, ls, j, k, o0, true, p.line_flags[ls], cur, wd.obs_off, L);
+      double ob[8];
+      lane_linearise<false>(p, pol, camtab, camcf, ls, j, k, o0, true, p.line_flags[ls], cur, wd.obs_off, L, ob);
       if (L.valid) {
         const int orig = ob_orig[o0 + j];
         for (int q = 0; q < 4; ++q) out_r[4 * (long long)orig + q] = L.rs[q];
