@@ -233,7 +233,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     else per_chunk = (int)std::min<long long>(32, std::max<long long>(4, total_tiles / 2048));
     const std::vector<int> bounds = chunk_boundaries(wd.ntiles, per_chunk);
     wd.chunk_off = (int)chunks.size(); wd.nchunks = (int)bounds.size() - 1;
-    const long long slab_stride = (long long)wd.n * (wd.n + 1) / 2 + 3LL * wd.n + kSlabScalars;
+    const long long slab_stride = (long long)sys_doubles(wd.n) + kSlabScalars;
     for (int c = 0; c < wd.nchunks; ++c) {
       Chunk ck; ck.win = wi; ck.tile_begin = wd.tile_off + bounds[c]; ck.tile_end = wd.tile_off + bounds[c + 1];
       ck.slab_off = (int)slab; slab += slab_stride;
@@ -340,7 +340,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   b->lds_solve = sizeof(double) * (size_t)lds_doubles_solve(maxn);
   b->lds_bs = sizeof(double) * (size_t)lds_doubles_backsub(maxC, maxn);
   b->lds_bs_stream = sizeof(double) * (size_t)lds_doubles_backsub_stream(maxC, maxn);
-  b->lds_cost = sizeof(double) * (size_t)lds_doubles_cost(maxC);
+  b->lds_cost = sizeof(double) * (size_t)lds_doubles_cost(maxC, maxn);
   const size_t lds_max = std::max(std::max(b->lds_lin, b->lds_solve), std::max(b->lds_bs, b->lds_cost));
   if (lds_max > 160 * 1024) return SLSLAM_ERR_UNSUPPORTED;
   if (b->lds_lin > 48 * 1024) {

@@ -26,9 +26,19 @@
 
 namespace slslam {
 
-enum { kCamTab = 27 };   // doubles per camera in LDS: R[9] JL[9] t[3] scale[6]; odd stride (54 dwords):
-                         // conflict-free ds_read_b64 across cameras.  With the int8 free-index table the
-                         // linearise kernel needs 20 424 B for 20 cameras / 10 free -> 8 workgroups per CU
+enum { kCamTab = 21 };   // doubles per camera in LDS: R[9] JL[9] t[3]; odd stride (42 dwords): conflict-free
+                         // ds_read_b64 across cameras.  The Jacobi scale (6 per FREE camera) is a second table.
+
+// The wave's partial of the reduced camera system, in LDS and (verbatim) in its HBM slab.  Laid out by
+// BLOCK, with odd strides in 8-byte units so that the ds_add_f64 of lanes working on different
+// cameras / camera pairs fall on different banks (a packed lower triangle puts the 45 pair blocks of
+// a 10-camera window on only 8 distinct bank offsets):
+//   camera record cf  (kCamAcc = 39):  diagonal block, lower triangle [21] | b[6] | g[6] | hdiag[6]
+//   pair block (cj > ci) (kPairAcc = 37): 6x6, row a of cj, column b of ci [36] | pad
+// 20 cameras / 10 free: 3360 + 480 + 16440 + 24 = 20 304 B -> 8 workgroups per CU.
+enum { kCamAcc = 39, kPairAcc = 37, kRecB = 21, kRecG = 27, kRecH = 33 };
+__host__ __device__ inline int sys_doubles(int n) { const int cf = n / 6; return cf * kCamAcc + ((cf * (cf - 1)) / 2) * kPairAcc; }
+__device__ __forceinline__ int pair_base(int ncf, int cj, int ci) { return ncf * kCamAcc + ((cj * (cj - 1)) / 2 + ci) * kPairAcc; }
 
 __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 2 + c; }  // r >= c
 
@@ -118,7 +128,7 @@ __device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_e
 // SCALED: apply the Jacobi column scaling (false for the initial evaluation and the test hook).
 template <bool SCALED>
 __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy& pol, const double* camtab,
-                                               const signed char* camcf, int ls, int j, int k, int o0, bool line_ok,
+                                               const double* camscale, const signed char* camcf, int ls, int j, int k, int o0, bool line_ok,
                                                int lflags, int cur, int safe_obs, LaneLin& L, double (&ob)[8]) {
   L.valid = line_ok && j < k;
   const int o = L.valid ? o0 + j : safe_obs;
@@ -142,6 +152,7 @@ __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy&
   for (int q = 0; q < 3; ++q) t[q] = ct[18 + q];
   L.cf = camcf[L.cam];
   L.kept = L.valid && !(L.cf < 0 && !L.line_free);
+  const double* cs = camscale + (L.cf >= 0 ? L.cf : 0) * 6;
   double cp[3], dv[3], dcp[12], ddv[9], r[4];
   line_points_jac<double>(trig, cp, dv, dcp, ddv);
   obs_linearise<double>(R, JL, t, cp, dv, dcp, ddv, ob, pol.baseline, r, L.Jc, L.Jl);
@@ -153,7 +164,7 @@ __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy&
     const double* lsc = p.line_scale + (long long)lsafe * 4;
     double sc[6], sl[4];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) sc[a] = ct[21 + a] * sr;
+    for (int a = 0; a < 6; ++a) sc[a] = cs[a] * sr;
 #pragma unroll
     for (int a = 0; a < 4; ++a) sl[a] = lsc[a] * sr;
 #pragma unroll
@@ -261,7 +272,7 @@ __device__ __forceinline__ void lane_F(const LaneLin& L, const double K[10], dou
 // Camera table of one window in LDS.  WITH_JAC: R and JL at buffer `buf`; else R only.
 template <bool WITH_JAC, bool UNIT_SCALE>
 __device__ __forceinline__ void load_cam_table(const BatchPtrs& p, const WinDesc& wd, int buf, int lane,
-                                               double* camtab, signed char* camcf) {
+                                               double* camtab, double* camscale, signed char* camcf) {
   for (int c = lane; c < wd.C; c += 64) {
     const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + buf) * kCamRec;
     double w[3] = { x[0], x[1], x[2] }, R[9], JL[9];
@@ -270,14 +281,16 @@ __device__ __forceinline__ void load_cam_table(const BatchPtrs& p, const WinDesc
     double* ct = camtab + c * kCamTab;
     for (int q = 0; q < 9; ++q) { ct[q] = R[q]; ct[9 + q] = JL[q]; }
     ct[18] = x[3]; ct[19] = x[4]; ct[20] = x[5];
-    for (int a = 0; a < 6; ++a) ct[21 + a] = UNIT_SCALE ? 1.0 : p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
-    camcf[c] = (signed char)p.cam_cf[wd.cam_off + c];
+    const int cf = p.cam_cf[wd.cam_off + c];
+    if (cf >= 0)
+      for (int a = 0; a < 6; ++a) camscale[6 * cf + a] = UNIT_SCALE ? 1.0 : p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
+    camcf[c] = (signed char)cf;
   }
 }
 
 __host__ __device__ inline int lds_doubles_linearise(int C, int n) {
-  // camtab + S tri + b + g + hdiag ; free-index bytes appended
-  return C * kCamTab + (n * (n + 1)) / 2 + 3 * n + (C + 7) / 8;
+  // camera table + scale table (one unused slot when no camera is free) + partial system ; free-index bytes appended
+  return C * kCamTab + (n > 0 ? n : 6) + sys_doubles(n) + (C + 7) / 8;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -294,15 +307,13 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
   if (st->status != kRunning) return;
   const int cur = st->cur;
   const double radius = st->radius;
-  const int n = wd.n, ntri = (n * (n + 1)) / 2;
+  const int n = wd.n, ncf = n / 6, nsys = sys_doubles(n);
   double* camtab = smem;
-  double* S = camtab + wd.C * kCamTab;
-  double* bvec = S + ntri;
-  double* gvec = bvec + n;
-  double* hvec = gvec + n;
-  signed char* camcf = (signed char*)(hvec + n);
-  load_cam_table<true, INIT>(p, wd, cur, lane, camtab, camcf);
-  for (int q = lane; q < ntri + 3 * n; q += 64) S[q] = 0.0;
+  double* camscale = camtab + wd.C * kCamTab;
+  double* S = camscale + (n > 0 ? n : 6);
+  signed char* camcf = (signed char*)(S + nsys);
+  load_cam_table<true, INIT>(p, wd, cur, lane, camtab, camscale, camcf);
+  for (int q = lane; q < nsys; q += 64) S[q] = 0.0;
   __syncthreads();
 
   double acc_cost = 0.0, acc_fixed = 0.0, acc_gmax = 0.0, acc_xn2 = 0.0;
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     const bool line_ok = tc.line_ok;
     LaneLin L;
     double ob[8];
-    lane_linearise<!INIT>(p, pol, camtab, camcf, ls, j, k, o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob);
+    lane_linearise<!INIT>(p, pol, camtab, camscale, camcf, ls, j, k, o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob);
     if (L.kept) acc_cost += L.cost;
     if (INIT && L.valid && !L.kept) acc_fixed += L.cost;
 
@@ -336,11 +347,12 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
         }
       }
       if (L.valid && L.cf >= 0) {
+        double* rec = S + L.cf * kCamAcc;
         for (int a = 0; a < 6; ++a) {
           double ga = 0.0, ha = 0.0;
           for (int r = 0; r < 4; ++r) { ga += L.Jc[6 * r + a] * L.rs[r]; ha += L.Jc[6 * r + a] * L.Jc[6 * r + a]; }
-          lds_add(&gvec[6 * L.cf + a], ga);
-          lds_add(&hvec[6 * L.cf + a], ha);
+          lds_add(&rec[kRecG + a], ga);
+          lds_add(&rec[kRecH + a], ha);
         }
       }
       continue;
@@ -384,16 +396,16 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     }
 
     if (cam_free) {
-      const int base = 6 * L.cf;
+      double* rec = S + L.cf * kCamAcc;
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         double ga = 0.0, ha = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ga += L.Jc[6 * r + a] * L.rs[r]; ha += L.Jc[6 * r + a] * L.Jc[6 * r + a]; }
         const double fu = F[4 * a] * u[0] + F[4 * a + 1] * u[1] + F[4 * a + 2] * u[2] + F[4 * a + 3] * u[3];
-        lds_add(&gvec[base + a], ga);
-        lds_add(&hvec[base + a], ha);
-        lds_add(&bvec[base + a], ga - fu);
+        lds_add(&rec[kRecG + a], ga);
+        lds_add(&rec[kRecH + a], ha);
+        lds_add(&rec[kRecB + a], ga - fu);
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
           double v = 0.0;
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
           for (int r = 0; r < 4; ++r) v += L.Jc[6 * r + a] * L.Jc[6 * r + b];
 #pragma unroll
           for (int m = 0; m < 4; ++m) v -= F[4 * a + m] * F[4 * b + m];
-          lds_add(&S[tri_index(base + a, base + b)], v);
+          lds_add(&rec[tri_index(a, b)], v);
         }
       }
     }
@@ -418,6 +430,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       const int ci = __shfl(L.cf, li), cj = __shfl(L.cf, lj);
       if (has) {
         if (cj != ci) {        // cj > ci by construction
+          double* blk = S + pair_base(ncf, cj, ci);
 #pragma unroll
           for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -425,14 +438,14 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
               double v = 0.0;
 #pragma unroll
               for (int m = 0; m < 4; ++m) v += Fj[4 * a + m] * Fi[4 * b + m];
-              lds_add(&S[tri_index(6 * cj + a, 6 * ci + b)], -v);
+              lds_add(&blk[6 * a + b], -v);
             }
         } else {               // the same camera observes the line twice: symmetric part
           for (int a = 0; a < 6; ++a)
             for (int b = 0; b <= a; ++b) {
               double v = 0.0;
               for (int m = 0; m < 4; ++m) v += Fj[4 * a + m] * Fi[4 * b + m] + Fi[4 * a + m] * Fj[4 * b + m];
-              lds_add(&S[tri_index(6 * ci + a, 6 * ci + b)], -v);
+              lds_add(&S[ci * kCamAcc + tri_index(a, b)], -v);
             }
         }
       }
@@ -441,12 +454,12 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
 
   __syncthreads();
   double* slab = p.slab + ck.slab_off;
-  for (int q = lane; q < ntri + 3 * n; q += 64) slab[q] = S[q];
+  for (int q = lane; q < nsys; q += 64) slab[q] = S[q];
   const double c_sum = wave_sum(acc_cost), f_sum = wave_sum(acc_fixed), x_sum = wave_sum(acc_xn2);
   const double g_max = wave_max(acc_gmax);
   const int any_fail = __any(fail);
   if (lane == 0) {
-    double* sc = slab + ntri + 3 * n;
+    double* sc = slab + nsys;
     sc[kScCost] = c_sum; sc[kScFixedCost] = f_sum; sc[kScGradMaxLine] = g_max; sc[kScXn2Line] = x_sum;
     sc[kScFail] = any_fail ? 1.0 : 0.0;
   }
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(64) void k_reduced_solve(BatchPtrs p, Policy pol) {
   const WinDesc wd = p.wins[w];
   LMState* st = p.state + w;
   if (st->status != kRunning) return;
-  const int n = wd.n, ntri = (n * (n + 1)) / 2, ld = solve_stride(n);
+  const int n = wd.n, ncf = n / 6, nsys = sys_doubles(n), ld = solve_stride(n);
   double* A = smem;               // n x ld, lower triangle used
   double* bvec = A + n * ld;      // b | g | hdiag | y, contiguous
   double* gvec = bvec + n;
@@ -480,25 +493,37 @@ __global__ __launch_bounds__(64) void k_reduced_solve(BatchPtrs p, Policy pol) {
   // ordered (bitwise reproducible) reduction over the window's chunk partials; the slabs of one
   // window are consecutive with a uniform stride, so the loads of the chunk loop are independent
   const long long slab0 = p.chunks[wd.chunk_off].slab_off;
-  const long long sstride = (long long)ntri + 3 * n + kSlabScalars;
-  for (int q = lane; q < ntri + 3 * n; q += 64) {
+  const long long sstride = (long long)nsys + kSlabScalars;
+  for (int q = lane; q < nsys; q += 64) {
     const double* src = p.slab + slab0 + q;
     double s = 0.0;
 #pragma unroll 8
     for (int k = 0; k < wd.nchunks; ++k) s += src[k * sstride];
-    if (q < ntri) {
-      int r = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
-      while (tri_index(r, 0) > q) --r;
-      while (tri_index(r + 1, 0) <= q) ++r;
-      A[r * ld + (q - tri_index(r, 0))] = s;
+    // where the entry lives in the dense lower triangle / the right-hand sides
+    if (q < ncf * kCamAcc) {
+      const int cf = q / kCamAcc, e = q - cf * kCamAcc;
+      if (e < kRecB) {
+        int a = e >= 15 ? 5 : e >= 10 ? 4 : e >= 6 ? 3 : e >= 3 ? 2 : e >= 1 ? 1 : 0;
+        A[(6 * cf + a) * ld + 6 * cf + (e - tri_index(a, 0))] = s;
+      } else {
+        const int v = (e - kRecB) / 6, a = (e - kRecB) - 6 * v;      // 0 = b, 1 = g, 2 = hdiag
+        bvec[v * n + 6 * cf + a] = s;
+      }
     } else {
-      bvec[q - ntri] = s;
+      const int pq = q - ncf * kCamAcc, pr = pq / kPairAcc, e = pq - pr * kPairAcc;
+      if (e < 36) {
+        int cj = (int)((sqrt(8.0 * pr + 1.0) + 1.0) * 0.5);
+        while ((cj * (cj - 1)) / 2 > pr) --cj;
+        while (((cj + 1) * cj) / 2 <= pr) ++cj;
+        const int ci = pr - (cj * (cj - 1)) / 2;
+        A[(6 * cj + e / 6) * ld + 6 * ci + (e % 6)] = s;
+      }
     }
   }
   double gmax_line = 0.0;
   int fail = 0;
   for (int k = 0; k < wd.nchunks; ++k) {
-    const double* sc = p.slab + p.chunks[wd.chunk_off + k].slab_off + ntri + 3 * n;
+    const double* sc = p.slab + p.chunks[wd.chunk_off + k].slab_off + nsys;
     gmax_line = fmax(gmax_line, sc[kScGradMaxLine]);
     if (sc[kScFail] != 0.0) fail = 1;
   }
@@ -619,7 +644,7 @@ __global__ __launch_bounds__(64) void k_reduced_solve(BatchPtrs p, Policy pol) {
 // registers when the line's candidate parameters become known, the candidate residual is
 // evaluated right here: no third sweep over the observations and no separate sin/cos pass.
 enum { kCandTab = 13 };   // doubles per camera of the candidate table: R[9] t[3]; odd stride in 8-byte units
-__host__ __device__ inline int lds_doubles_backsub(int C, int n) { return C * (kCamTab + kCandTab) + n + (C + 7) / 8; }
+__host__ __device__ inline int lds_doubles_backsub(int C, int n) { return C * (kCamTab + kCandTab) + 2 * (n > 0 ? n : 6) + (C + 7) / 8; }
 
 // sin/cos table of a candidate line, computed cooperatively: every lane of a line's group holds the
 // same u[4]; lane (j & 3) evaluates the sin/cos of angle (j & 3) and the quad shares the results
@@ -658,9 +683,10 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
   const int n = wd.n;
   double* camtab = smem;
   double* candtab = camtab + wd.C * kCamTab;
-  double* yc = candtab + wd.C * kCandTab;
-  signed char* camcf = (signed char*)(yc + n);
-  load_cam_table<true, false>(p, wd, cur, lane, camtab, camcf);
+  double* camscale = candtab + wd.C * kCandTab;
+  double* yc = camscale + (n > 0 ? n : 6);
+  signed char* camcf = (signed char*)(yc + (n > 0 ? n : 6));
+  load_cam_table<true, false>(p, wd, cur, lane, camtab, camscale, camcf);
   for (int c = lane; c < wd.C; c += 64) {     // candidate camera poses (written by k_reduced_solve)
     const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + (1 - cur)) * kCamRec;
     double w[3] = { x[0], x[1], x[2] }, R[9];
@@ -682,7 +708,7 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
     const bool line_ok = tc.line_ok;
     LaneLin L;
     double ob[8];
-    lane_linearise<true>(p, pol, camtab, camcf, ls, j, k, tc.o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob);
+    lane_linearise<true>(p, pol, camtab, camscale, camcf, ls, j, k, tc.o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob);
     double H[10], g[4];
     line_block(L, width, H, g);
     const bool line_active = L.line_free && k > 0;
@@ -866,7 +892,7 @@ __global__ __launch_bounds__(256) void k_line_trig(BatchPtrs p, int which) {
 
 // ------------------------------------------------------------------------------------------
 // Kernel 5: cost of the reduced program at the candidate point (residuals only).
-__host__ __device__ inline int lds_doubles_cost(int C) { return C * kCamTab + (C + 7) / 8; }
+__host__ __device__ inline int lds_doubles_cost(int C, int n) { return C * kCamTab + (n > 0 ? n : 6) + (C + 7) / 8; }
 
 __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -877,8 +903,9 @@ __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) 
   if (st->status != kRunning) return;
   const int cand = 1 - st->cur;
   double* camtab = smem;
-  signed char* camcf = (signed char*)(camtab + wd.C * kCamTab);
-  load_cam_table<false, true>(p, wd, cand, lane, camtab, camcf);
+  double* camscale = camtab + wd.C * kCamTab;
+  signed char* camcf = (signed char*)(camscale + (wd.n > 0 ? wd.n : 6));
+  load_cam_table<false, true>(p, wd, cand, lane, camtab, camscale, camcf);
   __syncthreads();
   double acc = 0.0;
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
@@ -933,14 +960,14 @@ __global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol, int p
   const WinDesc wd = p.wins[w];
   LMState* st = p.state + w;
   if (st->status != kRunning) return;
-  const int n = wd.n, ntri = (n * (n + 1)) / 2;
+  const int n = wd.n, nsys = sys_doubles(n);
   IterRec rec;
   rec.pad = 0;
   if (phase == 0) {
     // ---- Ceres: initial cost / gradient / Jacobi scale
     double cost = 0.0, fixed = 0.0, gmax = 0.0, xn2 = 0.0;
     for (int c = 0; c < wd.nchunks; ++c) {
-      const double* sc = p.slab + p.chunks[wd.chunk_off + c].slab_off + ntri + 3 * n;
+      const double* sc = p.slab + p.chunks[wd.chunk_off + c].slab_off + nsys;
       cost += sc[kScCost]; fixed += sc[kScFixedCost]; gmax = fmax(gmax, sc[kScGradMaxLine]); xn2 += sc[kScXn2Line];
     }
     for (int c = 0; c < wd.C; ++c) {
@@ -951,8 +978,8 @@ __global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol, int p
         if (cf >= 0) {
           double g = 0.0, h = 0.0;
           for (int k = 0; k < wd.nchunks; ++k) {
-            const double* sl = p.slab + p.chunks[wd.chunk_off + k].slab_off + ntri;
-            g += sl[n + 6 * cf + a]; h += sl[2 * n + 6 * cf + a];
+            const double* sl = p.slab + p.chunks[wd.chunk_off + k].slab_off + cf * kCamAcc;
+            g += sl[kRecG + a]; h += sl[kRecH + a];
           }
           gmax = fmax(gmax, fabs(g));
           xn2 += x[a] * x[a];
@@ -1042,8 +1069,9 @@ __global__ __launch_bounds__(64) void k_debug_linearise(BatchPtrs p, Policy pol,
   const LMState* st = p.state + w;
   const int cur = st->cur;
   double* camtab = smem;
-  signed char* camcf = (signed char*)(camtab + wd.C * kCamTab);
-  load_cam_table<true, true>(p, wd, cur, lane, camtab, camcf);
+  double* camscale = camtab + wd.C * kCamTab;
+  signed char* camcf = (signed char*)(camscale + (wd.n > 0 ? wd.n : 6));
+  load_cam_table<true, true>(p, wd, cur, lane, camtab, camscale, camcf);
   __syncthreads();
   double acc = 0.0;
   for (int l = 0; l < wd.L; ++l) {
@@ -1053,7 +1081,7 @@ __global__ __launch_bounds__(64) void k_debug_linearise(BatchPtrs p, Policy pol,
       const int j = j0 + lane;
       LaneLin L;
       double ob[8];
-      lane_linearise<false>(p, pol, camtab, camcf, ls, j, k, o0, true, p.line_flags[ls], cur, wd.obs_off, L, ob);
+      lane_linearise<false>(p, pol, camtab, camscale, camcf, ls, j, k, o0, true, p.line_flags[ls], cur, wd.obs_off, L, ob);
       if (L.valid) {
         const int orig = ob_orig[o0 + j];
         for (int q = 0; q < 4; ++q) out_r[4 * (long long)orig + q] = L.rs[q];
