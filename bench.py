@@ -56,6 +56,27 @@ def cpu_baseline(windows, budget_s=12.0):
     return its / dt, "%d of the bench windows (%.1f s, %d LM iterations), 1 thread" % (len(outs), dt, its), outs
 
 
+def cpu_baseline_all_cores(windows, budget_s=15.0):
+    """Same oracle, fanned out over independent windows on every host core: one
+    solve per thread (ctypes releases the GIL), as many windows as fit the time budget."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle          # cpu_baseline leg only
+    cores = os.cpu_count() or 1
+    per_core = max(1, int(budget_s / 0.25 / 2))      # ~0.2-0.25 s per 2000-line window and thread
+    sample = windows[:min(len(windows), cores * per_core)]
+
+    def one(w):
+        _, s, _ = pyoracle.lba_solve(w, linear_solver=1)
+        return s["num_successful_steps"] + s["num_unsuccessful_steps"]
+    pyoracle.lib()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        its = sum(ex.map(one, sample))
+    dt = time.perf_counter() - t0
+    return its / dt, cores, "%d of the bench windows (%.1f s wall, %d LM iterations), one solve per thread, %d threads" % (
+        len(sample), dt, its, min(cores, len(sample)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +210,8 @@ def main():
             v, sample, outs = cpu_baseline(windows)
             out["cpu_baseline"] = {"value": v, "unit": "LM iterations/s", "cores": 1, "kind": "port", "sample": sample,
                                    "host_cores_available": os.cpu_count()}
+            va, ca, sa = cpu_baseline_all_cores(windows)
+            out["cpu_baseline_all_cores"] = {"value": va, "unit": "LM iterations/s", "cores": ca, "kind": "port", "sample": sa}
             # trajectory error of the GPU solve against the oracle solve of the same windows
             err = []
             for i, xo in enumerate(outs):

@@ -200,8 +200,7 @@ int slslam_po_solve(const slslam_po_graph* graph, const slslam_solver_options* o
  * common line, the mean absolute endpoint-to-line distance in both stereo images, an inlier when it is
  * below error_thr = 5 / focal_length (src/parameter.h:56); hypotheses with |t| > 1 are skipped
  * (src/slam.cpp:398-399) and score -1 here.  The reference's float/double mix (float `sql`, float
- * error accumulator) is reproduced exactly, so scores and inlier sets are bit-identical.
- * Hypothesis generation (vo_angle_axis_approx) and the adaptive trial loop stay on the host. */
+ * error accumulator) is reproduced exactly, so scores and inlier sets are bit-identical. */
 typedef struct slslam_ransac_frame {
   int num_hypotheses;             /* motions to score                                           */
   int num_lines;                  /* comm_size: lines visible in both frames                    */
@@ -215,6 +214,34 @@ typedef struct slslam_ransac_frame {
  * Synchronous; host pointers. */
 int slslam_ransac_score(const slslam_ransac_frame* frame, double baseline, double error_thr,
                         int* scores, unsigned long long* inlier_bits);
+
+/* ------------------------------------------------------------------ RANSAC hypothesis generation + trial loop
+ * Replaces: SLAM::vo_angle_axis_approx (reference src/slam.cpp:433-574) — the linearised stereo-line motion from
+ * s = max_feat_num = 5 sampled correspondences — for EVERY pre-drawn trial at once (lane <-> trial), and
+ * SLAM::ransac_motion (src/slam.cpp:322-427): generate, score, then replay the reference's adaptive trial loop
+ * (`trial_cnt < ransac_trial && trial_cnt <= max_trials`, ransac_trial re-estimated whenever the best score
+ * improves, :363, :415-423) in trial order over the scores, so that best pose, best score, inlier set and
+ * trial_cnt are what the sequential loop returns for the same sample sequence.  The caller draws the samples
+ * (the reference: rand.rand_sample(sample, comm_size, s) once per trial, :366). */
+typedef struct slslam_ransac_trials {
+  int num_trials;                 /* pre-drawn trials (<= max_trials + 1 are ever looked at)            */
+  int sample_size;                /* s = max_feat_num (src/parameter.h:25), 1..16                       */
+  int num_lines;                  /* comm_size                                                          */
+  const int*    samples;          /* [num_trials * s] indices into the common-line arrays               */
+  const double* observations0;    /* [8 K] obs0: previous frame                                         */
+  const double* observations1;    /* [8 K] obs1: current frame                                          */
+} slslam_ransac_trials;
+
+/* poses[12 H] (R row-major | t), valid[H] = num_sol (0 when a degenerate sample made the reference return 0).
+ * `baseline` is passed through as given (the reference calls it with -baseline, src/slam.cpp:392). */
+int slslam_ransac_generate(const slslam_ransac_trials* trials, double baseline, double* poses, int* valid);
+
+/* Whole ransac_motion.  lines [6 K] as in slslam_ransac_frame.  *best_score_io: in = the caller's running best
+ * (reference: 0), out = best score; *trial_cnt = trials executed; best_pose[12] and best_inlier_bits[(K+63)/64]
+ * (may be NULL) are written only when some trial beat the incoming best score. */
+int slslam_ransac_motion(const slslam_ransac_trials* trials, const double* lines, double baseline, double error_thr,
+                         double prob_free_outliers, int max_trials, int* best_score_io, int* trial_cnt,
+                         double* best_pose, unsigned long long* best_inlier_bits);
 
 /* ------------------------------------------------------------------ misc */
 int         slslam_device_count(void);          /* 0 when no HIP device is usable */

@@ -92,6 +92,9 @@ def lib():
         _lib.oracle_po_solve.argtypes = [C.POINTER(POProblem), C.POINTER(LMOptions), dp,
                                          C.POINTER(Summary), C.POINTER(Iteration), C.c_int, ip]
         _lib.oracle_ransac_score.argtypes = [C.c_int, dp, C.c_int, dp, dp, C.c_double, C.c_double, ip, C.POINTER(C.c_ubyte)]
+        _lib.oracle_vo_angle_axis_approx.argtypes = [C.c_int, dp, dp, C.c_double, dp]
+        _lib.oracle_ransac_motion.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_int, ip, C.c_double, C.c_double, C.c_double,
+                                              C.c_int, ip, dp, C.POINTER(C.c_ubyte)]
         _lib.oracle_av_to_orth.argtypes = [dp, dp]
         _lib.oracle_orth_to_av.argtypes = [dp, dp]
     return _lib
@@ -243,3 +246,26 @@ def ransac_score(poses, observations, lines, baseline=0.12, error_thr=5.0 / 406.
     lib().oracle_ransac_score(h, _dp(poses), k, _dp(obs), _dp(ln), float(baseline), float(error_thr), _ip(scores),
                               inl.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return scores[:h], inl[:h * k].reshape(h, k).astype(bool)
+
+
+def vo_angle_axis_approx(obs0, obs1, baseline=-0.12):
+    """SLAM::vo_angle_axis_approx on s sampled correspondences -> (num_solutions, pose[12])."""
+    o0, o1 = _f64(obs0).reshape(-1, 8), _f64(obs1).reshape(-1, 8)
+    pose = np.zeros(12)
+    n = lib().oracle_vo_angle_axis_approx(len(o0), _dp(o0), _dp(o1), float(baseline), _dp(pose))
+    return n, pose
+
+
+def ransac_motion(obs0, obs1, lines, samples, baseline=0.12, error_thr=5.0 / 406.05, prob_free_outliers=0.999,
+                  max_trials=1000, best_score=0):
+    """SLAM::ransac_motion over a given sample sequence [T, s] -> (trial_cnt, best_score, best_pose, inliers)."""
+    o0, o1, ln = _f64(obs0).reshape(-1, 8), _f64(obs1).reshape(-1, 8), _f64(lines).reshape(-1, 6)
+    smp = np.ascontiguousarray(samples, dtype=np.int32)
+    k = len(o0)
+    bs = np.array([best_score], dtype=np.int32)
+    pose = np.zeros(12)
+    inl = np.zeros(max(k, 1), dtype=np.uint8)
+    tc = lib().oracle_ransac_motion(k, _dp(o0), _dp(o1), _dp(ln), smp.shape[1], smp.shape[0], _ip(smp), float(baseline),
+                                    float(error_thr), float(prob_free_outliers), int(max_trials), _ip(bs), _dp(pose),
+                                    inl.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return tc, int(bs[0]), pose, inl[:k].astype(bool)

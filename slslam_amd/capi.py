@@ -59,6 +59,11 @@ class LBAWindow(C.Structure):
                 ("parameters", C.POINTER(C.c_double))]
 
 
+class RansacTrials(C.Structure):
+    _fields_ = [("num_trials", C.c_int), ("sample_size", C.c_int), ("num_lines", C.c_int), ("samples", C.POINTER(C.c_int)),
+                ("observations0", C.POINTER(C.c_double)), ("observations1", C.POINTER(C.c_double))]
+
+
 class RansacFrame(C.Structure):
     _fields_ = [("num_hypotheses", C.c_int), ("num_lines", C.c_int), ("poses", C.POINTER(C.c_double)),
                 ("observations", C.POINTER(C.c_double)), ("lines", C.POINTER(C.c_double))]
@@ -77,7 +82,7 @@ EXPORTS = [
     "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
-    "slslam_po_solve", "slslam_ransac_score", "slslam_device_count", "slslam_version", "slslam_status_string",
+    "slslam_po_solve", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_device_count", "slslam_version", "slslam_status_string",
 ]
 
 _lib = None
@@ -116,6 +121,9 @@ def lib():
     L.slslam_po_solve.argtypes = [C.POINTER(POGraph), C.POINTER(SolverOptions), C.POINTER(Summary),
                                   C.POINTER(Iteration), C.c_int, ip]
     L.slslam_ransac_score.argtypes = [C.POINTER(RansacFrame), C.c_double, C.c_double, ip, C.POINTER(C.c_ulonglong)]
+    L.slslam_ransac_generate.argtypes = [C.POINTER(RansacTrials), C.c_double, dp, ip]
+    L.slslam_ransac_motion.argtypes = [C.POINTER(RansacTrials), dp, C.c_double, C.c_double, C.c_double, C.c_int, ip, ip, dp,
+                                       C.POINTER(C.c_ulonglong)]
     L.slslam_device_count.restype = C.c_int
     L.slslam_version.restype = C.c_char_p
     L.slslam_status_string.argtypes = [C.c_int]
@@ -323,3 +331,46 @@ def ransac_score(poses, observations, lines, baseline=0.12, error_thr=5.0 / 406.
             n = min(64, k - 64 * w)
             mask[:, 64 * w:64 * w + n] = ((b[:, w:w + 1] >> np.arange(n, dtype=np.uint64)) & np.uint64(1)).astype(bool)
     return scores[:h], mask
+
+
+def _trials(obs0, obs1, samples):
+    o0 = np.ascontiguousarray(obs0, dtype=np.float64).reshape(-1, 8)
+    o1 = np.ascontiguousarray(obs1, dtype=np.float64).reshape(-1, 8)
+    smp = np.ascontiguousarray(samples, dtype=np.int32)
+    if smp.ndim != 2 or len(o0) != len(o1):
+        raise ValueError("samples must be [trials, s]; obs0 and obs1 must have the same length")
+    return RansacTrials(smp.shape[0], smp.shape[1], len(o0), _ip(smp), _dp(o0), _dp(o1)), (o0, o1, smp)
+
+
+def ransac_generate(obs0, obs1, samples, baseline=-0.12):
+    """SLAM::vo_angle_axis_approx for every pre-drawn trial (slslam_ransac_generate) -> (poses [H,12], valid [H])."""
+    tr, keep = _trials(obs0, obs1, samples)
+    h = tr.num_trials
+    poses = np.zeros((max(h, 1), 12))
+    valid = np.zeros(max(h, 1), dtype=np.int32)
+    _check(lib().slslam_ransac_generate(C.byref(tr), float(baseline), _dp(poses), _ip(valid)), "slslam_ransac_generate")
+    return poses[:h], valid[:h]
+
+
+def ransac_motion(obs0, obs1, lines, samples, baseline=0.12, error_thr=5.0 / 406.05, prob_free_outliers=0.999,
+                  max_trials=1000, best_score=0):
+    """SLAM::ransac_motion over a pre-drawn sample sequence (slslam_ransac_motion)
+    -> (trial_cnt, best_score, best_pose [12], inlier mask [K])."""
+    tr, keep = _trials(obs0, obs1, samples)
+    ln = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 6)
+    k = tr.num_lines
+    if len(ln) != k:
+        raise ValueError("lines and observations must have the same length")
+    words = (k + 63) // 64
+    bs = np.array([best_score], dtype=np.int32)
+    tc = np.zeros(1, dtype=np.int32)
+    pose = np.zeros(12)
+    bits = np.zeros(max(words, 1), dtype=np.uint64)
+    _check(lib().slslam_ransac_motion(C.byref(tr), _dp(ln), float(baseline), float(error_thr), float(prob_free_outliers),
+                                      int(max_trials), _ip(bs), _ip(tc), _dp(pose), bits.ctypes.data_as(C.POINTER(C.c_ulonglong))),
+           "slslam_ransac_motion")
+    mask = np.zeros(k, dtype=bool)
+    for w in range(words):
+        n = min(64, k - 64 * w)
+        mask[64 * w:64 * w + n] = ((bits[w] >> np.arange(n, dtype=np.uint64)) & np.uint64(1)).astype(bool)
+    return int(tc[0]), int(bs[0]), pose, mask

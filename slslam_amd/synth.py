@@ -387,3 +387,48 @@ def make_ransac_frame(seed, num_lines=150, num_hypotheses=256, noise_px=0.5):
         th = t + rng.normal(size=3) * s
         poses.append(np.concatenate([Rh.reshape(-1), th]))
     return np.array(poses), obs[has], lines[has], np.concatenate([R.reshape(-1), t])
+
+
+def make_ransac_pair(seed, num_lines=150, noise_px=0.5, outlier_frac=0.2, num_trials=64, sample_size=5,
+                     rot_deg=1.0, step_m=0.15):
+    """Inputs of SLAM::ransac_motion (reference src/slam.cpp:322-427): the lines common to the previous
+    and the current frame (world = previous frame), their stereo observations in both frames (a
+    fraction of the current ones corrupted: wrong matches), and a pre-drawn sample sequence
+    (rand.rand_sample draws sample_size distinct indices per trial).  Frame-to-frame motion is small
+    (the generator linearises the rotation).  Returns dict(obs0, obs1, lines, samples, true_pose)."""
+    rng = np.random.default_rng(np.random.SeedSequence([7, int(seed)]))
+    # a dedicated small-motion pair: previous frame = identity, current frame = small motion
+    wv = rng.normal(size=3) * np.deg2rad(rot_deg)
+    tv = rng.normal(size=3) * step_m * np.array([0.3, 0.1, 1.0])
+    R = rodrigues(wv)
+    f, cx, cy, B = 406.05, 327.783, 237.172, 0.12
+    obs0, obs1, lines = [], [], []
+    while len(lines) < num_lines:
+        c = np.array([rng.uniform(-4, 4), rng.uniform(-2, 2), rng.uniform(2.5, 10)])
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        h = rng.uniform(0.25, 1.5)
+        P = np.stack([c - h * d, c + h * d])
+        ok, rec = True, []
+        for (Rc, tc) in ((np.eye(3), np.zeros(3)), (R, tv)):
+            o = []
+            for k in range(2):
+                Q = (Rc @ P.T).T + tc - np.array([k * B, 0, 0])
+                if np.any(Q[:, 2] < 0.5):
+                    ok = False
+                px = np.stack([f * Q[:, 0] / Q[:, 2] + cx, f * Q[:, 1] / Q[:, 2] + cy], axis=1)
+                if np.any(px[:, 0] < 0) or np.any(px[:, 0] > 640) or np.any(px[:, 1] < 0) or np.any(px[:, 1] > 480):
+                    ok = False
+                px = px + rng.normal(size=(2, 2)) * noise_px
+                o.append(((px - [cx, cy]) / f).reshape(-1))
+            rec.append(np.concatenate(o))
+        if not ok:
+            continue
+        dv = (P[1] - P[0]) / np.linalg.norm(P[1] - P[0])
+        cp = P[0] - dv * (P[0] @ dv)
+        obs0.append(rec[0]); obs1.append(rec[1]); lines.append(np.concatenate([cp, dv]))
+    obs0, obs1, lines = np.array(obs0), np.array(obs1), np.array(lines)
+    bad = rng.random(num_lines) < outlier_frac
+    obs1[bad] += rng.normal(size=(int(bad.sum()), 8)) * 0.05
+    samples = np.stack([rng.choice(num_lines, size=sample_size, replace=False) for _ in range(num_trials)]).astype(np.int32)
+    return dict(obs0=obs0, obs1=obs1, lines=lines, samples=samples, true_pose=np.concatenate([R.reshape(-1), tv]),
+                outliers=bad)

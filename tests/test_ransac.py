@@ -46,3 +46,60 @@ def test_gpu_scores_are_bit_identical(hip, oracle, seed, K, H):
     assert len(s) == 0
     s, m = hip.ransac_score(poses, obs[:0], lines[:0])
     assert np.array_equal(s, np.where(np.linalg.norm(poses[:, 9:], axis=1) > 1.0, -1, 0))
+
+
+def test_oracle_motion_generator_recovers_small_motion(oracle):
+    """SLAM::vo_angle_axis_approx (slam.cpp:433-574) restated: on noise-free correspondences of a small
+    frame-to-frame motion the linearised solver returns that motion (to the linearisation error), which
+    pins the sign conventions (-baseline at the call site, T = previous -> current)."""
+    fr = synth.make_ransac_pair(1, num_lines=80, noise_px=0.0, outlier_frac=0.0, rot_deg=0.3)
+    for tr in fr["samples"][:8]:
+        n, pose = oracle.vo_angle_axis_approx(fr["obs0"][tr], fr["obs1"][tr])
+        assert n == 1
+        assert np.abs(pose[:9] - fr["true_pose"][:9]).max() < 2e-4
+        assert np.abs(pose[9:] - fr["true_pose"][9:]).max() < 5e-3
+    # degenerate sample (a zero-length observed segment -> zero image line): no solution
+    o0 = fr["obs0"][fr["samples"][0]].copy()
+    o0[0, 2:4] = o0[0, 0:2]
+    n, _ = oracle.vo_angle_axis_approx(o0, fr["obs1"][fr["samples"][0]])
+    assert n == 0
+
+
+def test_oracle_ransac_motion_finds_the_inlier_set(oracle):
+    fr = synth.make_ransac_pair(2, num_lines=150, noise_px=0.3, outlier_frac=0.25, num_trials=200)
+    tc, best, pose, inl = oracle.ransac_motion(fr["obs0"], fr["obs1"], fr["lines"], fr["samples"])
+    good = ~fr["outliers"]
+    assert 0 < tc < 200                                          # the adaptive bound stopped the loop early
+    assert best >= 0.9 * good.sum() and (inl & fr["outliers"]).sum() <= 0.1 * fr["outliers"].sum() + 2
+    assert np.abs(pose[9:] - fr["true_pose"][9:]).max() < 0.05
+    # the loop honours an incoming best score that nothing beats
+    tc2, best2, _, _ = oracle.ransac_motion(fr["obs0"], fr["obs1"], fr["lines"], fr["samples"], best_score=10 ** 6)
+    assert best2 == 10 ** 6 and tc2 == min(len(fr["obs0"]), 200)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,K,T", [(1, 150, 256), (2, 40, 64), (3, 300, 1001)])
+def test_gpu_motion_generator_and_trial_loop(hip, oracle, seed, K, T):
+    fr = synth.make_ransac_pair(seed, num_lines=K, noise_px=0.4, outlier_frac=0.3, num_trials=T)
+    poses, valid = hip.ransac_generate(fr["obs0"], fr["obs1"], fr["samples"])
+    assert valid.all()
+    for h in range(0, T, max(1, T // 40)):
+        n, ref = oracle.vo_angle_axis_approx(fr["obs0"][fr["samples"][h]], fr["obs1"][fr["samples"][h]])
+        assert n == 1
+        # fp64, same operation order; sin/cos of the device library differ from glibc by an ulp
+        assert np.abs(poses[h] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    tc0, b0, p0, i0 = oracle.ransac_motion(fr["obs0"], fr["obs1"], fr["lines"], fr["samples"])
+    tc1, b1, p1, i1 = hip.ransac_motion(fr["obs0"], fr["obs1"], fr["lines"], fr["samples"])
+    assert (tc0, b0) == (tc1, b1)
+    assert np.array_equal(i0, i1)
+    assert np.abs(p0 - p1).max() < 1e-9
+    # degenerate sample in trial 0 -> that trial is skipped (num_sol == 0), the loop goes on
+    o0 = fr["obs0"].copy()
+    k = fr["samples"][0][0]
+    o0[k, 2:4] = o0[k, 0:2]
+    _, v = hip.ransac_generate(o0, fr["obs1"], fr["samples"])
+    uses = (fr["samples"] == k).any(axis=1)
+    assert np.array_equal(v == 0, uses)
+    t0 = oracle.ransac_motion(o0, fr["obs1"], fr["lines"], fr["samples"])
+    t1 = hip.ransac_motion(o0, fr["obs1"], fr["lines"], fr["samples"])
+    assert t0[:2] == t1[:2] and np.array_equal(t0[3], t1[3])
