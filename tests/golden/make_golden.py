@@ -11,6 +11,11 @@ The reference ships no golden vectors for this path and its solver (Ceres 1.7.0)
                         scipy.optimize.least_squares (trust-region reflective, numerical Jacobian)
                         on that transcription.
 * `po_optimum.npz`     a small pose graph and its least-squares optimum, same method.
+* `traj_excerpt.txt`   DATA excerpt (25 lines) of two trajectory files the reference ships as results
+                        (matlab_script/traj_slslam_itbt3f_basize10_wolc.txt lines 1-12 and
+                        traj_slslam_myungdong_basize10_wlc.txt lines 100-112): output of the reference's
+                        SLAM::save_trajectory (src/slam.cpp:1470-1496), used to pin the text format of
+                        slslam_write_trajectory.
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -149,7 +154,15 @@ def make_po(rng):
     print("po optimum: cost %.6e -> %.6e, |grad|inf %.2e" % (0.5 * np.sum(fun(x0[6:]) ** 2), 0.5 * np.sum(sol.fun ** 2), np.abs(sol.grad).max()))
 
 
+def make_traj_excerpt():
+    ref = "/root/reference/matlab_script"
+    a = open(os.path.join(ref, "traj_slslam_itbt3f_basize10_wolc.txt")).read().splitlines(True)[:12]
+    b = open(os.path.join(ref, "traj_slslam_myungdong_basize10_wlc.txt")).read().splitlines(True)[99:112]
+    open(os.path.join(HERE, "traj_excerpt.txt"), "w").write("".join(a + b))
+
+
 if __name__ == "__main__":
+    make_traj_excerpt()
     rng = np.random.default_rng(20260927)
     make_kat(rng)
     make_lba(rng)

@@ -237,3 +237,106 @@ def test_window_packer_reproduces_the_array_contract(oracle):
     lib.slslam_gc_line_from_pose((C.c_double * 6)(*lms[0].line), C.byref(kfs[lms[0].init_kf_id].T), lw.ctypes.data_as(C.POINTER(C.c_double)))
     assert np.abs(lw - synth.orth_to_av(x2[6 * Cn:6 * Cn + 4])).max() < 1e-9
     lib.slslam_free_packed_window(C.byref(pk))
+
+
+def _host_lib():
+    import ctypes as C
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    return C, C.CDLL(os.path.join(LIBDIR, "libslslam_host.so"))
+
+
+def test_trajectory_writer_reproduces_the_reference_files():
+    """Lines of trajectory files the reference ships (output of SLAM::save_trajectory, slam.cpp:1470-1496):
+    rebuild the keyframe pose each line encodes, format it with slslam_format_trajectory_line -> same text."""
+    C, lib = _host_lib()
+
+    class Pose(C.Structure):
+        _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3)]
+    golden = open(os.path.join(ROOT, "tests", "golden", "traj_excerpt.txt")).read().splitlines(True)
+    assert len(golden) == 25
+    buf = C.create_string_buffer(512)
+    for ln in golden:
+        f = ln.split("\t")
+        idx, z, mx, my, w = int(f[0]), float(f[1]), float(f[2]), float(f[3]), np.array([float(v) for v in f[4:7]])
+        Ti = Pose()                                           # gc_T_inv(kf->T): camera position / orientation in the root frame
+        lib.slslam_gc_rodrigues_to_R((C.c_double * 3)(*w), Ti.R)
+        Ti.t[:] = [-mx + 0.0, -my + 0.0, z]
+        T = Pose()
+        lib.slslam_gc_T_inv(C.byref(Ti), C.byref(T))
+        assert lib.slslam_format_trajectory_line(idx, C.byref(T), buf, 512) == 0
+        got = buf.value.decode()
+        if idx == 0:                                          # the root line: signs of zero are not recoverable from text
+            assert got.replace("-0", "0") == ln.replace("-0", "0")
+        else:
+            assert got == ln
+
+
+def test_frame_reader_and_metric_embedding(tmp_path):
+    C, lib = _host_lib()
+
+    class Intr(C.Structure):
+        _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
+
+    class Frame(C.Structure):
+        _fields_ = [("num_lines", C.c_int), ("ids", C.POINTER(C.c_int)), ("observations", C.POINTER(C.c_double))]
+
+    class Pose(C.Structure):
+        _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3)]
+
+    class Edge(C.Structure):
+        _fields_ = [("from_", C.c_int), ("to", C.c_int), ("T", Pose)]
+    # ---- reader: "id x0 y0 x1 y1 x2 y2 x3 y3 extra", unsorted ids, a duplicate, an alias, a blank line
+    K = Intr(406.05, 406.05, 327.783, 237.172)
+    rows = {17: [100.5, 50.25, 200, 60, 90, 50, 190, 60], 3: [10, 20, 30, 40, 5, 20, 25, 40], 9: [1, 2, 3, 4, 5, 6, 7, 8]}
+    text = "17 " + " ".join(str(v) for v in rows[17]) + " 0.5\n" + "3 " + " ".join(str(v) for v in rows[3]) + "\n\n" + \
+           "17 0 0 0 0 0 0 0 0\n" + "9 " + " ".join(str(v) for v in rows[9]) + " 1\n"
+    path = tmp_path / "0007.txt"
+    path.write_text(text)
+    buf = C.create_string_buffer(512)
+    assert lib.slslam_frame_path(str(tmp_path).encode(), 7, buf, 512) == 0 and buf.value.decode() == str(path)
+    fr = Frame()
+    af, at = (C.c_int * 1)(9), (C.c_int * 1)(2)               # match_lookup: feature 9 is landmark 2
+    assert lib.slslam_read_frame_file(str(path).encode(), C.byref(K), af, at, 1, C.byref(fr)) == 0
+    assert [fr.ids[i] for i in range(fr.num_lines)] == [2, 3, 17]          # std::map order, first duplicate wins
+    want = {2: rows[9], 3: rows[3], 17: rows[17]}
+    for i in range(fr.num_lines):
+        px = np.array(want[fr.ids[i]])
+        c = np.array([327.783, 237.172] * 4)
+        got = np.array([fr.observations[8 * i + q] for q in range(8)])
+        assert np.abs(got - (px / 406.05 - c / 406.05)).max() < 1e-15       # obs / f - c / f (slam.cpp:121-128)
+    lib.slslam_free_frame(C.byref(fr))
+    assert lib.slslam_read_frame_file(b"/nonexistent/0001.txt", C.byref(K), None, None, 0, C.byref(fr)) == 1
+    # ---- metric embedding on a chain 0-1-2-3 with a shortcut 0-3: poses compose along the graph walk
+    rng = np.random.default_rng(5)
+    true = [np.r_[rng.normal(size=3) * 0.1, rng.normal(size=3)] for _ in range(4)]
+    true[0][:] = 0
+    P = (Pose * 4)()
+    for i in range(4):
+        lib.slslam_gc_wt_to_Rt((C.c_double * 6)(*true[i]), C.byref(P[i]))
+    pairs = [(0, 1), (1, 0), (1, 2), (2, 1), (2, 3), (3, 2), (0, 3), (3, 0)]
+    E = (Edge * len(pairs))()
+    for e, (a, b) in enumerate(pairs):
+        E[e].from_, E[e].to = a, b
+        lib.slslam_gc_T_21(C.byref(P[b]), C.byref(P[a]), C.byref(E[e].T))   # T_{b<-a}
+    ids = (C.c_int * 4)(0, 1, 2, 3)
+    nbr_ptr = (C.c_int * 5)(0, 2, 4, 6, 8)
+    nbr = (C.c_int * 8)(1, 3, 0, 2, 1, 3, 0, 2)
+    out = (Pose * 4)()
+    order, dist, n = (C.c_int * 4)(), (C.c_double * 4)(), C.c_int(0)
+    assert lib.slslam_metric_embedding(0, 4, ids, nbr_ptr, nbr, E, len(pairs), out, order, dist, C.byref(n)) == 0
+    assert n.value == 4 and order[0] == 0 and dist[0] == 0.0 and list(dist) == sorted(dist)
+    for i in range(4):
+        wt = np.zeros(6)
+        lib.slslam_gc_Rt_to_wt(C.byref(out[i]), wt.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.abs(wt - true[i]).max() < 1e-12
+    assert lib.slslam_metric_embedding(42, 4, ids, nbr_ptr, nbr, E, len(pairs), out, order, dist, C.byref(n)) == 1
+    # ---- landmark endpoints: a segment given by (point, direction) + end parameters in its keyframe
+    line = np.r_[[0.3, -0.2, 4.0], [0.6, 0.0, 0.8]]
+    ep = np.zeros(6)
+    lib.slslam_landmark_endpoints(line.ctypes.data_as(C.POINTER(C.c_double)), (C.c_double * 2)(-0.5, 1.5), C.byref(P[2]),
+                                  ep.ctypes.data_as(C.POINTER(C.c_double)))
+    v = line[3:] / np.linalg.norm(line[3:])
+    p0 = line[:3] - v * (line[:3] @ v)
+    R2 = np.array(P[2].R).reshape(3, 3); t2 = np.array(P[2].t)
+    for e, s in enumerate((-0.5, 1.5)):
+        assert np.abs(ep[3 * e:3 * e + 3] - R2.T @ (p0 + v * s - t2)).max() < 1e-12
