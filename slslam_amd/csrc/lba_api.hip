@@ -409,7 +409,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     }
     if (!capturing && ((it + 1) % 16) == 0) HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
     if (b->nchunk > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_linearise_schur<false>, g_chunk, blk64, b->lds_lin, s, p, pol));
-    LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve, g_win, blk64, b->lds_solve, s, p, pol));
+    LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve, g_win, blk256, b->lds_solve, s, p, pol));
     if (b->nchunk > 0) {
       if (pol.store_f) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub_stream, g_chunk, blk64, b->lds_bs_stream, s, p, pol));
       else LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub, g_chunk, blk64, b->lds_bs, s, p, pol));

@@ -4,8 +4,9 @@
 //   k_linearise_schur  one 64-lane wave per chunk of a window's lines; lane <-> observation,
 //                      a line owns a 2^g-lane group (segmented xor-shuffle reductions), per-wave
 //                      private partial of the reduced camera system in LDS (ds_add_f64)
-//   k_reduced_solve    one wave per window: ordered reduction of the chunk partials, LM damping,
-//                      in-LDS Cholesky of the (6 Cf)^2 system, candidate camera poses
+//   k_reduced_solve    one workgroup per window: ordered reduction of the chunk partials, LM damping,
+//                      blocked in-LDS Cholesky of the (6 Cf)^2 system on v_mfma_f64_16x16x4_f64,
+//                      candidate camera poses
 //   k_backsub          same sweep as the first kernel, back-substitutes every line, writes the
 //                      candidate line parameters (+ their sin/cos table) and the step statistics and,
 //                      with the observation still in registers, the cost at the candidate point
@@ -466,48 +467,75 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel 2: reduced camera system of one window.  Ordered sum of the chunk partials
-// (bitwise reproducible), S += D_c^2, in-LDS Cholesky, y_c, candidate camera poses.
-// Also performs the gradient-tolerance test Ceres does right after accepting a step.
-__host__ __device__ inline int solve_stride(int n) { return ((n + 30) / 32) * 32 + 1; }  // == 1 (mod 32) doubles
-__host__ __device__ inline int lds_doubles_solve(int n) { return n * solve_stride(n) + 4 * n + 8; }
+// Kernel 2: reduced camera system of one window, one 256-thread workgroup (4 waves).
+//   1. ordered sum of the window's chunk partials (bitwise reproducible; every thread owns entries,
+//      the loads of one entry over the chunks are independent and in flight together)
+//   2. gradient-tolerance test Ceres does right after accepting a step
+//   3. S += D_c^2, blocked right-looking Cholesky in LDS with 16x16 tiles: diagonal tile by rank-1
+//      updates (one element per thread), its triangular inverse, then the panel (L21 = A21 L11^-T) and
+//      the trailing update (A22 -= L21 L21^T) on v_mfma_f64_16x16x4_f64, tiles dealt to the 4 waves —
+//      the one dense contraction of the LBA path (n = 6 Cf = 60: 64 MFMA per factorisation)
+//   4. block forward / backward substitution with the diagonal-tile inverses
+//   5. step statistics of the camera block, candidate camera poses
+__host__ __device__ inline int solve_pad(int n) { return ((n + 15) / 16) * 16; }
+__host__ __device__ inline int solve_stride(int n) { return ((solve_pad(n) + 30) / 32) * 32 + 1; }  // == 1 (mod 32) doubles
+enum { kInvLd = 17 };
+__host__ __device__ inline int lds_doubles_solve(int n) {
+  const int N = solve_pad(n);
+  return N * solve_stride(n) + (N / 16) * 16 * kInvLd + 5 * N + 16;
+}
+typedef double solve_acc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double readlane_f64(double v, int l) {      // l wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 
-__global__ __launch_bounds__(64) void k_reduced_solve(BatchPtrs p, Policy pol) {
+__global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = blockIdx.x;
   const WinDesc wd = p.wins[w];
   LMState* st = p.state + w;
   if (st->status != kRunning) return;
-  const int n = wd.n, ncf = n / 6, nsys = sys_doubles(n), ld = solve_stride(n);
-  double* A = smem;               // n x ld, lower triangle used
-  double* bvec = A + n * ld;      // b | g | hdiag | y, contiguous
-  double* gvec = bvec + n;
-  double* hvec = gvec + n;
-  double* yvec = hvec + n;
+  const int n = wd.n, ncf = n / 6, nsys = sys_doubles(n), N = solve_pad(n), nt = N / 16, ld = solve_stride(n);
+  double* A = smem;                       // N x ld, lower triangle used
+  double* Linv = A + N * ld;              // nt diagonal-tile inverses, 16 x kInvLd each
+  double* bvec = Linv + nt * 16 * kInvLd; // b | g | hdiag | y | tmp, N each
+  double* gvec = bvec + N;
+  double* hvec = gvec + N;
+  double* yvec = hvec + N;
+  double* tvec = yvec + N;
+  double* red = tvec + N;                 // 16 scratch doubles
   const int cur = st->cur;
   const double radius = st->radius;
   const int need_grad_check = st->need_grad_check;
   const double abs_grad_tol = st->abs_grad_tol;
 
-  // ordered (bitwise reproducible) reduction over the window's chunk partials; the slabs of one
-  // window are consecutive with a uniform stride, so the loads of the chunk loop are independent
+  for (int q = tid; q < N * ld; q += 256) A[q] = 0.0;
+  for (int q = tid; q < 5 * N; q += 256) bvec[q] = 0.0;
+  __syncthreads();
+  // ---- 1. ordered reduction over the window's chunk partials (uniform stride between consecutive slabs)
   const long long slab0 = p.chunks[wd.chunk_off].slab_off;
   const long long sstride = (long long)nsys + kSlabScalars;
-  for (int q = lane; q < nsys; q += 64) {
+#pragma unroll 2
+  for (int q = tid; q < nsys; q += 256) {
     const double* src = p.slab + slab0 + q;
     double s = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < wd.nchunks; ++k) s += src[k * sstride];
-    // where the entry lives in the dense lower triangle / the right-hand sides
+    for (int k0 = 0; k0 < wd.nchunks; k0 += 8) {           // 8 independent loads in flight, summed in chunk order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (k0 + u < wd.nchunks) ? src[(k0 + u) * sstride] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
     if (q < ncf * kCamAcc) {
       const int cf = q / kCamAcc, e = q - cf * kCamAcc;
       if (e < kRecB) {
-        int a = e >= 15 ? 5 : e >= 10 ? 4 : e >= 6 ? 3 : e >= 3 ? 2 : e >= 1 ? 1 : 0;
+        const int a = e >= 15 ? 5 : e >= 10 ? 4 : e >= 6 ? 3 : e >= 3 ? 2 : e >= 1 ? 1 : 0;
         A[(6 * cf + a) * ld + 6 * cf + (e - tri_index(a, 0))] = s;
       } else {
         const int v = (e - kRecB) / 6, a = (e - kRecB) - 6 * v;      // 0 = b, 1 = g, 2 = hdiag
-        bvec[v * n + 6 * cf + a] = s;
+        bvec[v * N + 6 * cf + a] = s;
       }
     } else {
       const int pq = q - ncf * kCamAcc, pr = pq / kPairAcc, e = pq - pr * kPairAcc;
@@ -529,80 +557,161 @@ __global__ __launch_bounds__(64) void k_reduced_solve(BatchPtrs p, Policy pol) {
   }
   __syncthreads();
 
-  // gradient max-norm at the accepted point: gvec holds the SCALED gradient J'^T r, the true
+  // ---- 2. gradient max-norm at the accepted point: gvec holds the SCALED gradient J'^T r, the true
   // gradient is g / scale.  Ceres tests it right after accepting a step.
   if (need_grad_check) {
-    double gm = 0.0;
-    for (int c = lane; c < wd.C; c += 64) {
-      const int cf = p.cam_cf[wd.cam_off + c];
-      if (cf < 0) continue;
-      for (int a = 0; a < 6; ++a)
-        gm = fmax(gm, fabs(gvec[6 * cf + a] / p.cam_scale[(long long)(wd.cam_off + c) * 6 + a]));
-    }
-    gm = fmax(wave_max(gm), gmax_line);
-    if (lane == 0) {
-      st->grad_max = gm;
-      st->need_grad_check = 0;
-      if (st->ntrace > 0 && st->ntrace <= kMaxTrace)
-        p.trace[(long long)w * kMaxTrace + st->ntrace - 1].gradient_max_norm = gm;
-      if (gm <= abs_grad_tol) st->status = 1 /* SLSLAM_GRADIENT_TOLERANCE */;
-    }
-    if (gm <= abs_grad_tol) return;
-  }
-
-  // LM damping of the camera columns: D^2 = clamp(diag(J'^T J')) / radius
-  for (int q = lane; q < n; q += 64) {
-    const double d2 = fmin(fmax(hvec[q], pol.min_lm_diagonal), pol.max_lm_diagonal) / radius;
-    hvec[q] = d2;
-    A[q * ld + q] += d2;
-    yvec[q] = bvec[q];
-  }
-  __syncthreads();
-
-  // left-looking Cholesky in LDS, lane <-> row (two rows per lane when n > 64)
-  for (int jc = 0; jc < n; ++jc) {
-    double s[2] = { 0.0, 0.0 };
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = lane + 64 * h;
-      if (r >= jc && r < n) {
-        double v = A[r * ld + jc];
-        for (int k = 0; k < jc; ++k) v -= A[r * ld + k] * A[jc * ld + k];
-        s[h] = v;
+    if (wave == 0) {
+      double gm = 0.0;
+      for (int c = lane; c < wd.C; c += 64) {
+        const int cf = p.cam_cf[wd.cam_off + c];
+        if (cf < 0) continue;
+        for (int a = 0; a < 6; ++a)
+          gm = fmax(gm, fabs(gvec[6 * cf + a] / p.cam_scale[(long long)(wd.cam_off + c) * 6 + a]));
+      }
+      gm = fmax(wave_max(gm), gmax_line);
+      if (lane == 0) {
+        red[0] = gm;
+        st->grad_max = gm;
+        st->need_grad_check = 0;
+        if (st->ntrace > 0 && st->ntrace <= kMaxTrace)
+          p.trace[(long long)w * kMaxTrace + st->ntrace - 1].gradient_max_norm = gm;
+        if (gm <= abs_grad_tol) st->status = 1 /* SLSLAM_GRADIENT_TOLERANCE */;
       }
     }
     __syncthreads();
+    if (red[0] <= abs_grad_tol) return;
+  }
+
+  // ---- 3. LM damping of the camera columns: D^2 = clamp(diag(J'^T J')) / radius; identity on the padding
+  for (int q = tid; q < N; q += 256) {
+    if (q < n) {
+      const double d2 = fmin(fmax(hvec[q], pol.min_lm_diagonal), pol.max_lm_diagonal) / radius;
+      hvec[q] = d2;
+      A[q * ld + q] += d2;
+    } else {
+      A[q * ld + q] = 1.0;
+    }
+  }
+  __syncthreads();
+
+  const int er = tid >> 4, ec = tid & 15;       // this thread's element of a 16x16 tile
+  for (int kb = 0; kb < nt; ++kb) {
+    double* D = A + (16 * kb) * ld + 16 * kb;   // diagonal tile
+    // (a)+(b) diagonal tile in the registers of wave 0, lane <-> COLUMN of the symmetric tile (so that
+    // the multiplier l_c of a lane's own column is lane-local, and only the pivot column has to be
+    // broadcast: v_readlane from lane jc, at most 16 live scalars).  Right-looking Cholesky; the same
+    // row operations applied to the identity give L^-1 in the same sweep.  No LDS traffic, no barriers.
+    if (wave == 0) {
+      double a[16], e[16];
+      const int c = lane & 15;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      if (lane + 64 * h == jc) A[jc * ld + jc] = (s[h] > 0.0 && isfinite(s[h])) ? sqrt(s[h]) : -1.0;
-    __syncthreads();
-    double d = A[jc * ld + jc];
-    if (!(d > 0.0)) { fail = 1; d = 1.0; }
+      for (int r = 0; r < 16; ++r) { a[r] = (r >= c) ? D[r * ld + c] : D[c * ld + r]; e[r] = (r == c) ? 1.0 : 0.0; }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = lane + 64 * h;
-      if (r > jc && r < n) A[r * ld + jc] = s[h] / d;
+      for (int jc = 0; jc < 16; ++jc) {
+        const double piv = readlane_f64(a[jc], jc);
+        const bool okp = piv > 0.0 && isfinite(piv);
+        if (!okp) fail = 1;
+        const double ip = okp ? inv_sqrt<double>(piv) : 1.0;       // v_rsq_f64 + refinement: no sqrt, no divide on the chain
+        const double lcown = a[jc] * ip;                           // L[c][jc], this lane's multiplier (c > jc)
+        if (c == jc) {                                             // the pivot column becomes column jc of L
+          a[jc] = okp ? piv * ip : 1.0;
+#pragma unroll
+          for (int r = jc + 1; r < 16; ++r) a[r] *= ip;
+        }
+        const double ej = e[jc] * ip;                              // row jc of the inverse so far, scaled
+        e[jc] = ej;
+#pragma unroll
+        for (int r = jc + 1; r < 16; ++r) {
+          const double lr = readlane_f64(a[r], jc);                // L[r][jc]
+          if (c > jc) a[r] -= lr * lcown;
+          e[r] -= lr * ej;
+        }
+      }
+      if (lane < 16) {
+        double* Lw = Linv + kb * 16 * kInvLd;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (r >= c) D[r * ld + c] = a[r];
+          Lw[r * kInvLd + c] = (r >= c) ? e[r] : 0.0;
+        }
+      }
     }
     __syncthreads();
-    if (!(A[jc * ld + jc] > 0.0)) { __syncthreads(); if (lane == 0) A[jc * ld + jc] = 1.0; __syncthreads(); }
-  }
-  // forward then backward substitution: serial in the pivot, lane-parallel over rows
-  for (int jc = 0; jc < n; ++jc) {
-    const double yj = yvec[jc] / A[jc * ld + jc];
+    const double* Li = Linv + kb * 16 * kInvLd;
+    // (c) panel: L(i,kb) = A(i,kb) Linv^T, one tile per wave at a time
+    for (int i = kb + 1 + wave; i < nt; i += 4) {
+      double* T = A + (16 * i) * ld + 16 * kb;
+      solve_acc_t acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const double a = T[(lane & 15) * ld + 4 * s4 + (lane >> 4)];          // A[m][k]
+        const double b = Li[(lane & 15) * kInvLd + 4 * s4 + (lane >> 4)];     // B[k][n] = Linv[n][k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) T[((lane >> 4) + 4 * q) * ld + (lane & 15)] = acc[q];
+    }
     __syncthreads();
-    if (lane == 0) yvec[jc] = yj;
-    for (int r = jc + 1 + lane; r < n; r += 64) yvec[r] -= A[r * ld + jc] * yj;
-    __syncthreads();
-  }
-  for (int jc = n - 1; jc >= 0; --jc) {
-    const double yj = yvec[jc] / A[jc * ld + jc];
-    __syncthreads();
-    if (lane == 0) yvec[jc] = yj;
-    for (int r = lane; r < jc; r += 64) yvec[r] -= A[jc * ld + r] * yj;
+    // (d) trailing update: A(i,j) -= L(i,kb) L(j,kb)^T for kb < j <= i, tiles dealt round-robin to the waves
+    int tile = 0;
+    for (int i = kb + 1; i < nt; ++i)
+      for (int jt = kb + 1; jt <= i; ++jt, ++tile) {
+        if ((tile & 3) != wave) continue;
+        double* C = A + (16 * i) * ld + 16 * jt;
+        const double* Pi = A + (16 * i) * ld + 16 * kb;
+        const double* Pj = A + (16 * jt) * ld + 16 * kb;
+        solve_acc_t acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = C[((lane >> 4) + 4 * q) * ld + (lane & 15)];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const double a = -Pi[(lane & 15) * ld + 4 * s4 + (lane >> 4)];
+          const double b = Pj[(lane & 15) * ld + 4 * s4 + (lane >> 4)];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[((lane >> 4) + 4 * q) * ld + (lane & 15)] = acc[q];
+      }
     __syncthreads();
   }
 
-  // step statistics of the camera block and candidate camera poses
+  // ---- 4. block substitution.  forward: y_k = Linv_k (b_k - sum_{c < 16k} L[k,c] y_c)
+  for (int kb = 0; kb < nt; ++kb) {
+    {
+      double sacc = 0.0;
+      for (int c = ec; c < 16 * kb; c += 16) sacc += A[(16 * kb + er) * ld + c] * yvec[c];
+      sacc += dpp_move<0xB1>(sacc); sacc += dpp_move<0x4E>(sacc); sacc += dpp_move<0x141>(sacc); sacc += dpp_move<0x140>(sacc);
+      if (ec == 0) tvec[er] = bvec[16 * kb + er] - sacc;
+    }
+    __syncthreads();
+    if (tid < 16) {
+      const double* Li = Linv + kb * 16 * kInvLd;
+      double sacc = 0.0;
+      for (int k = 0; k <= tid; ++k) sacc += Li[tid * kInvLd + k] * tvec[k];
+      yvec[16 * kb + tid] = sacc;
+    }
+    __syncthreads();
+  }
+  // backward: x_k = Linv_k^T (y_k - sum_{r >= 16(k+1)} L[r,k]^T x_r), in place in yvec
+  for (int kb = nt - 1; kb >= 0; --kb) {
+    {
+      double sacc = 0.0;                                   // thread (er = column within tile, ec = row part)
+      for (int r = 16 * (kb + 1) + ec; r < N; r += 16) sacc += A[r * ld + 16 * kb + er] * yvec[r];
+      sacc += dpp_move<0xB1>(sacc); sacc += dpp_move<0x4E>(sacc); sacc += dpp_move<0x141>(sacc); sacc += dpp_move<0x140>(sacc);
+      if (ec == 0) tvec[er] = yvec[16 * kb + er] - sacc;
+    }
+    __syncthreads();
+    if (tid < 16) {
+      const double* Li = Linv + kb * 16 * kInvLd;
+      double sacc = 0.0;
+      for (int k = tid; k < 16; ++k) sacc += Li[k * kInvLd + tid] * tvec[k];
+      yvec[16 * kb + tid] = sacc;
+    }
+    __syncthreads();
+  }
+
+  // ---- 5. step statistics of the camera block and candidate camera poses (wave 0)
+  if (wave != 0) return;
   double model = 0.0, dn2 = 0.0, xn2 = 0.0;
   int bad = 0;
   for (int q = lane; q < n; q += 64) {
