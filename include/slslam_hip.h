@@ -70,7 +70,11 @@ typedef struct slslam_solver_options {
                                            algorithmic); 1: it streams Jacobian blocks the elimination
                                            spilled to HBM (+192 B per coupled observation)         */
   int    po_factor_fp32;                /* pose graph only: 1 = factor the normal matrix in fp32 (MFMA f32);
-                                           residuals, gradient, costs and LM bookkeeping stay fp64    */
+                                           residuals, gradient, costs and LM bookkeeping stay fp64
+                                           (implies po_dense_factor)                                    */
+  int    po_dense_factor;               /* pose graph only: 0 (default) = structured factorisation: chains of poses
+                                           eliminated concurrently (block tridiagonal), dense MFMA Cholesky of the
+                                           junction poses only; 1 = dense MFMA Cholesky of the whole normal matrix   */
 } slslam_solver_options;
 
 /* Fills every field with the configuration the reference runs (robust loss on, 10 iterations). */

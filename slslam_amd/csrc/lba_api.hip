@@ -45,6 +45,7 @@ extern "C" void slslam_default_options(slslam_solver_options* o) {
   o->chunks_per_window = 0;
   o->reuse_elimination = 0;
   o->po_factor_fp32 = 0;
+  o->po_dense_factor = 0;
 }
 
 extern "C" int slslam_device_count(void) {

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../include/slslam_hip.h"
@@ -22,6 +23,100 @@ using namespace slslam;
       goto done;                                                                        \
     }                                                                                   \
   } while (0)
+
+
+namespace {
+
+enum { kMaxChain = 16 };
+
+// Symbolic analysis of the structured factorisation: junction = free pose with >= 3 distinct free
+// neighbours (plus one pose per junction-free cycle); every other free pose lies on a chain.
+// Output: slot[] (offset of each pose in the reduced vector: chains first, pose by pose along the
+// path; junctions last), the chain descriptors, n_chain = unknowns before the junction block.
+void order_chains_first(int N, int E, const int* p1, const int* p2, const std::vector<int>& used, int gauge,
+                        std::vector<int>& slot, std::vector<PoChain>& chains, int* n_chain, int* n_total) {
+  std::vector<std::vector<int>> adj(N);
+  auto add = [&](int a, int b) { for (int v : adj[a]) if (v == b) return; adj[a].push_back(b); };
+  for (int e = 0; e < E; ++e) {
+    const int a = p1[e], b = p2[e];
+    if (a == gauge || b == gauge) continue;           // the constant pose only contributes to diagonals
+    add(a, b); add(b, a);
+  }
+  std::vector<char> isfree(N, 0), junction(N, 0), done(N, 0);
+  for (int k = 0; k < N; ++k) isfree[k] = used[k] && k != gauge;
+  for (int k = 0; k < N; ++k) if (isfree[k] && adj[k].size() >= 3) junction[k] = 1;
+  std::vector<std::vector<int>> paths;
+  auto walk = [&](int start) {                        // start: a chain pose with at most one chain neighbour
+    std::vector<int> path;
+    int prev = -1, cur = start;
+    while (cur >= 0) {
+      path.push_back(cur); done[cur] = 1;
+      int nxt = -1;
+      for (int v : adj[cur]) if (v != prev && !junction[v] && !done[v]) { nxt = v; break; }
+      prev = cur; cur = nxt;
+    }
+    paths.push_back(path);
+  };
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int k = 0; k < N; ++k) {
+      if (!isfree[k] || junction[k] || done[k]) continue;
+      int chain_nb = 0;
+      for (int v : adj[k]) if (!junction[v] && !done[v]) ++chain_nb;
+      if (chain_nb <= 1) walk(k);
+    }
+    if (pass == 0)                                    // what is left are junction-free cycles: open each at one pose
+      for (int k = 0; k < N; ++k)
+        if (isfree[k] && !junction[k] && !done[k]) {
+          bool alone = true;                          // still untouched after this loop's earlier promotions?
+          for (int v : adj[k]) if (junction[v]) alone = false;
+          if (alone) { junction[k] = 1; }
+        }
+  }
+  // a chain whose two ends meet the same junction: move its last pose to the junctions
+  for (auto& path : paths) {
+    if (path.size() < 2) continue;
+    int jl = -1, jr = -1;
+    for (int v : adj[path.front()]) if (junction[v]) jl = v;
+    for (int v : adj[path.back()]) if (junction[v]) jr = v;
+    if (jl >= 0 && jl == jr) { junction[path.back()] = 1; path.pop_back(); }
+  }
+  // a chain is sequential: cut long ones into pieces of at most kMaxChain poses, the cut poses join the junctions
+  {
+    std::vector<std::vector<int>> pieces;
+    for (auto& path : paths) {
+      size_t b = 0;
+      while (path.size() - b > (size_t)kMaxChain) {
+        pieces.emplace_back(path.begin() + b, path.begin() + b + kMaxChain);
+        junction[path[b + kMaxChain]] = 1;
+        b += kMaxChain + 1;
+      }
+      if (b < path.size()) pieces.emplace_back(path.begin() + b, path.end());
+    }
+    paths.swap(pieces);
+  }
+  int n = 0;
+  for (auto& path : paths) {
+    PoChain c;
+    c.start = n; c.len = (int)path.size(); c.jl = -1; c.jr = -1;
+    for (int v : path) { slot[v] = n; n += 6; }
+    chains.push_back(c);
+  }
+  *n_chain = n;
+  for (int k = 0; k < N; ++k) if (isfree[k] && junction[k]) { slot[k] = n; n += 6; }
+  *n_total = n;
+  for (size_t q = 0; q < paths.size(); ++q) {
+    const auto& path = paths[q];
+    PoChain& c = chains[q];
+    if (path.size() == 1) {
+      for (int v : adj[path[0]]) if (junction[v]) { if (c.jl < 0) c.jl = slot[v]; else c.jr = slot[v]; }
+    } else {
+      for (int v : adj[path.front()]) if (junction[v]) c.jl = slot[v];
+      for (int v : adj[path.back()]) if (junction[v]) c.jr = slot[v];
+    }
+  }
+}
+
+}  // namespace
 
 extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_options* opt_in,
                                slslam_summary* summary, slslam_iteration* trace, int trace_cap, int* trace_len) {
@@ -50,7 +145,15 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   for (int e = 0; e < E; ++e) { used[g->pose_index_1[e]] = 1; used[g->pose_index_2[e]] = 1; }
   const int gauge = g->pose_index_1[0];
   int n = 0, kept = 0;
-  for (int k = 0; k < N; ++k) if (used[k] && k != gauge) { slot[k] = n; n += 6; }
+  const bool f32 = opt.po_factor_fp32 != 0;
+  const bool structured = !f32 && !opt.po_dense_factor;
+  std::vector<PoChain> chains;
+  int n_chain = 0;                       // unknowns of the chain poses (ordered first)
+  if (!structured) {
+    for (int k = 0; k < N; ++k) if (used[k] && k != gauge) { slot[k] = n; n += 6; }
+  } else {
+    order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, gauge, slot, chains, &n_chain, &n);
+  }
   for (int e = 0; e < E; ++e) if (slot[g->pose_index_1[e]] >= 0 || slot[g->pose_index_2[e]] >= 0) ++kept;
   const int ld = ((n + 7) / 8) * 8 + 8;
 
@@ -64,12 +167,14 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   pol.max_invalid = opt.max_num_consecutive_invalid_steps; pol.jacobi_scaling = opt.jacobi_scaling; pol.pad = 0;
 
   int rc = SLSLAM_OK;
-  PoPtrs p;
+  PoPtrs p, pj;
   std::memset(&p, 0, sizeof(p));
+  PoChain* d_chains = nullptr;
+  const int nj = structured ? n - n_chain : 0;
+  const int nblk_j = (nj + kNB - 1) / kNB;
   int *d_p1 = nullptr, *d_p2 = nullptr, *d_slot = nullptr;
   double *d_cons = nullptr, *d_linv = nullptr;
   float *d_Hf = nullptr, *d_linvf = nullptr;
-  const bool f32 = opt.po_factor_fp32 != 0;
   LMState hst;
   std::vector<IterRec> htrace(kMaxTrace);
   std::vector<double> x2((size_t)12 * N), ones((size_t)(n > 0 ? n : 1), 1.0);
@@ -112,6 +217,12 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   PO_TRY(hipMemset(p.flags, 0, sizeof(int) * 2));
   p.p1 = d_p1; p.p2 = d_p2; p.cons = d_cons; p.slot = d_slot;
   p.N = N; p.E = E; p.n = n; p.ld = ld;
+  pj = p;                                  // the junction block as a matrix of its own (same leading dimension)
+  pj.n = nj; pj.H = p.H + (size_t)n_chain * ld + n_chain; pj.y = p.y + n_chain;
+  if (!chains.empty()) {
+    PO_TRY(hipMalloc((void**)&d_chains, sizeof(PoChain) * chains.size()));
+    PO_TRY(hipMemcpy(d_chains, chains.data(), sizeof(PoChain) * chains.size(), hipMemcpyHostToDevice));
+  }
 
   // ---- initial evaluation: cost, gradient, column norms -> Jacobi scale
   PO_TRY(hipMemsetAsync(p.H, 0, hbytes, 0));
@@ -131,7 +242,23 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 0);
     hipLaunchKernelGGL(k_po_prepare, dim3(1), dim3(256), 0, 0, p, pol, 0);
     if (f32) hipLaunchKernelGGL(k_po_to_f32, dim3(256), dim3(256), 0, 0, p, d_Hf);
-    for (int bk = 0; bk < nblk; ++bk) {
+    if (structured) {
+      // chains eliminated concurrently, then the dense MFMA Cholesky of the junction block only
+      if (!chains.empty()) hipLaunchKernelGGL(k_po_chain_eliminate, dim3((unsigned)chains.size()), dim3(64), 0, 0, p, (const PoChain*)d_chains);
+      for (int bk = 0; bk < nblk_j; ++bk) {
+        const int k0 = bk * kNB;
+        const int rem = nj - (k0 + kNB);
+        const int tb = rem > 0 ? (rem + kNB - 1) / kNB : 0;
+        hipLaunchKernelGGL(k_po_potrf_diag<double>, dim3(1), dim3(256), 0, 0, pj, pj.H, d_linv + (size_t)bk * kNB * kNB, k0);
+        if (tb > 0) {
+          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)tb), dim3(256), 0, 0, pj, pj.H, (const double*)(d_linv + (size_t)bk * kNB * kNB), k0, 0);
+          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, pj, pj.H, (const double*)(d_linv + (size_t)bk * kNB * kNB), k0, 1);
+        }
+      }
+      if (nj > 0) hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(256), 0, 0, pj, (const double*)pj.H, (const double*)d_linv);
+      if (!chains.empty()) hipLaunchKernelGGL(k_po_chain_backsub, dim3((unsigned)chains.size()), dim3(64), 0, 0, p, (const PoChain*)d_chains);
+    }
+    for (int bk = 0; bk < (structured ? 0 : nblk); ++bk) {
       const int k0 = bk * kNB;
       const int rem = n - (k0 + kNB);
       const int tb = rem > 0 ? (rem + kNB - 1) / kNB : 0;
@@ -149,7 +276,8 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
         }
       }
     }
-    if (f32) hipLaunchKernelGGL(k_po_trisolve<float>, dim3(1), dim3(256), 0, 0, p, (const float*)d_Hf, (const float*)d_linvf);
+    if (structured) { /* solved above */ }
+    else if (f32) hipLaunchKernelGGL(k_po_trisolve<float>, dim3(1), dim3(256), 0, 0, p, (const float*)d_Hf, (const float*)d_linvf);
     else hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(256), 0, 0, p, (const double*)p.H, (const double*)d_linv);
     hipLaunchKernelGGL(k_po_candidate, dim3(1), dim3(256), 0, 0, p);
     hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 1);
@@ -184,6 +312,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     }
   }
 done:
+  (void)hipFree(d_chains);
   (void)hipFree(d_p1); (void)hipFree(d_p2); (void)hipFree(d_slot); (void)hipFree(d_cons);
   (void)hipFree(p.x); (void)hipFree(p.scale); (void)hipFree(p.H); (void)hipFree(p.g); (void)hipFree(p.d2);
   (void)hipFree(p.y); (void)hipFree(d_linv); (void)hipFree(d_Hf); (void)hipFree(d_linvf); (void)hipFree(p.scal); (void)hipFree(p.flags);

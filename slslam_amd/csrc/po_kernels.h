@@ -467,6 +467,220 @@ __global__ __launch_bounds__(256) void k_po_trisolve(PoPtrs p, const T* A, const
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Structured factorisation (default): a pose graph is chains of odometry edges tied together by a few
+// loop closures.  The host orders the unknowns chains first (each chain's poses consecutive, in path
+// order), junction poses (degree >= 3) last; then
+//   k_po_chain_eliminate   one wave per chain: block-tridiagonal elimination along the chain with the
+//                          fill towards the chain's (at most two) junctions carried along; the Schur
+//                          complement contributions go to the junction block of the same dense matrix
+//   dense blocked Cholesky (the MFMA kernels above) of the junction block only (6 * #junctions unknowns)
+//   k_po_chain_backsub     one wave per chain: back-substitution from the junction solution
+// In place on the dense lower-triangular storage (room for the fill), so linearisation, damping and
+// the LM bookkeeping are unchanged.  Chains are independent: a 260-pose graph with 8 loop closures is
+// ~17 chains of ~15 poses eliminated concurrently + one ~100 x 100 dense system, instead of 25
+// dependent 64-wide block steps over a 1554 x 1554 matrix.
+struct PoChain { int start, len, jl, jr; };   // offsets in the reduced vector; jl / jr = -1 when the end is free
+
+__device__ __forceinline__ bool chol6_and_inverse(const double* Ds /* LDS, 6x6 symmetric */, double L[21], double Li[21]) {
+  // packing: (r, c) -> r (r + 1) / 2 + c, c <= r.  1/sqrt by v_rsq_f64 + refinement: no divide on the chain.
+  bool ok = true;
+  double invd[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      double sacc = Ds[6 * r + c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) sacc -= L[(r * (r + 1)) / 2 + k] * L[(c * (c + 1)) / 2 + k];
+      if (c == r) {
+        if (!(sacc > 0.0) || !isfinite(sacc)) { ok = false; sacc = 1.0; }
+        invd[r] = rsqrt(sacc);
+        L[(r * (r + 1)) / 2 + r] = sacc * invd[r];
+      } else {
+        L[(r * (r + 1)) / 2 + c] = sacc * invd[c];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {          // column c of the inverse
+#pragma unroll
+    for (int r = c; r < 6; ++r) {
+      double sacc = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = c; k < r; ++k) sacc -= L[(r * (r + 1)) / 2 + k] * Li[(k * (k + 1)) / 2 + c];
+      Li[(r * (r + 1)) / 2 + c] = sacc * invd[r];
+    }
+  }
+  return ok;
+}
+
+__global__ __launch_bounds__(64) void k_po_chain_eliminate(PoPtrs p, const PoChain* chains) {
+  if (p.st->status != kRunning) return;
+  __shared__ double Ds[36], Bs[36], Cs[36], Rs[36], Lis[36], Bt[36], Ct[36], Rt[36], gs[6], gt[6];
+  const PoChain ch = chains[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int r = lane / 6, c = lane - 6 * r;
+  const bool el = lane < 36;
+  const long long ld = p.ld;
+  double* H = p.H;
+  double accLL = 0.0, accRR = 0.0, accRL = 0.0, accgL = 0.0, accgR = 0.0;
+  // state of the node being eliminated: D (symmetric), C (coupling to the left junction), B / R (coupling to
+  // the next chain node / the right junction), g.  Everything the NEXT node needs from memory is requested
+  // at the top of a step and consumed at its end.
+  double dcur = 0.0, ccur = 0.0, gcur = 0.0, bcur = 0.0, rcur = 0.0;
+  if (el) {
+    const int s0 = ch.start;
+    dcur = H[(s0 + max(r, c)) * ld + s0 + min(r, c)];
+    ccur = ch.jl >= 0 ? H[(ch.jl + r) * ld + s0 + c] : 0.0;
+    if (ch.len > 1) bcur = H[(s0 + 6 + r) * ld + s0 + c];
+    else if (ch.jr >= 0) rcur = H[(ch.jr + r) * ld + s0 + c];
+  }
+  if (lane < 6) gcur = p.y[ch.start + lane];
+  int fail = 0;
+  for (int i = 0; i < ch.len; ++i) {
+    const int si = ch.start + 6 * i, sn = si + 6;
+    const bool last = i == ch.len - 1, next_last = i == ch.len - 2;
+    double dnext = 0.0, gnext = 0.0, bnext = 0.0, rnext = 0.0;
+    if (el && !last) {
+      dnext = H[(sn + max(r, c)) * ld + sn + min(r, c)];
+      if (!next_last) bnext = H[(sn + 6 + r) * ld + sn + c];
+      else if (ch.jr >= 0) rnext = H[(ch.jr + r) * ld + sn + c];
+    }
+    if (lane < 6 && !last) gnext = p.y[sn + lane];
+    if (el) { Ds[lane] = dcur; Bs[lane] = bcur; Cs[lane] = ccur; Rs[lane] = rcur; }
+    if (lane < 6) gs[lane] = gcur;
+    __syncthreads();
+    double L[21], Li[21];
+    if (!chol6_and_inverse(Ds, L, Li)) fail = 1;       // every lane, redundantly: no cross-lane traffic
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Lis[6 * a + q] = q <= a ? Li[(a * (a + 1)) / 2 + q] : 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int q = 0; q <= a; ++q) H[(si + a) * ld + si + q] = L[(a * (a + 1)) / 2 + q];   // keep the factor
+    }
+    __syncthreads();
+    // X~ = X L^-T :  X~[r][c] = sum_k X[r][k] Linv[c][k]
+    if (el) {
+      double bt = 0.0, ct = 0.0, rt = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const double li = Lis[6 * c + k]; bt += Bs[6 * r + k] * li; ct += Cs[6 * r + k] * li; rt += Rs[6 * r + k] * li; }
+      Bt[lane] = bt; Ct[lane] = ct; Rt[lane] = rt;
+      if (!last) H[(sn + r) * ld + si + c] = bt;
+      else if (ch.jr >= 0) H[(ch.jr + r) * ld + si + c] = rt;
+      if (ch.jl >= 0) H[(ch.jl + r) * ld + si + c] = ct;
+    }
+    if (lane < 6) {
+      double gg = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gg += Lis[6 * lane + k] * gs[k];
+      gt[lane] = gg;
+      p.y[si + lane] = gg;
+    }
+    __syncthreads();
+    if (el) {
+      double dd = 0.0, cc = 0.0, ll = 0.0, r2 = 0.0, rl = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        dd += Bt[6 * r + k] * Bt[6 * c + k];
+        cc += Ct[6 * r + k] * Bt[6 * c + k];
+        ll += Ct[6 * r + k] * Ct[6 * c + k];
+        r2 += Rt[6 * r + k] * Rt[6 * c + k];
+        rl += Rt[6 * r + k] * Ct[6 * c + k];
+      }
+      dcur = dnext - dd;         // D_{i+1} - B~ B~^T
+      ccur = -cc;                // fill: H(jl, v_{i+1}) = - C~ B~^T  (an interior chain node has no edge to a junction)
+      bcur = bnext; rcur = rnext;
+      accLL += ll; accRR += r2; accRL += rl;
+    }
+    if (lane < 6) {
+      double gb = 0.0, gl = 0.0, gr = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { gb += Bt[6 * lane + k] * gt[k]; gl += Ct[6 * lane + k] * gt[k]; gr += Rt[6 * lane + k] * gt[k]; }
+      gcur = gnext - gb;
+      accgL += gl; accgR += gr;
+    }
+    __syncthreads();
+  }
+  // Schur complement contributions of this chain to the junction system (several chains meet at a junction: atomics)
+  if (el) {
+    if (ch.jl >= 0 && r >= c) atomicAdd(&H[(ch.jl + r) * ld + ch.jl + c], -accLL);
+    if (ch.jr >= 0 && r >= c) atomicAdd(&H[(ch.jr + r) * ld + ch.jr + c], -accRR);
+    if (ch.jl >= 0 && ch.jr >= 0) {
+      if (ch.jr > ch.jl) atomicAdd(&H[(ch.jr + r) * ld + ch.jl + c], -accRL);
+      else atomicAdd(&H[(ch.jl + c) * ld + ch.jr + r], -accRL);
+    }
+  }
+  if (lane < 6) {
+    if (ch.jl >= 0) atomicAdd(&p.y[ch.jl + lane], -accgL);
+    if (ch.jr >= 0) atomicAdd(&p.y[ch.jr + lane], -accgR);
+  }
+  if (__any(fail) && lane == 0) p.flags[0] = 1;
+}
+
+// y_i = L_i^-T ( g~_i - B~_i^T y_{i+1} - C~_i^T y_jl - [last] R~^T y_jr ), from the end of the chain to its start.
+// The three 6x6 blocks of the next step are requested while the current one is solved.
+__global__ __launch_bounds__(64) void k_po_chain_backsub(PoPtrs p, const PoChain* chains) {
+  if (p.st->status != kRunning) return;
+  __shared__ double Ls[36], Xs[36], Cs[36], gsh[6], rhs[6], ysol[6], ylr[12], idiag[6];
+  const PoChain ch = chains[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int r = lane / 6, c = lane - 6 * r;
+  const bool el = lane < 36;
+  const long long ld = p.ld;
+  const double* H = p.H;
+  if (lane < 6) { ylr[lane] = ch.jl >= 0 ? p.y[ch.jl + lane] : 0.0; ylr[6 + lane] = ch.jr >= 0 ? p.y[ch.jr + lane] : 0.0; ysol[lane] = 0.0; }
+  auto load = [&](int i, double& l, double& x, double& cc, double& g) {
+    const int si = ch.start + 6 * i, sn = si + 6;
+    const bool last = i == ch.len - 1;
+    l = x = cc = g = 0.0;
+    if (el) {
+      l = r >= c ? H[(si + r) * ld + si + c] : 0.0;
+      if (!last) x = H[(sn + r) * ld + si + c];                 // B~[r][c]
+      else if (ch.jr >= 0) x = H[(ch.jr + r) * ld + si + c];    // R~[r][c]
+      if (ch.jl >= 0) cc = H[(ch.jl + r) * ld + si + c];        // C~[r][c]
+    }
+    if (lane < 6) g = p.y[si + lane];
+  };
+  double l, x, cc, g;
+  load(ch.len - 1, l, x, cc, g);
+  for (int i = ch.len - 1; i >= 0; --i) {
+    const int si = ch.start + 6 * i;
+    const bool last = i == ch.len - 1;
+    if (el) { Ls[lane] = l; Xs[lane] = x; Cs[lane] = cc; }
+    if (lane < 6) gsh[lane] = g;
+    if (i > 0) load(i - 1, l, x, cc, g);                        // in flight during this step
+    __syncthreads();
+    if (lane < 6) {
+      // rhs[a] = g~[a] - sum_k ( X[k][a] yv[k] + C~[k][a] yl[k] ),  yv = y_{i+1} or y_jr
+      double sacc = gsh[lane];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sacc -= Xs[6 * k + lane] * (last ? ylr[6 + k] : ysol[k]) + Cs[6 * k + lane] * ylr[k];
+      rhs[lane] = sacc;
+      idiag[lane] = 1.0 / Ls[7 * lane];
+    }
+    __syncthreads();
+    if (lane == 0) {                              // L^T y = rhs, 6 unknowns
+      double y[6];
+#pragma unroll
+      for (int a = 5; a >= 0; --a) {
+        double t = rhs[a];
+#pragma unroll
+        for (int k = a + 1; k < 6; ++k) t -= Ls[6 * k + a] * y[k];
+        y[a] = t * idiag[a];
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) ysol[a] = y[a];
+    }
+    __syncthreads();
+    if (lane < 6) p.y[si + lane] = ysol[lane];
+  }
+}
+
 // candidate poses and step statistics; one workgroup.
 __global__ __launch_bounds__(256) void k_po_candidate(PoPtrs p) {
   LMState* st = p.st;

@@ -115,3 +115,58 @@ def test_po_fp32_factorisation_tolerance(hip):
     a, sa, _ = hip.po_solve(g2)
     b, sb, _ = hip.po_solve(g2, po_factor_fp32=1)
     assert np.abs(a - b).max() < 1e-5 and abs(sa["final_cost"] - sb["final_cost"]) <= 1e-5 * sa["final_cost"]
+
+
+def _add_edges(g, pairs, rng):
+    """extra edges between existing poses, constraints from the true poses + a little noise"""
+    truth = g["true_parameters"].reshape(-1, 6)
+    ed = {(int(a), int(b)): c for a, b, c in zip(g["pose_index_1"], g["pose_index_2"], g["constraints"])}
+    for a, b in pairs:
+        a, b = (a, b) if a < b else (b, a)
+        if (a, b) in ed:
+            continue
+        Ra, ta = synth.wt_to_rt(truth[a]); Rb, tb = synth.wt_to_rt(truth[b])
+        Rrel = synth.rodrigues(rng.normal(0, 1e-3, 3)) @ Rb @ Ra.T
+        ed[(a, b)] = synth.rt_to_wt(Rrel, tb - (Rb @ Ra.T) @ ta + rng.normal(0, 2e-3, 3))
+    keys = sorted(ed)
+    return dict(g, pose_index_1=np.array([k[0] for k in keys], dtype=np.int32), pose_index_2=np.array([k[1] for k in keys], dtype=np.int32),
+                constraints=np.array([ed[k] for k in keys]))
+
+
+@pytest.mark.parametrize("shape", ["single_chain", "ring", "two_ends_one_junction", "hub", "long_chains", "dense_loops", "two_poses"])
+def test_po_structured_factorisation_topologies(hip, oracle, shape):
+    """The default factorisation eliminates chains of poses concurrently and factors only the junction poses
+    densely.  Every topology class of the symbolic analysis (free-ended chain, junction-free cycle, chain
+    returning to its junction, high-degree junction, chains longer than the cut length, many loop closures)
+    must give what the dense factorisation of the whole matrix and the oracle give."""
+    rng = np.random.default_rng(11)
+    if shape == "single_chain":
+        g = synth.make_pose_graph(21, num_poses=50, num_loops=0)
+        g["parameters"] = g["parameters"] + rng.normal(0, 2e-3, g["parameters"].shape) * (np.arange(len(g["parameters"])) >= 6)
+    elif shape == "ring":                      # 1..N-1 form a cycle of degree-2 poses (pose 0 is the constant one)
+        g = _add_edges(synth.make_pose_graph(22, num_poses=30, num_loops=0), [(1, 29)], rng)
+    elif shape == "two_ends_one_junction":     # 5-6-...-14 leaves junction 5 and comes back to it
+        g = _add_edges(synth.make_pose_graph(23, num_poses=30, num_loops=0), [(5, 14), (5, 20)], rng)
+    elif shape == "hub":
+        g = _add_edges(synth.make_pose_graph(24, num_poses=40, num_loops=0), [(10, k) for k in (15, 20, 25, 30, 35, 39)], rng)
+    elif shape == "long_chains":
+        g = synth.make_pose_graph(25, num_poses=120, num_loops=2)
+    elif shape == "dense_loops":
+        g = _add_edges(synth.make_pose_graph(26, num_poses=60, num_loops=0), [(i, i + 7) for i in range(1, 50, 3)], rng)
+    else:
+        g = synth.make_pose_graph(27, num_poses=2, num_loops=0)
+        g["parameters"] = g["parameters"] + np.r_[np.zeros(6), rng.normal(0, 1e-2, 6)]
+    x0, s0, t0 = oracle.po_solve(g)
+    xs, ss, ts = hip.po_solve(g)
+    xd, sd, td = hip.po_solve(g, po_dense_factor=1)
+    assert np.abs(xs - xd).max() < 1e-9                                  # same system, different elimination order
+    assert np.abs(xs - x0).max() < 1e-6
+    if shape in ("single_chain", "two_poses"):
+        # a tree: every constraint can be met exactly, the solve runs into rounding noise (cost ~ 1e-20) and the
+        # iteration at which a tolerance fires is not comparable; the poses are
+        assert ss["final_cost"] < 1e-12 * ss["initial_cost"] and s0["final_cost"] < 1e-12 * s0["initial_cost"]
+        return
+    assert ss["num_successful_steps"] == sd["num_successful_steps"] == s0["num_successful_steps"]
+    assert ss["termination_type"] == sd["termination_type"] == s0["termination_type"]
+    assert abs(ss["final_cost"] - s0["final_cost"]) <= 1e-7 * s0["final_cost"] + 1e-20
+    _trace_parity(t0, ts, n=3)
