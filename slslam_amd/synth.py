@@ -180,6 +180,9 @@ def make_window(seed, num_lines=2000, num_kf=20, num_free=10, noise_px=0.5,
     "triangulate" = every landmark freshly initialised from its first stereo observation
     (SLAM::initialize_lm) - the hard, far-from-optimum case.
     """
+    if (num_kf if all_free else min(num_free, num_kf)) < 2:
+        raise ValueError("a window line must be seen by >= 2 free keyframes (slam.cpp:839-840): num_free >= 2; "
+                         "the 1-free-camera shape is make_motion_only()")
     rng = np.random.default_rng(np.random.SeedSequence([4, int(seed)]))   # rseed=4: main.cpp:26
     Rwc, cw = _trajectory(rng, num_kf)
     # re-root on the newest keyframe: world := newest camera frame
