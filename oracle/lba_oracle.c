@@ -490,3 +490,17 @@ void oracle_orth_to_av(const double orth[4], double av[6]) {
   av[4] = s1 * s2 * s3 + c1 * c3;
   av[5] = s1 * c2;
 }
+
+/* Fan-out of independent windows over host cores: each window goes through
+ * oracle_lba_solve unchanged, one window per OpenMP task.  Used only by bench.py's cpu_baseline leg. */
+int oracle_lba_solve_many(int count, const oracle_lba_problem* problems, const oracle_lm_options* opt,
+                          double* const* params, oracle_summary* summaries, int num_threads) {
+  int rc_any = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads) reduction(| : rc_any)
+#endif
+  for (int i = 0; i < count; ++i)
+    rc_any |= oracle_lba_solve(&problems[i], opt, params[i], &summaries[i], 0, 0, 0);
+  (void)num_threads;
+  return rc_any;
+}

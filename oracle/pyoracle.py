@@ -85,6 +85,8 @@ def lib():
         _lib.oracle_lba_cost.restype = C.c_double
         _lib.oracle_lba_solve.argtypes = [C.POINTER(LBAProblem), C.POINTER(LMOptions), dp,
                                           C.POINTER(Summary), C.POINTER(Iteration), C.c_int, ip]
+        _lib.oracle_lba_solve_many.argtypes = [C.c_int, C.POINTER(LBAProblem), C.POINTER(LMOptions), C.POINTER(dp),
+                                               C.POINTER(Summary), C.c_int]
         _lib.oracle_pose_residual.argtypes = [dp, dp, dp, dp]
         _lib.oracle_pose_residual_jet.argtypes = [dp, dp, dp, dp, dp, dp]
         _lib.oracle_po_cost.argtypes = [C.POINTER(POProblem), dp]
@@ -187,6 +189,19 @@ def lba_solve(w, params=None, huber_delta=1.0 / 406.05, trace_cap=256, **opt):
     d = _summary_dict(s)
     d["rc"] = rc
     return x, d, _trace_list(tr, min(n.value, trace_cap))
+
+
+def lba_solve_many(windows, num_threads, huber_delta=1.0 / 406.05, **opt):
+    """Independent windows fanned out over host threads inside the C library (OpenMP).
+    Returns (list of solved parameter vectors, list of summary dicts)."""
+    hs = [_LBAHandle(w, huber_delta) for w in windows]
+    xs = [_f64(w["parameters"]).copy() for w in windows]
+    probs = (LBAProblem * len(hs))(*[h.p for h in hs])
+    ptrs = (C.POINTER(C.c_double) * len(xs))(*[_dp(x) for x in xs])
+    sums = (Summary * len(hs))()
+    o = default_options(**opt)
+    lib().oracle_lba_solve_many(len(hs), probs, C.byref(o), ptrs, sums, int(num_threads))
+    return xs, [_summary_dict(s) for s in sums]
 
 
 def pose_residual_jet(p1, p2, c):
