@@ -170,6 +170,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   PoPtrs p, pj;
   std::memset(&p, 0, sizeof(p));
   PoChain* d_chains = nullptr;
+  char* arena = nullptr;
   const int nj = structured ? n - n_chain : 0;
   const int nblk_j = (nj + kNB - 1) / kNB;
   int *d_p1 = nullptr, *d_p2 = nullptr, *d_slot = nullptr;
@@ -182,25 +183,25 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   const int nblk = (n + kNB - 1) / kNB;
   const dim3 g_edges((unsigned)((E + 4) / 5));
 
-  PO_TRY(hipMalloc((void**)&d_p1, sizeof(int) * E));
-  PO_TRY(hipMalloc((void**)&d_p2, sizeof(int) * E));
-  PO_TRY(hipMalloc((void**)&d_slot, sizeof(int) * (N > 0 ? N : 1)));
-  PO_TRY(hipMalloc((void**)&d_cons, sizeof(double) * 6 * E));
-  PO_TRY(hipMalloc((void**)&p.x, sizeof(double) * 12 * (N > 0 ? N : 1)));
-  PO_TRY(hipMalloc((void**)&p.scale, sizeof(double) * ones.size()));
-  PO_TRY(hipMalloc((void**)&p.H, hbytes));
-  PO_TRY(hipMalloc((void**)&p.g, sizeof(double) * ones.size()));
-  PO_TRY(hipMalloc((void**)&p.d2, sizeof(double) * ones.size()));
-  PO_TRY(hipMalloc((void**)&p.y, sizeof(double) * ones.size()));
-  PO_TRY(hipMalloc((void**)&d_linv, sizeof(double) * kNB * kNB * (size_t)(nblk > 0 ? nblk : 1)));
-  if (f32) {
-    PO_TRY(hipMalloc((void**)&d_Hf, sizeof(float) * (size_t)(n > 0 ? n : 1) * ld));
-    PO_TRY(hipMalloc((void**)&d_linvf, sizeof(float) * kNB * kNB * (size_t)(nblk > 0 ? nblk : 1)));
+  // one device allocation carved into the work arrays (17 hipMalloc / hipFree pairs cost more than a small solve)
+  {
+    const size_t nn = ones.size(), nb2 = (size_t)kNB * kNB * (size_t)(nblk > 0 ? nblk : 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_p1 = take(sizeof(int) * E), o_p2 = take(sizeof(int) * E), o_slot = take(sizeof(int) * (N > 0 ? N : 1)),
+                 o_cons = take(sizeof(double) * 6 * E), o_x = take(sizeof(double) * 12 * (N > 0 ? N : 1)), o_scale = take(sizeof(double) * nn),
+                 o_H = take(hbytes), o_g = take(sizeof(double) * nn), o_d2 = take(sizeof(double) * nn), o_y = take(sizeof(double) * nn),
+                 o_linv = take(sizeof(double) * nb2), o_Hf = take(f32 ? sizeof(float) * (size_t)(n > 0 ? n : 1) * ld : 0),
+                 o_linvf = take(f32 ? sizeof(float) * nb2 : 0), o_scal = take(sizeof(double) * 8), o_flags = take(sizeof(int) * 2),
+                 o_st = take(sizeof(LMState)), o_trace = take(sizeof(IterRec) * kMaxTrace), o_chains = take(sizeof(PoChain) * (chains.size() + 1));
+    PO_TRY(hipMalloc((void**)&arena, off));
+    d_p1 = (int*)(arena + o_p1); d_p2 = (int*)(arena + o_p2); d_slot = (int*)(arena + o_slot); d_cons = (double*)(arena + o_cons);
+    p.x = (double*)(arena + o_x); p.scale = (double*)(arena + o_scale); p.H = (double*)(arena + o_H); p.g = (double*)(arena + o_g);
+    p.d2 = (double*)(arena + o_d2); p.y = (double*)(arena + o_y); d_linv = (double*)(arena + o_linv);
+    if (f32) { d_Hf = (float*)(arena + o_Hf); d_linvf = (float*)(arena + o_linvf); }
+    p.scal = (double*)(arena + o_scal); p.flags = (int*)(arena + o_flags); p.st = (LMState*)(arena + o_st);
+    p.trace = (IterRec*)(arena + o_trace); d_chains = (PoChain*)(arena + o_chains);
   }
-  PO_TRY(hipMalloc((void**)&p.scal, sizeof(double) * 8));
-  PO_TRY(hipMalloc((void**)&p.flags, sizeof(int) * 2));
-  PO_TRY(hipMalloc((void**)&p.st, sizeof(LMState)));
-  PO_TRY(hipMalloc((void**)&p.trace, sizeof(IterRec) * kMaxTrace));
   PO_TRY(hipMemcpy(d_p1, g->pose_index_1, sizeof(int) * E, hipMemcpyHostToDevice));
   PO_TRY(hipMemcpy(d_p2, g->pose_index_2, sizeof(int) * E, hipMemcpyHostToDevice));
   PO_TRY(hipMemcpy(d_slot, slot.data(), sizeof(int) * N, hipMemcpyHostToDevice));
@@ -220,7 +221,6 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   pj = p;                                  // the junction block as a matrix of its own (same leading dimension)
   pj.n = nj; pj.H = p.H + (size_t)n_chain * ld + n_chain; pj.y = p.y + n_chain;
   if (!chains.empty()) {
-    PO_TRY(hipMalloc((void**)&d_chains, sizeof(PoChain) * chains.size()));
     PO_TRY(hipMemcpy(d_chains, chains.data(), sizeof(PoChain) * chains.size(), hipMemcpyHostToDevice));
   }
 
@@ -312,10 +312,6 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     }
   }
 done:
-  (void)hipFree(d_chains);
-  (void)hipFree(d_p1); (void)hipFree(d_p2); (void)hipFree(d_slot); (void)hipFree(d_cons);
-  (void)hipFree(p.x); (void)hipFree(p.scale); (void)hipFree(p.H); (void)hipFree(p.g); (void)hipFree(p.d2);
-  (void)hipFree(p.y); (void)hipFree(d_linv); (void)hipFree(d_Hf); (void)hipFree(d_linvf); (void)hipFree(p.scal); (void)hipFree(p.flags);
-  (void)hipFree(p.st); (void)hipFree(p.trace);
+  (void)hipFree(arena);
   return rc;
 }
