@@ -621,11 +621,17 @@ extern "C" int slslam_lba_batch_linearise(slslam_lba_batch* b, int index, double
 extern "C" int slslam_lba_solve(const slslam_lba_window* w, const slslam_solver_options* opt,
                                 slslam_summary* summary, slslam_iteration* trace, int trace_cap, int* trace_len) {
   if (!w) return SLSLAM_ERR_INVALID_ARGUMENT;
+  slslam_solver_options o;
+  if (opt) o = *opt; else slslam_default_options(&o);
+  if (o.max_num_iterations < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
+  {   // malformed input is reported as such on any machine, before the device is looked for
+    PackedWindow probe;
+    const int prc = pack_window(w, &probe);
+    if (prc != SLSLAM_OK) return prc;
+  }
   slslam_lba_batch* b = nullptr;
   int rc = slslam_lba_batch_create(-1, &b);
   if (rc) return rc;
-  slslam_solver_options o;
-  if (opt) o = *opt; else slslam_default_options(&o);
   o.use_graph = 0;   // a single solve is replayed once: capture would only add latency
   if ((rc = slslam_lba_batch_add(b, w, nullptr)) == SLSLAM_OK &&
       (rc = slslam_lba_batch_finalize(b, &o)) == SLSLAM_OK &&

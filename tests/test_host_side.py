@@ -197,3 +197,42 @@ def test_no_cpu_fallback():
         for f in os.listdir(p):
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 assert not pat.search(open(os.path.join(p, f)).read()), "%s/%s references the oracle" % (d, f)
+
+
+def test_argument_validation_comes_before_the_device():
+    """Malformed inputs are rejected with SLSLAM_ERR_INVALID_ARGUMENT (1) on any machine; well-formed ones need a
+    HIP device (SLSLAM_ERR_NO_DEVICE = 2 here): every entry point, including the RANSAC and pose-graph ones."""
+    from slslam_amd import capi
+    gpu = capi.device_count() > 0
+
+    def status(fn, *a, **k):
+        try:
+            fn(*a, **k)
+            return 0
+        except capi.SlslamError as e:
+            return e.status
+    w = synth.make_window(1, num_lines=8)
+    bad = dict(w, camera_index=w["camera_index"].copy())
+    bad["camera_index"][0] = 99
+    assert status(capi.lba_solve, bad) == 1
+    nanw = dict(w, observations=w["observations"].copy())
+    nanw["observations"][0, 0] = np.nan
+    assert status(capi.lba_solve, nanw) == 1
+    assert status(capi.lba_solve, w, max_num_iterations=-1) == 1
+    g = synth.make_pose_graph(1, num_poses=6, num_loops=1)
+    gb = dict(g, pose_index_2=g["pose_index_2"].copy())
+    gb["pose_index_2"][0] = gb["pose_index_1"][0]                         # self edge
+    assert status(capi.po_solve, gb) == 1
+    fr = synth.make_ransac_pair(1, num_lines=20, num_trials=4)
+    smp = fr["samples"].copy()
+    smp[0, 0] = 20                                                        # index past the common lines
+    assert status(capi.ransac_generate, fr["obs0"], fr["obs1"], smp) == 1
+    assert status(capi.ransac_motion, fr["obs0"], fr["obs1"], fr["lines"], smp) == 1
+    assert status(capi.ransac_generate, fr["obs0"], fr["obs1"], np.zeros((2, 17), dtype=np.int32)) == 1    # s > 16
+    ok = 0 if gpu else 2
+    assert status(capi.lba_solve, w) == ok
+    assert status(capi.po_solve, g) == ok
+    assert status(capi.ransac_generate, fr["obs0"], fr["obs1"], fr["samples"]) == ok
+    assert status(capi.ransac_motion, fr["obs0"], fr["obs1"], fr["lines"], fr["samples"]) == ok
+    poses, obs, lines, _ = synth.make_ransac_frame(1, num_lines=10, num_hypotheses=3)
+    assert status(capi.ransac_score, poses, obs, lines) == ok
