@@ -12,12 +12,13 @@ kv = dict(a.split("=") for a in sys.argv[3:])
 chunks = [int(x) for x in kv.get("chunks", "0").split(",")]
 steps = int(kv.get("steps", 3))
 reuse = int(kv.get("reuse", 0))
+maxit = int(kv.get("maxit", 10))
 ws = [synth.make_window(100 + i, num_lines=lines) for i in range(nb)]
 for c in chunks:
     b = capi.LBABatch()
     for w in ws:
         b.add(w)
-    b.finalize(use_graph=0, chunks_per_window=c, reuse_elimination=reuse)
+    b.finalize(use_graph=0, chunks_per_window=c, reuse_elimination=reuse, max_num_iterations=maxit)
     b.reset(); b.solve(); b.download()
     b.set_profiling(True)
     b.iterations(clear=True)
