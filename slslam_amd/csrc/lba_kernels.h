@@ -471,24 +471,22 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
 //   1. ordered sum of the window's chunk partials (bitwise reproducible; every thread owns entries,
 //      the loads of one entry over the chunks are independent and in flight together)
 //   2. gradient-tolerance test Ceres does right after accepting a step
-//   3. S += D_c^2, blocked right-looking Cholesky in LDS with 16x16 tiles: diagonal tile by rank-1
-//      updates (one element per thread), its triangular inverse, then the panel (L21 = A21 L11^-T) and
+//   3. S += D_c^2, blocked right-looking Cholesky in LDS with 16x16 tiles: diagonal tile in the registers of
+//      one wave together with its triangular inverse, then the panel (L21 = A21 L11^-T) and
 //      the trailing update (A22 -= L21 L21^T) on v_mfma_f64_16x16x4_f64, tiles dealt to the 4 waves —
 //      the one dense contraction of the LBA path (n = 6 Cf = 60: 64 MFMA per factorisation)
 //   4. block forward / backward substitution with the diagonal-tile inverses
 //   5. step statistics of the camera block, candidate camera poses
 __host__ __device__ inline int solve_pad(int n) { return ((n + 15) / 16) * 16; }
 __host__ __device__ inline int solve_stride(int n) { return ((solve_pad(n) + 30) / 32) * 32 + 1; }  // == 1 (mod 32) doubles
-enum { kInvLd = 17 };
+// The inverse of a diagonal tile's factor is kept IN the tile: strictly lower part transposed into the tile's
+// (otherwise unused) strict upper triangle, its diagonal 1 / L[r][r] in a vector: 36.5 KB of LDS for n = 60,
+// i.e. 4 workgroups per CU and the whole 1024-window batch resident in one round.
 __host__ __device__ inline int lds_doubles_solve(int n) {
   const int N = solve_pad(n);
-  return N * solve_stride(n) + (N / 16) * 16 * kInvLd + 5 * N + 16;
+  return N * solve_stride(n) + 6 * N + 16;
 }
 typedef double solve_acc_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double readlane_f64(double v, int l) {      // l wave-uniform
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
 
 __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -499,20 +497,20 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
   if (st->status != kRunning) return;
   const int n = wd.n, ncf = n / 6, nsys = sys_doubles(n), N = solve_pad(n), nt = N / 16, ld = solve_stride(n);
   double* A = smem;                       // N x ld, lower triangle used
-  double* Linv = A + N * ld;              // nt diagonal-tile inverses, 16 x kInvLd each
-  double* bvec = Linv + nt * 16 * kInvLd; // b | g | hdiag | y | tmp, N each
+  double* bvec = A + N * ld;              // b | g | hdiag | y | tmp | 1 / diag(L), N each
   double* gvec = bvec + N;
   double* hvec = gvec + N;
   double* yvec = hvec + N;
   double* tvec = yvec + N;
-  double* red = tvec + N;                 // 16 scratch doubles
+  double* ivec = tvec + N;
+  double* red = ivec + N;                 // 16 scratch doubles
   const int cur = st->cur;
   const double radius = st->radius;
   const int need_grad_check = st->need_grad_check;
   const double abs_grad_tol = st->abs_grad_tol;
 
   for (int q = tid; q < N * ld; q += 256) A[q] = 0.0;
-  for (int q = tid; q < 5 * N; q += 256) bvec[q] = 0.0;
+  for (int q = tid; q < 6 * N; q += 256) bvec[q] = 0.0;
   __syncthreads();
   // ---- 1. ordered reduction over the window's chunk partials (uniform stride between consecutive slabs)
   const long long slab0 = p.chunks[wd.chunk_off].slab_off;
@@ -597,47 +595,51 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
   const int er = tid >> 4, ec = tid & 15;       // this thread's element of a 16x16 tile
   for (int kb = 0; kb < nt; ++kb) {
     double* D = A + (16 * kb) * ld + 16 * kb;   // diagonal tile
-    // (a)+(b) diagonal tile in the registers of wave 0, lane <-> COLUMN of the symmetric tile (so that
-    // the multiplier l_c of a lane's own column is lane-local, and only the pivot column has to be
-    // broadcast: v_readlane from lane jc, at most 16 live scalars).  Right-looking Cholesky; the same
-    // row operations applied to the identity give L^-1 in the same sweep.  No LDS traffic, no barriers.
+    // (a)+(b) diagonal tile in the registers of wave 0: lane (q, c) holds rows 4q..4q+3 of column c of the
+    // SYMMETRIC tile (both triangles are maintained, so the multiplier of a lane's own column is an element of
+    // the pivot row) and of the identity the same row operations turn into L^-1.  Right-looking Cholesky,
+    // 16 steps; per step seven wave shuffles, all reading the state before the step: one round trip.
     if (wave == 0) {
-      double a[16], e[16];
-      const int c = lane & 15;
+      const int c = lane & 15, q = lane >> 4;
+      double a[4], e[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { a[r] = (r >= c) ? D[r * ld + c] : D[c * ld + r]; e[r] = (r == c) ? 1.0 : 0.0; }
+      for (int k = 0; k < 4; ++k) {
+        const int r = 4 * q + k;
+        a[k] = (r >= c) ? D[r * ld + c] : D[c * ld + r];
+        e[k] = (r == c) ? 1.0 : 0.0;
+      }
 #pragma unroll
       for (int jc = 0; jc < 16; ++jc) {
-        const double piv = readlane_f64(a[jc], jc);
+        const int qj = jc >> 2, kj = jc & 3;                   // compile-time after unrolling
+        const double piv = __shfl(a[kj], 16 * qj + jc);
+        const double arow_c = __shfl(a[kj], 16 * qj + c);       // A[jc][c] = A[c][jc]
+        const double erow_c = __shfl(e[kj], 16 * qj + c);       // E[jc][c]
+        double lrow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lrow[k] = __shfl(a[k], (lane & 48) | jc);   // A[4q+k][jc]
         const bool okp = piv > 0.0 && isfinite(piv);
         if (!okp) fail = 1;
-        const double ip = okp ? inv_sqrt<double>(piv) : 1.0;       // v_rsq_f64 + refinement: no sqrt, no divide on the chain
-        const double lcown = a[jc] * ip;                           // L[c][jc], this lane's multiplier (c > jc)
-        if (c == jc) {                                             // the pivot column becomes column jc of L
-          a[jc] = okp ? piv * ip : 1.0;
+        const double ip = okp ? inv_sqrt<double>(piv) : 1.0;    // v_rsq_f64 + refinement: no sqrt, no divide on the chain
+        const double lcown = arow_c * ip, ej = erow_c * ip;
 #pragma unroll
-          for (int r = jc + 1; r < 16; ++r) a[r] *= ip;
-        }
-        const double ej = e[jc] * ip;                              // row jc of the inverse so far, scaled
-        e[jc] = ej;
-#pragma unroll
-        for (int r = jc + 1; r < 16; ++r) {
-          const double lr = readlane_f64(a[r], jc);                // L[r][jc]
-          if (c > jc) a[r] -= lr * lcown;
-          e[r] -= lr * ej;
+        for (int k = 0; k < 4; ++k) {
+          const int r = 4 * q + k;
+          const double lr = lrow[k] * ip;                       // L[r][jc]
+          if (c == jc) a[k] = (r > jc) ? lr : (r == jc ? (okp ? piv * ip : 1.0) : a[k]);
+          else if (r > jc && c > jc) a[k] -= lr * lcown;
+          if (r == jc) e[k] = ej;
+          else if (r > jc) e[k] -= lr * ej;
         }
       }
-      if (lane < 16) {
-        double* Lw = Linv + kb * 16 * kInvLd;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (r >= c) D[r * ld + c] = a[r];
-          Lw[r * kInvLd + c] = (r >= c) ? e[r] : 0.0;
-        }
+      for (int k = 0; k < 4; ++k) {
+        const int r = 4 * q + k;
+        if (r >= c) D[r * ld + c] = a[k];             // L
+        if (r > c) D[c * ld + r] = e[k];              // L^-1 (strictly lower part), transposed into the upper triangle
+        if (r == c) ivec[16 * kb + r] = e[k];         // its diagonal
       }
     }
     __syncthreads();
-    const double* Li = Linv + kb * 16 * kInvLd;
     // (c) panel: L(i,kb) = A(i,kb) Linv^T, one tile per wave at a time
     for (int i = kb + 1 + wave; i < nt; i += 4) {
       double* T = A + (16 * i) * ld + 16 * kb;
@@ -645,7 +647,8 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const double a = T[(lane & 15) * ld + 4 * s4 + (lane >> 4)];          // A[m][k]
-        const double b = Li[(lane & 15) * kInvLd + 4 * s4 + (lane >> 4)];     // B[k][n] = Linv[n][k]
+        const int bn = lane & 15, bk = 4 * s4 + (lane >> 4);                  // B[k][n] = Linv[n][k], zero above the diagonal
+        const double b = bn > bk ? D[bk * ld + bn] : (bn == bk ? ivec[16 * kb + bn] : 0.0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
       }
 #pragma unroll
@@ -685,9 +688,9 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
     }
     __syncthreads();
     if (tid < 16) {
-      const double* Li = Linv + kb * 16 * kInvLd;
-      double sacc = 0.0;
-      for (int k = 0; k <= tid; ++k) sacc += Li[tid * kInvLd + k] * tvec[k];
+      const double* Dk = A + (16 * kb) * ld + 16 * kb;
+      double sacc = ivec[16 * kb + tid] * tvec[tid];
+      for (int k = 0; k < tid; ++k) sacc += Dk[k * ld + tid] * tvec[k];          // Linv[tid][k]
       yvec[16 * kb + tid] = sacc;
     }
     __syncthreads();
@@ -702,9 +705,9 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
     }
     __syncthreads();
     if (tid < 16) {
-      const double* Li = Linv + kb * 16 * kInvLd;
-      double sacc = 0.0;
-      for (int k = tid; k < 16; ++k) sacc += Li[k * kInvLd + tid] * tvec[k];
+      const double* Dk = A + (16 * kb) * ld + 16 * kb;
+      double sacc = ivec[16 * kb + tid] * tvec[tid];
+      for (int k = tid + 1; k < 16; ++k) sacc += Dk[tid * ld + k] * tvec[k];     // Linv[k][tid]
       yvec[16 * kb + tid] = sacc;
     }
     __syncthreads();
