@@ -398,7 +398,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
   } while (0)
   if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 0));
   if (b->nchunk > 0) LAUNCH(FAM_INIT, hipLaunchKernelGGL(k_linearise_schur<true>, g_chunk, blk64, b->lds_lin, s, p, pol));
-  LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol, 0));
+  LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_init, g_win, blk64, 0, s, p, pol));
   for (int it = 0; it < pol.max_num_iterations; ++it) {
     // long solves (the reference's max_num_iter = 1000 study): every 16 iterations ask the device
     // whether any window is still iterating and stop enqueueing when none is
@@ -419,7 +419,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 1));
       if (b->nchunk > 0) LAUNCH(FAM_COST, hipLaunchKernelGGL(k_candidate_cost, g_chunk, blk64, b->lds_cost, s, p, pol));
     }
-    LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol, 1));
+    LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol));
   }
 #undef LAUNCH
   HIP_TRY(hipGetLastError());

@@ -1059,14 +1059,75 @@ __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) 
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel 6: the trust-region bookkeeping of one window (one lane).
-// phase 0 = after the initial evaluation, 1 = after an LM iteration.
+// Kernel 6: the trust-region bookkeeping of one window (one lane) after an LM iteration.
 __device__ __forceinline__ void push_trace(BatchPtrs& p, int w, LMState* st, const IterRec& r) {
   if (st->ntrace < kMaxTrace) p.trace[(long long)w * kMaxTrace + st->ntrace] = r;
   st->ntrace++;
 }
 
-__global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol, int phase) {
+// After the initial evaluation (Ceres: cost, gradient and column norms at x0): one wave per window,
+// lane <-> camera column; the chunk partials of a column are summed in chunk order with the loads in flight together.
+__global__ __launch_bounds__(64) void k_lm_init(BatchPtrs p, Policy pol) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const WinDesc wd = p.wins[w];
+  LMState* st = p.state + w;
+  if (st->status != kRunning) return;
+  const int n = wd.n, nsys = sys_doubles(n);
+  const long long slab0 = p.chunks[wd.chunk_off].slab_off;
+  const long long sstride = (long long)nsys + kSlabScalars;
+  double cost = 0.0, fixed = 0.0, gmax = 0.0, xn2 = 0.0;
+  for (int c = lane; c < wd.nchunks; c += 64) {
+    const double* sc = p.slab + slab0 + c * sstride + nsys;
+    cost += sc[kScCost]; fixed += sc[kScFixedCost]; gmax = fmax(gmax, sc[kScGradMaxLine]); xn2 += sc[kScXn2Line];
+  }
+  // cost / fixed cost: chunk order matters for bitwise reproducibility -> ordered sum by lane 0 below when > 64 chunks never happens;
+  // with <= 64 chunks every lane holds at most one term and the xor-tree below is a fixed order
+  for (int q = lane; q < 6 * wd.C; q += 64) {
+    const int c = q / 6, a = q - 6 * c;
+    const int cf = p.cam_cf[wd.cam_off + c];
+    double sc = 1.0;
+    if (cf >= 0) {
+      const double* src = p.slab + slab0 + cf * kCamAcc;
+      double g = 0.0, h = 0.0;
+      for (int k0 = 0; k0 < wd.nchunks; k0 += 8) {
+        double vg[8], vh[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool in = k0 + u < wd.nchunks;
+          const double* sl = src + (long long)(in ? k0 + u : k0) * sstride;
+          vg[u] = in ? sl[kRecG + a] : 0.0; vh[u] = in ? sl[kRecH + a] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { g += vg[u]; h += vh[u]; }
+      }
+      const double x = p.cam_x[((long long)(wd.cam_off + c) * 2 + st->cur) * kCamRec + a];
+      gmax = fmax(gmax, fabs(g));
+      xn2 += x * x;
+      if (pol.jacobi_scaling) sc = 1.0 / (1.0 + sqrt(h));
+    }
+    p.cam_scale[(long long)(wd.cam_off + c) * 6 + a] = sc;
+  }
+  cost = wave_sum(cost); fixed = wave_sum(fixed); xn2 = wave_sum(xn2); gmax = wave_max(gmax);
+  if (lane != 0) return;
+  st->cost = cost; st->fixed_cost = fixed; st->initial_cost = cost + fixed; st->min_cost = cost + fixed;
+  st->x_norm = sqrt(xn2);
+  st->grad_max = gmax;
+  const double g0 = gmax > 1e-12 ? gmax : 1e-12;
+  st->abs_grad_tol = pol.gradient_tolerance * g0;
+  st->need_grad_check = 0;
+  if (wd.nfree_params == 0) { st->status = 2 /* FUNCTION_TOLERANCE: no free blocks */; return; }
+  if (!isfinite(cost)) { st->status = 4; return; }
+  if (gmax <= st->abs_grad_tol) { st->status = 1; return; }
+  IterRec rec;
+  rec.pad = 0;
+  rec.iteration = 0; rec.step_is_valid = 0; rec.step_is_successful = 0;
+  rec.cost = cost + fixed; rec.cost_change = 0; rec.gradient_max_norm = gmax; rec.step_norm = 0;
+  rec.relative_decrease = 0; rec.trust_region_radius = st->radius; rec.model_cost_change = 0;
+  push_trace(p, w, st, rec);
+  if (st->iter >= pol.max_num_iterations) st->status = 0;
+}
+
+__global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= p.nwin) return;
   const WinDesc wd = p.wins[w];
@@ -1075,48 +1136,6 @@ __global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol, int p
   const int n = wd.n, nsys = sys_doubles(n);
   IterRec rec;
   rec.pad = 0;
-  if (phase == 0) {
-    // ---- Ceres: initial cost / gradient / Jacobi scale
-    double cost = 0.0, fixed = 0.0, gmax = 0.0, xn2 = 0.0;
-    for (int c = 0; c < wd.nchunks; ++c) {
-      const double* sc = p.slab + p.chunks[wd.chunk_off + c].slab_off + nsys;
-      cost += sc[kScCost]; fixed += sc[kScFixedCost]; gmax = fmax(gmax, sc[kScGradMaxLine]); xn2 += sc[kScXn2Line];
-    }
-    for (int c = 0; c < wd.C; ++c) {
-      const int cf = p.cam_cf[wd.cam_off + c];
-      const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + st->cur) * kCamRec;
-      for (int a = 0; a < 6; ++a) {
-        double sc = 1.0;
-        if (cf >= 0) {
-          double g = 0.0, h = 0.0;
-          for (int k = 0; k < wd.nchunks; ++k) {
-            const double* sl = p.slab + p.chunks[wd.chunk_off + k].slab_off + cf * kCamAcc;
-            g += sl[kRecG + a]; h += sl[kRecH + a];
-          }
-          gmax = fmax(gmax, fabs(g));
-          xn2 += x[a] * x[a];
-          if (pol.jacobi_scaling) sc = 1.0 / (1.0 + sqrt(h));
-        }
-        p.cam_scale[(long long)(wd.cam_off + c) * 6 + a] = sc;
-      }
-    }
-    st->cost = cost; st->fixed_cost = fixed; st->initial_cost = cost + fixed; st->min_cost = cost + fixed;
-    st->x_norm = sqrt(xn2);
-    st->grad_max = gmax;
-    const double g0 = gmax > 1e-12 ? gmax : 1e-12;
-    st->abs_grad_tol = pol.gradient_tolerance * g0;
-    st->need_grad_check = 0;
-    if (wd.nfree_params == 0) { st->status = 2 /* FUNCTION_TOLERANCE: no free blocks */; return; }
-    if (!isfinite(cost)) { st->status = 4; return; }
-    if (gmax <= st->abs_grad_tol) { st->status = 1; return; }
-    rec.iteration = 0; rec.step_is_valid = 0; rec.step_is_successful = 0;
-    rec.cost = cost + fixed; rec.cost_change = 0; rec.gradient_max_norm = gmax; rec.step_norm = 0;
-    rec.relative_decrease = 0; rec.trust_region_radius = st->radius; rec.model_cost_change = 0;
-    push_trace(p, w, st, rec);
-    if (st->iter >= pol.max_num_iterations) st->status = 0;
-    return;
-  }
-
   // ---- one LM iteration
   double new_cost = 0.0, model = st->cam_model, dn2 = st->cam_dn2, xn2 = st->cam_xn2;
   for (int c = 0; c < wd.nchunks; ++c) {
