@@ -183,6 +183,53 @@ __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy&
   }
 }
 
+// Back-substitution form of lane_linearise: same residual and (robustified, Jacobi-scaled) line Jacobian, but the
+// camera Jacobian only as its product with the camera step, jy = Jc' y_c (obs_linearise_jy): the camera table
+// of the back-substitution holds R[9] t[3] | JL (s_w o y_w) [3] | s_t o y_t [3] per camera (kBsTab doubles).
+enum { kBsTab = 19 };
+__device__ __forceinline__ void lane_linearise_bs(const BatchPtrs& p, const Policy& pol, const double* bstab,
+                                                  const signed char* camcf, int ls, int j, int k, int o0, bool line_ok,
+                                                  int lflags, int cur, int safe_obs, LaneLin& L, double (&ob)[8], double (&jy)[4]) {
+  L.valid = line_ok && j < k;
+  const int o = L.valid ? o0 + j : safe_obs;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
+    ob[2 * q] = e.x; ob[2 * q + 1] = e.y;
+  }
+  L.cam = p.ob_cam[o];
+  const int lsafe = line_ok ? ls : 0;
+  const double* lrec = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
+  double trig[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
+  L.line_free = line_ok && !(lflags & 1);
+  const double* ct = bstab + L.cam * kBsTab;
+  double R[9], t[3], vw[3], yt[3];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) R[q] = ct[q];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { t[q] = ct[9 + q]; vw[q] = ct[12 + q]; yt[q] = ct[15 + q]; }
+  L.cf = camcf[L.cam];
+  L.kept = L.valid && !(L.cf < 0 && !L.line_free);
+  double cp[3], dv[3], dcp[12], ddv[9], r[4];
+  line_points_jac<double>(trig, cp, dv, dcp, ddv);
+  obs_linearise_jy<double>(R, t, vw, yt, cp, dv, dcp, ddv, ob, pol.baseline, r, jy, L.Jl);
+  const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+  const double sr = huber_scale<double>(s, pol.huber_delta, &L.cost);
+  const double* lsc = p.line_scale + (long long)lsafe * 4;
+  double sl[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) sl[a] = lsc[a] * sr;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    L.rs[q] = r[q] * sr;
+    jy[q] *= sr;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) L.Jl[4 * q + a] *= sl[a];
+  }
+}
+
 // Per-line normal-equation block, summed over the line's group of lanes (every lane of the group
 // ends with the same values): H = sum Jl^T Jl (lower triangle, 10 values), g = sum Jl^T r.
 __device__ __forceinline__ void line_block(const LaneLin& L, int width, double H[10], double g[4]) {
@@ -756,7 +803,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
 // registers when the line's candidate parameters become known, the candidate residual is
 // evaluated right here: no third sweep over the observations and no separate sin/cos pass.
 enum { kCandTab = 13 };   // doubles per camera of the candidate table: R[9] t[3]; odd stride in 8-byte units
-__host__ __device__ inline int lds_doubles_backsub(int C, int n) { return C * (kCamTab + kCandTab) + 2 * (n > 0 ? n : 6) + (C + 7) / 8; }
+__host__ __device__ inline int lds_doubles_backsub(int C, int n) { (void)n; return C * (kBsTab + kCandTab) + (C + 7) / 8; }
 
 // sin/cos table of a candidate line, computed cooperatively: every lane of a line's group holds the
 // same u[4]; lane (j & 3) evaluates the sin/cos of angle (j & 3) and the quad shares the results
@@ -793,21 +840,37 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
   const int cur = st->cur;
   const double radius = st->radius;
   const int n = wd.n;
-  double* camtab = smem;
-  double* candtab = camtab + wd.C * kCamTab;
-  double* camscale = candtab + wd.C * kCandTab;
-  double* yc = camscale + (n > 0 ? n : 6);
-  signed char* camcf = (signed char*)(yc + (n > 0 ? n : 6));
-  load_cam_table<true, false>(p, wd, cur, lane, camtab, camscale, camcf);
-  for (int c = lane; c < wd.C; c += 64) {     // candidate camera poses (written by k_reduced_solve)
-    const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + (1 - cur)) * kCamRec;
-    double w[3] = { x[0], x[1], x[2] }, R[9];
-    cam_rotation<double>(w, R);
+  double* bstab = smem;
+  double* candtab = bstab + wd.C * kBsTab;
+  signed char* camcf = (signed char*)(candtab + wd.C * kCandTab);
+  for (int c = lane; c < wd.C; c += 64) {
+    // accepted pose: R, t and the camera step folded through JL and the Jacobi scale;
+    // candidate pose (written by k_reduced_solve): R, t for the cost at the candidate point
+    const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + cur) * kCamRec;
+    const double* xc = p.cam_x + ((long long)(wd.cam_off + c) * 2 + (1 - cur)) * kCamRec;
+    double w[3] = { x[0], x[1], x[2] }, R[9], JL[9];
+    cam_prepare<double>(w, R, JL);
+    double* bt = bstab + c * kBsTab;
+    for (int q = 0; q < 9; ++q) bt[q] = R[q];
+    bt[9] = x[3]; bt[10] = x[4]; bt[11] = x[5];
+    const int cf = p.cam_cf[wd.cam_off + c];
+    double yw[3] = { 0, 0, 0 }, yt[3] = { 0, 0, 0 };
+    if (cf >= 0) {
+      const double* sc = p.cam_scale + (long long)(wd.cam_off + c) * 6;
+      const double* y = p.ysys + wd.sys_off + 6 * cf;
+      for (int a = 0; a < 3; ++a) { yw[a] = sc[a] * y[a]; yt[a] = sc[3 + a] * y[3 + a]; }
+    }
+    for (int i = 0; i < 3; ++i) {
+      bt[12 + i] = JL[3 * i] * yw[0] + JL[3 * i + 1] * yw[1] + JL[3 * i + 2] * yw[2];   // (JL yw)[i]:  (tau^T JL) . yw = tau . (JL yw)
+      bt[15 + i] = yt[i];
+    }
+    camcf[c] = (signed char)cf;
+    double wc[3] = { xc[0], xc[1], xc[2] }, Rc[9];
+    cam_rotation<double>(wc, Rc);
     double* ct = candtab + c * kCandTab;
-    for (int q = 0; q < 9; ++q) ct[q] = R[q];
-    ct[9] = x[3]; ct[10] = x[4]; ct[11] = x[5];
+    for (int q = 0; q < 9; ++q) ct[q] = Rc[q];
+    ct[9] = xc[3]; ct[10] = xc[4]; ct[11] = xc[5];
   }
-  for (int q = lane; q < n; q += 64) yc[q] = p.ysys[wd.sys_off + q];
   __syncthreads();
 
   double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0, acc_cost = 0.0;
@@ -819,22 +882,14 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
     const int j = tc.j, ls = tc.ls, k = tc.k;
     const bool line_ok = tc.line_ok;
     LaneLin L;
-    double ob[8];
-    lane_linearise<true>(p, pol, camtab, camscale, camcf, ls, j, k, tc.o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob);
+    double ob[8], jy[4];
+    lane_linearise_bs(p, pol, bstab, camcf, ls, j, k, tc.o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob, jy);
     double H[10], g[4];
     line_block(L, width, H, g);
     const bool line_active = L.line_free && k > 0;
     // w = sum_i (Jc_i^T Jl_i)^T y_c[cam_i] = sum_i Jl_i^T (Jc_i y_c)
     double wv[4] = { 0, 0, 0, 0 };
     if (L.valid && L.cf >= 0 && L.line_free) {
-      double jy[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double s = 0.0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) s += L.Jc[6 * r + a] * yc[6 * L.cf + a];
-        jy[r] = s;
-      }
 #pragma unroll
       for (int a = 0; a < 4; ++a) wv[a] = L.Jl[a] * jy[0] + L.Jl[4 + a] * jy[1] + L.Jl[8 + a] * jy[2] + L.Jl[12 + a] * jy[3];
     }

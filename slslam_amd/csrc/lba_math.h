@@ -213,6 +213,53 @@ SLS_HD void obs_linearise(const T R[9], const T JL[9], const T t[3],
   }
 }
 
+// Back-substitution form: residuals, the line Jacobian Jl[4][4] and, instead of the camera Jacobian,
+// its product with the camera step:  jy[row] = (dr/dw) . yw + (dr/dt) . yt  with  dr/dw = tau^T JL,
+// i.e. jy = tau . (JL yw) + gP . yt.  The caller passes vw = JL yw (3) and yt (3): J_cam is never formed
+// (24 doubles fewer live per lane).
+template <typename T>
+SLS_HD void obs_linearise_jy(const T R[9], const T t[3], const T vw[3], const T yt[3],
+                             const T cp[3], const T dv[3], const T dcp[12], const T ddv[9],
+                             const T ob[8], T baseline, T r[4], T jy[4], T Jl[16]) {
+  T Q[3], P[3], dc[3];
+  for (int i = 0; i < 3; ++i) {
+    Q[i] = R[3 * i] * cp[0] + R[3 * i + 1] * cp[1] + R[3 * i + 2] * cp[2];
+    P[i] = Q[i] + t[i];
+    dc[i] = R[3 * i] * dv[0] + R[3 * i + 1] * dv[1] + R[3 * i + 2] * dv[2];
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (k == 1) P[0] -= baseline;
+    const T n0 = P[1] * dc[2] - P[2] * dc[1];
+    const T n1 = P[2] * dc[0] - P[0] * dc[2];
+    const T n2 = P[0] * dc[1] - P[1] * dc[0];
+    const T is = inv_sqrt<T>(n0 * n0 + n1 * n1);
+    const T m0 = n0 * is, m1 = n1 * is, m2 = n2 * is;
+    for (int e = 0; e < 2; ++e) {
+      const int row = 2 * k + e;
+      const T x = ob[4 * k + 2 * e], y = ob[4 * k + 2 * e + 1];
+      const T rho = x * m0 + y * m1 + m2;
+      r[row] = -rho;
+      const T q0 = -(x - rho * m0) * is, q1 = -(y - rho * m1) * is, q2 = -is;
+      const T gP[3] = { dc[1] * q2 - dc[2] * q1, dc[2] * q0 - dc[0] * q2, dc[0] * q1 - dc[1] * q0 };
+      const T gD[3] = { q1 * P[2] - q2 * P[1], q2 * P[0] - q0 * P[2], q0 * P[1] - q1 * P[0] };
+      const T tau[3] = { Q[1] * gP[2] - Q[2] * gP[1] + dc[1] * gD[2] - dc[2] * gD[1],
+                         Q[2] * gP[0] - Q[0] * gP[2] + dc[2] * gD[0] - dc[0] * gD[2],
+                         Q[0] * gP[1] - Q[1] * gP[0] + dc[0] * gD[1] - dc[1] * gD[0] };
+      jy[row] = tau[0] * vw[0] + tau[1] * vw[1] + tau[2] * vw[2] + gP[0] * yt[0] + gP[1] * yt[1] + gP[2] * yt[2];
+      T hP[3], hD[3];                                    // R^T gP, R^T gD
+      for (int i = 0; i < 3; ++i) {
+        hP[i] = R[i] * gP[0] + R[3 + i] * gP[1] + R[6 + i] * gP[2];
+        hD[i] = R[i] * gD[0] + R[3 + i] * gD[1] + R[6 + i] * gD[2];
+      }
+      T* jl = Jl + 4 * row;
+      for (int j = 0; j < 3; ++j)
+        jl[j] = hP[0] * dcp[3 * j] + hP[1] * dcp[3 * j + 1] + hP[2] * dcp[3 * j + 2]
+              + hD[0] * ddv[3 * j] + hD[1] * ddv[3 * j + 1] + hD[2] * ddv[3 * j + 2];
+      jl[3] = hP[0] * dcp[9] + hP[1] * dcp[10] + hP[2] * dcp[11];
+    }
+  }
+}
+
 // ceres::HuberLoss(a) + Corrector for rho'' <= 0 (lba_problem.cpp:78-80): returns the factor
 // sqrt(rho') that scales both residual and Jacobian, and the block cost rho/2.
 // a <= 0 disables the loss (FLAGS_robust = false).
