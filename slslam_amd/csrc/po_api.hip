@@ -27,7 +27,7 @@ using namespace slslam;
 
 namespace {
 
-enum { kMaxChain = 16 };
+enum { kMaxChain = 32 };
 
 // Symbolic analysis of the structured factorisation: junction = free pose with >= 3 distinct free
 // neighbours (plus one pose per junction-free cycle); every other free pose lies on a chain.
