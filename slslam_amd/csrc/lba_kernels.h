@@ -125,25 +125,57 @@ __device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_e
   return c;
 }
 
+// What a lane reads from HBM for its observation: the four endpoint pairs, the camera id and the sin/cos table
+// of its line.  Requested for tile t + 1 in the low-register-pressure tail of tile t (after the Jacobians are
+// dead), so that the HBM latency of the next tile overlaps the pair products of the current one.
+struct ObsPref {
+  double ob[8];
+  double trig[7];
+  int cam;
+};
+__device__ __forceinline__ void prefetch_obs(const BatchPtrs& p, const TileCtx& c, int cur, int safe_obs, ObsPref& f) {
+  const bool valid = c.line_ok && c.j < c.k;
+  const int o = valid ? c.o0 + c.j : safe_obs;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {     // (x,y) endpoint pairs: one 16-byte load per plane
+    const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
+    f.ob[2 * q] = e.x; f.ob[2 * q + 1] = e.y;
+  }
+  f.cam = p.ob_cam[o];
+  const int lsafe = c.line_ok ? c.ls : 0;
+  const double* lrec = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) f.trig[q] = lrec[4 + q];
+}
+
 // Load one observation + its line record and linearise it.  cur selects the parameter buffer.
 // SCALED: apply the Jacobi column scaling (false for the initial evaluation and the test hook).
 template <bool SCALED>
 __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy& pol, const double* camtab,
                                                const double* camscale, const signed char* camcf, int ls, int j, int k, int o0, bool line_ok,
-                                               int lflags, int cur, int safe_obs, LaneLin& L, double (&ob)[8]) {
+                                               int lflags, int cur, int safe_obs, LaneLin& L, double (&ob)[8],
+                                               const ObsPref* pf = nullptr) {
   L.valid = line_ok && j < k;
-  const int o = L.valid ? o0 + j : safe_obs;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {     // (x,y) endpoint pairs: one 16-byte load per plane
-    const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
-    ob[2 * q] = e.x; ob[2 * q + 1] = e.y;
-  }
-  L.cam = p.ob_cam[o];
   const int lsafe = line_ok ? ls : 0;
-  const double* lrec = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
   double trig[7];
+  if (pf) {
 #pragma unroll
-  for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
+    for (int q = 0; q < 8; ++q) ob[q] = pf->ob[q];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) trig[q] = pf->trig[q];
+    L.cam = pf->cam;
+  } else {
+    const int o = L.valid ? o0 + j : safe_obs;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {     // (x,y) endpoint pairs: one 16-byte load per plane
+      const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
+      ob[2 * q] = e.x; ob[2 * q + 1] = e.y;
+    }
+    L.cam = p.ob_cam[o];
+    const double* lrec = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
+  }
   L.line_free = line_ok && !(lflags & 1);
   const double* ct = camtab + L.cam * kCamTab;
   double R[9], JL[9], t[3];
@@ -367,15 +399,18 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
   double acc_cost = 0.0, acc_fixed = 0.0, acc_gmax = 0.0, acc_xn2 = 0.0;
   int fail = 0;
   TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
+  ObsPref pfn;
+  prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
     const TileCtx tc = nxt;
+    const ObsPref pf = pfn;
     nxt = fetch_tile(p, t + 1, ck.tile_end, lane);      // in flight while this tile is processed
     const int width = 1 << tc.glog2;
     const int j = tc.j, ls = tc.ls, o0 = tc.o0, k = tc.k;
     const bool line_ok = tc.line_ok;
     LaneLin L;
     double ob[8];
-    lane_linearise<!INIT>(p, pol, camtab, camscale, camcf, ls, j, k, o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob);
+    lane_linearise<!INIT>(p, pol, camtab, camscale, camcf, ls, j, k, o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob, &pf);
     if (L.kept) acc_cost += L.cost;
     if (INIT && L.valid && !L.kept) acc_fixed += L.cost;
 
@@ -403,6 +438,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
           lds_add(&rec[kRecH + a], ha);
         }
       }
+      prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
       continue;
     }
 
@@ -465,6 +501,11 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
         }
       }
     }
+
+    // the next tile's observation, camera id and line table: requested now (J_c, J_l are dead), used at the top of
+    // the next iteration; the scheduling barrier keeps the loads from sinking to their first use
+    prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- off-diagonal camera pairs of the tile, balanced over the lanes
     for (int base_it = 0; base_it < tc.nitems; base_it += 64) {
