@@ -221,20 +221,17 @@ __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy&
 enum { kBsTab = 19 };
 __device__ __forceinline__ void lane_linearise_bs(const BatchPtrs& p, const Policy& pol, const double* bstab,
                                                   const signed char* camcf, int ls, int j, int k, int o0, bool line_ok,
-                                                  int lflags, int cur, int safe_obs, LaneLin& L, double (&ob)[8], double (&jy)[4]) {
+                                                  int lflags, int cur, int safe_obs, LaneLin& L, double (&ob)[8], double (&jy)[4],
+                                                  const ObsPref& pf) {
+  (void)o0; (void)cur; (void)safe_obs;
   L.valid = line_ok && j < k;
-  const int o = L.valid ? o0 + j : safe_obs;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
-    ob[2 * q] = e.x; ob[2 * q + 1] = e.y;
-  }
-  L.cam = p.ob_cam[o];
   const int lsafe = line_ok ? ls : 0;
-  const double* lrec = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
   double trig[7];
 #pragma unroll
-  for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
+  for (int q = 0; q < 8; ++q) ob[q] = pf.ob[q];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) trig[q] = pf.trig[q];
+  L.cam = pf.cam;
   L.line_free = line_ok && !(lflags & 1);
   const double* ct = bstab + L.cam * kBsTab;
   double R[9], t[3], vw[3], yt[3];
@@ -916,15 +913,18 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
 
   double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0, acc_cost = 0.0;
   TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
+  ObsPref pfn;
+  prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
     const TileCtx tc = nxt;
+    const ObsPref pf = pfn;
     nxt = fetch_tile(p, t + 1, ck.tile_end, lane);
     const int width = 1 << tc.glog2;
     const int j = tc.j, ls = tc.ls, k = tc.k;
     const bool line_ok = tc.line_ok;
     LaneLin L;
     double ob[8], jy[4];
-    lane_linearise_bs(p, pol, bstab, camcf, ls, j, k, tc.o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob, jy);
+    lane_linearise_bs(p, pol, bstab, camcf, ls, j, k, tc.o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob, jy, pf);
     double H[10], g[4];
     line_block(L, width, H, g);
     const bool line_active = L.line_free && k > 0;
@@ -935,6 +935,9 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
       for (int a = 0; a < 4; ++a) wv[a] = L.Jl[a] * jy[0] + L.Jl[4 + a] * jy[1] + L.Jl[8 + a] * jy[2] + L.Jl[12 + a] * jy[3];
     }
     group_sum_n<4>(wv, width);
+    // the next tile's loads go out here (the Jacobian is dead), see prefetch_obs
+    prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
+    __builtin_amdgcn_sched_barrier(0);
     // every lane of the group holds the same H, g, w: all of them take the step (the candidate
     // parameters are needed by every lane below); lane 0 of the group writes and accumulates
     const int lsafe = line_ok ? ls : 0;
