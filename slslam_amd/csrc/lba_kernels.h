@@ -476,6 +476,8 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       for (int q = 0; q < 4; ++q) { le[10 + q] = u[q]; le[14 + q] = D2[q]; le[18 + q] = g[q]; }
     }
 
+    prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
+    __builtin_amdgcn_sched_barrier(0);
     if (cam_free) {
       double* rec = S + L.cf * kCamAcc;
 #pragma unroll
@@ -498,11 +500,6 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
         }
       }
     }
-
-    // the next tile's observation, camera id and line table: requested now (J_c, J_l are dead), used at the top of
-    // the next iteration; the scheduling barrier keeps the loads from sinking to their first use
-    prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
-    __builtin_amdgcn_sched_barrier(0);
 
     // ---- off-diagonal camera pairs of the tile, balanced over the lanes
     for (int base_it = 0; base_it < tc.nitems; base_it += 64) {
