@@ -131,8 +131,11 @@ __device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_e
 struct ObsPref {
   double ob[8];
   double trig[7];
+  double lsc[4];      // Jacobi scale of the line's columns
+  double u[4];        // the line's parameters (back-substitution only)
   int cam;
 };
+template <bool WITH_U>
 __device__ __forceinline__ void prefetch_obs(const BatchPtrs& p, const TileCtx& c, int cur, int safe_obs, ObsPref& f) {
   const bool valid = c.line_ok && c.j < c.k;
   const int o = valid ? c.o0 + c.j : safe_obs;
@@ -146,6 +149,13 @@ __device__ __forceinline__ void prefetch_obs(const BatchPtrs& p, const TileCtx& 
   const double* lrec = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
 #pragma unroll
   for (int q = 0; q < 7; ++q) f.trig[q] = lrec[4 + q];
+  const double* ls = p.line_scale + (long long)lsafe * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) f.lsc[q] = ls[q];
+  if (WITH_U) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f.u[q] = lrec[q];
+  }
 }
 
 // Load one observation + its line record and linearise it.  cur selects the parameter buffer.
@@ -194,7 +204,7 @@ __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy&
 #pragma unroll
   for (int q = 0; q < 4; ++q) L.rs[q] = r[q] * sr;
   if (SCALED) {
-    const double* lsc = p.line_scale + (long long)lsafe * 4;
+    const double* lsc = pf ? pf->lsc : p.line_scale + (long long)lsafe * 4;
     double sc[6], sl[4];
 #pragma unroll
     for (int a = 0; a < 6; ++a) sc[a] = cs[a] * sr;
@@ -246,10 +256,9 @@ __device__ __forceinline__ void lane_linearise_bs(const BatchPtrs& p, const Poli
   obs_linearise_jy<double>(R, t, vw, yt, cp, dv, dcp, ddv, ob, pol.baseline, r, jy, L.Jl);
   const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
   const double sr = huber_scale<double>(s, pol.huber_delta, &L.cost);
-  const double* lsc = p.line_scale + (long long)lsafe * 4;
   double sl[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) sl[a] = lsc[a] * sr;
+  for (int a = 0; a < 4; ++a) sl[a] = pf.lsc[a] * sr;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     L.rs[q] = r[q] * sr;
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
   int fail = 0;
   TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
   ObsPref pfn;
-  prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
+  prefetch_obs<false>(p, nxt, cur, wd.obs_off, pfn);
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
     const TileCtx tc = nxt;
     const ObsPref pf = pfn;
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
           lds_add(&rec[kRecH + a], ha);
         }
       }
-      prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
+      prefetch_obs<false>(p, nxt, cur, wd.obs_off, pfn);
       continue;
     }
 
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       for (int q = 0; q < 4; ++q) { le[10 + q] = u[q]; le[14 + q] = D2[q]; le[18 + q] = g[q]; }
     }
 
-    prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
+    prefetch_obs<false>(p, nxt, cur, wd.obs_off, pfn);
     __builtin_amdgcn_sched_barrier(0);
     if (cam_free) {
       double* rec = S + L.cf * kCamAcc;
@@ -911,7 +920,7 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
   double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0, acc_cost = 0.0;
   TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
   ObsPref pfn;
-  prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
+  prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
     const TileCtx tc = nxt;
     const ObsPref pf = pfn;
@@ -933,13 +942,12 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
     }
     group_sum_n<4>(wv, width);
     // the next tile's loads go out here (the Jacobian is dead), see prefetch_obs
-    prefetch_obs(p, nxt, cur, wd.obs_off, pfn);
+    prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
     __builtin_amdgcn_sched_barrier(0);
     // every lane of the group holds the same H, g, w: all of them take the step (the candidate
     // parameters are needed by every lane below); lane 0 of the group writes and accumulates
     const int lsafe = line_ok ? ls : 0;
-    const double* xl = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
-    double xn[4] = { xl[0], xl[1], xl[2], xl[3] };
+    double xn[4] = { pf.u[0], pf.u[1], pf.u[2], pf.u[3] };
     const bool head = line_ok && j == 0;
     if (line_active) {
       double D2[4], K[10];
@@ -956,9 +964,8 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
       y[1] = K[2] * z1 + K[4] * z2 + K[7] * z3;
       y[2] = K[5] * z2 + K[8] * z3;
       y[3] = K[9] * z3;
-      const double* lsc = p.line_scale + (long long)lsafe * 4;
       for (int a = 0; a < 4; ++a) {
-        const double v = xn[a] - y[a] * lsc[a];
+        const double v = xn[a] - y[a] * pf.lsc[a];
         const double dd = xn[a] - v;
         if (head) {
           acc_model += 0.5 * y[a] * (g[a] + D2[a] * y[a]);
