@@ -134,9 +134,10 @@ struct ObsPref {
   double lsc[4];      // Jacobi scale of the line's columns
   double u[4];        // the line's parameters (back-substitution only)
   int cam;
+  int items01;        // elimination only: this lane's work items of the first two pair passes, (li, lj) bytes x 2
 };
-template <bool WITH_U>
-__device__ __forceinline__ void prefetch_obs(const BatchPtrs& p, const TileCtx& c, int cur, int safe_obs, ObsPref& f) {
+template <bool WITH_U, bool WITH_ITEMS = false>
+__device__ __forceinline__ void prefetch_obs(const BatchPtrs& p, const TileCtx& c, int cur, int safe_obs, ObsPref& f, int lane = 0) {
   const bool valid = c.line_ok && c.j < c.k;
   const int o = valid ? c.o0 + c.j : safe_obs;
 #pragma unroll
@@ -155,6 +156,11 @@ __device__ __forceinline__ void prefetch_obs(const BatchPtrs& p, const TileCtx& 
   if (WITH_U) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) f.u[q] = lrec[q];
+  }
+  if (WITH_ITEMS) {
+    const unsigned short* it16 = reinterpret_cast<const unsigned short*>(p.items);     // one item = 2 bytes (li, lj)
+    const int i0 = lane < c.nitems ? c.item_off + lane : 0, i1 = 64 + lane < c.nitems ? c.item_off + 64 + lane : 0;
+    f.items01 = (int)it16[i0] | ((int)it16[i1] << 16);
   }
 }
 
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
   int fail = 0;
   TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
   ObsPref pfn;
-  prefetch_obs<false>(p, nxt, cur, wd.obs_off, pfn);
+  prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
     const TileCtx tc = nxt;
     const ObsPref pf = pfn;
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
           lds_add(&rec[kRecH + a], ha);
         }
       }
-      prefetch_obs<false>(p, nxt, cur, wd.obs_off, pfn);
+      prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
       continue;
     }
 
@@ -461,8 +467,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       u[2] = K[3] * g[0] + K[4] * g[1] + K[5] * g[2];
       u[3] = K[6] * g[0] + K[7] * g[1] + K[8] * g[2] + K[9] * g[3];
       if (line_ok && j == 0) {
-        const double* lsc = p.line_scale + (long long)ls * 4;
-        for (int a = 0; a < 4; ++a) acc_gmax = fmax(acc_gmax, fabs(g[a] / lsc[a]));
+        for (int a = 0; a < 4; ++a) acc_gmax = fmax(acc_gmax, fabs(g[a] / pf.lsc[a]));
       }
     }
     const bool cam_free = L.valid && L.cf >= 0;
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       for (int q = 0; q < 4; ++q) { le[10 + q] = u[q]; le[14 + q] = D2[q]; le[18 + q] = g[q]; }
     }
 
-    prefetch_obs<false>(p, nxt, cur, wd.obs_off, pfn);
+    prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
     __builtin_amdgcn_sched_barrier(0);
     if (cam_free) {
       double* rec = S + L.cf * kCamAcc;
@@ -515,7 +520,12 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       const int it = base_it + lane;
       const bool has = it < tc.nitems;
       int li = 0, lj = 0;
-      if (has) { li = p.items[2 * (long long)(tc.item_off + it)]; lj = p.items[2 * (long long)(tc.item_off + it) + 1]; }
+      if (base_it < 128) {                          // the first two passes' items came with the tile's request
+        const int w16 = base_it == 0 ? (pf.items01 & 0xffff) : ((pf.items01 >> 16) & 0xffff);
+        if (has) { li = w16 & 0xff; lj = w16 >> 8; }
+      } else if (has) {
+        li = p.items[2 * (long long)(tc.item_off + it)]; lj = p.items[2 * (long long)(tc.item_off + it) + 1];
+      }
       double Fi[24], Fj[24];
 #pragma unroll
       for (int q = 0; q < 24; ++q) { Fi[q] = __shfl(F[q], li); Fj[q] = __shfl(F[q], lj); }
