@@ -312,7 +312,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if ((rc = b->d_cost_part.alloc(std::max<size_t>(1, (size_t)b->nchunk)))) return rc;
   if ((rc = b->d_ysys.alloc(std::max<size_t>(1, (size_t)sys)))) return rc;
   if ((rc = b->d_fstore.alloc(b->opt.reuse_elimination ? (size_t)24 * (size_t)std::max<long long>(1, nobs) : 2))) return rc;
-  if ((rc = b->d_line_elim.alloc(b->opt.reuse_elimination ? std::max<size_t>(1, (size_t)nline * kLineElim) : 1))) return rc;
+  if ((rc = b->d_line_elim.alloc(std::max<size_t>(1, (size_t)nline * kLineElim)))) return rc;
   if ((rc = b->d_params_out.alloc(std::max<size_t>(1, (size_t)param_off)))) return rc;
   if ((rc = b->d_state.upload(b->h_state0))) return rc;
   if ((rc = b->d_trace.alloc(std::max<size_t>(1, (size_t)B * kMaxTrace)))) return rc;

@@ -482,12 +482,18 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       for (int q = 0; q < 12; ++q)
         reinterpret_cast<double2*>(p.fstore)[(long long)q * p.ob_stride + o] = make_double2(F[2 * q], F[2 * q + 1]);
     }
-    if (pol.store_f && line_active && j == 0) {
+    // the per-line factor is kept for the back-substitution of the same iteration (176 B per line against
+    // ~500 B of observations): it does not have to rebuild and refactor the 4x4 block
+    if (line_active && j == 0) {
       double* le = p.line_elim + (long long)ls * kLineElim;
 #pragma unroll
       for (int q = 0; q < 10; ++q) le[q] = K[q];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { le[10 + q] = u[q]; le[14 + q] = D2[q]; le[18 + q] = g[q]; }
+      for (int q = 0; q < 4; ++q) { le[14 + q] = D2[q]; le[18 + q] = g[q]; }
+      if (pol.store_f) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) le[10 + q] = u[q];      // only the streaming back-substitution wants K g
+      }
     }
 
     prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
@@ -892,7 +898,6 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
   const LMState* st = p.state + ck.win;
   if (st->status != kRunning) return;
   const int cur = st->cur;
-  const double radius = st->radius;
   const int n = wd.n;
   double* bstab = smem;
   double* candtab = bstab + wd.C * kBsTab;
@@ -938,11 +943,19 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
     const int width = 1 << tc.glog2;
     const int j = tc.j, ls = tc.ls, k = tc.k;
     const bool line_ok = tc.line_ok;
+    // what the elimination kernel kept for this line at this linearisation point and radius: K = chol(H_ll + D^2)^-1,
+    // D^2, g_l (the same values this sweep would recompute); every lane of the line's group reads the same record
+    double K[10], D2[4], g[4];
+    {
+      const double* le = p.line_elim + (long long)(tc.line_ok ? tc.ls : 0) * kLineElim;
+#pragma unroll
+      for (int q = 0; q < 10; ++q) K[q] = le[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { D2[q] = le[14 + q]; g[q] = le[18 + q]; }
+    }
     LaneLin L;
     double ob[8], jy[4];
     lane_linearise_bs(p, pol, bstab, camcf, ls, j, k, tc.o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob, jy, pf);
-    double H[10], g[4];
-    line_block(L, width, H, g);
     const bool line_active = L.line_free && k > 0;
     // w = sum_i (Jc_i^T Jl_i)^T y_c[cam_i] = sum_i Jl_i^T (Jc_i y_c)
     double wv[4] = { 0, 0, 0, 0 };
@@ -960,9 +973,6 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
     double xn[4] = { pf.u[0], pf.u[1], pf.u[2], pf.u[3] };
     const bool head = line_ok && j == 0;
     if (line_active) {
-      double D2[4], K[10];
-      lm_diag4(H, pol, radius, D2);
-      chol4_inverse(H, D2, K);
       // z = K (g - w);  y = K^T z
       const double e0 = g[0] - wv[0], e1 = g[1] - wv[1], e2 = g[2] - wv[2], e3 = g[3] - wv[3];
       const double z0 = K[0] * e0;
