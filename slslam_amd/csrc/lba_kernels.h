@@ -335,10 +335,11 @@ __device__ __forceinline__ bool chol4_inverse(const double H[10], const double D
   return ok && isfinite(d3) && isfinite(i3);
 }
 
-__device__ __forceinline__ void lm_diag4(const double H[10], const Policy& pol, double radius, double D2[4]) {
+// inv_radius = 1 / radius, computed once per wave: four fp64 divisions per tile would cost ~50 instructions
+__device__ __forceinline__ void lm_diag4(const double H[10], const Policy& pol, double inv_radius, double D2[4]) {
   const double d[4] = { H[0], H[2], H[5], H[9] };
 #pragma unroll
-  for (int a = 0; a < 4; ++a) D2[a] = fmin(fmax(d[a], pol.min_lm_diagonal), pol.max_lm_diagonal) / radius;
+  for (int a = 0; a < 4; ++a) D2[a] = fmin(fmax(d[a], pol.min_lm_diagonal), pol.max_lm_diagonal) * inv_radius;
 }
 
 // F = (Jc^T Jl) K^T  (6x4, row-major):  the line's share of the elimination, so that
@@ -399,6 +400,8 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
   if (st->status != kRunning) return;
   const int cur = st->cur;
   const double radius = st->radius;
+  const double inv_radius = 1.0 / radius;
+  const bool need_grad = st->need_grad_check != 0;
   const int n = wd.n, ncf = n / 6, nsys = sys_doubles(n);
   double* camtab = smem;
   double* camscale = camtab + wd.C * kCamTab;
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
 
     // ---- eliminate the line: A = H + D^2, A^-1 = K^T K
     double D2[4], K[10], u[4] = { 0, 0, 0, 0 }, F[24];
-    lm_diag4(H, pol, radius, D2);
+    lm_diag4(H, pol, inv_radius, D2);
     bool okc = true;
     if (line_active) okc = chol4_inverse(H, D2, K);
     else { for (int q = 0; q < 10; ++q) K[q] = 0.0; }
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       u[1] = K[1] * g[0] + K[2] * g[1];
       u[2] = K[3] * g[0] + K[4] * g[1] + K[5] * g[2];
       u[3] = K[6] * g[0] + K[7] * g[1] + K[8] * g[2] + K[9] * g[3];
-      if (line_ok && j == 0) {
+      if (need_grad && line_ok && j == 0) {       // only the launch after an accepted step tests the gradient
         for (int a = 0; a < 4; ++a) acc_gmax = fmax(acc_gmax, fabs(g[a] / pf.lsc[a]));
       }
     }
