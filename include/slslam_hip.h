@@ -197,6 +197,14 @@ typedef struct slslam_po_graph {
 int slslam_po_solve(const slslam_po_graph* graph, const slslam_solver_options* opt,
                     slslam_summary* summary, slslam_iteration* trace, int trace_cap, int* trace_len);
 
+/* The symbolic analysis behind the structured pose-graph factorisation (host only, no device needed), for
+ * inspection and tests: slot[N] = offset of each pose in the reduced vector (-1: the constant pose of edge 0 or a
+ * pose no edge references), chains first, junction poses last; chain_start / chain_len / chain_left / chain_right
+ * [*num_chains, capacity max_chains] describe the chains (left / right = slot of the junction at that end, -1 when
+ * free).  Returns SLSLAM_ERR_INVALID_ARGUMENT on malformed graphs, SLSLAM_ERR_UNSUPPORTED if max_chains is too small. */
+int slslam_po_structure(const slslam_po_graph* graph, int* slot, int max_chains, int* num_chains, int* chain_start,
+                        int* chain_len, int* chain_left, int* chain_right, int* num_chain_unknowns, int* num_unknowns);
+
 /* ------------------------------------------------------------------ RANSAC hypothesis scoring
  * (the per-frame cost centre next to the hot path.)
  * Replaces: the scoring loop of SLAM::ransac_motion (reference src/slam.cpp:396-413) with

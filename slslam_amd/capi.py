@@ -82,7 +82,7 @@ EXPORTS = [
     "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
-    "slslam_po_solve", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_device_count", "slslam_version", "slslam_status_string",
+    "slslam_po_solve", "slslam_po_structure", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_device_count", "slslam_version", "slslam_status_string",
 ]
 
 _lib = None
@@ -121,6 +121,7 @@ def lib():
     L.slslam_po_solve.argtypes = [C.POINTER(POGraph), C.POINTER(SolverOptions), C.POINTER(Summary),
                                   C.POINTER(Iteration), C.c_int, ip]
     L.slslam_ransac_score.argtypes = [C.POINTER(RansacFrame), C.c_double, C.c_double, ip, C.POINTER(C.c_ulonglong)]
+    L.slslam_po_structure.argtypes = [C.POINTER(POGraph), ip, C.c_int, ip, ip, ip, ip, ip, ip, ip]
     L.slslam_ransac_generate.argtypes = [C.POINTER(RansacTrials), C.c_double, dp, ip]
     L.slslam_ransac_motion.argtypes = [C.POINTER(RansacTrials), dp, C.c_double, C.c_double, C.c_double, C.c_int, ip, ip, dp,
                                        C.POINTER(C.c_ulonglong)]
@@ -374,3 +375,20 @@ def ransac_motion(obs0, obs1, lines, samples, baseline=0.12, error_thr=5.0 / 406
         n = min(64, k - 64 * w)
         mask[64 * w:64 * w + n] = ((bits[w] >> np.arange(n, dtype=np.uint64)) & np.uint64(1)).astype(bool)
     return int(tc[0]), int(bs[0]), pose, mask
+
+
+def po_structure(g, max_chains=4096):
+    """Symbolic analysis of the structured pose-graph factorisation (slslam_po_structure; host only).
+    Returns dict(slot [N], chains [(start, len, left, right)], num_chain_unknowns, num_unknowns)."""
+    i1 = np.ascontiguousarray(g["pose_index_1"], dtype=np.int32)
+    i2 = np.ascontiguousarray(g["pose_index_2"], dtype=np.int32)
+    n = int(g["num_poses"])
+    cg = POGraph(n, len(i1), _ip(i1), _ip(i2), None, None)
+    slot = np.zeros(max(n, 1), dtype=np.int32)
+    arr = [np.zeros(max_chains, dtype=np.int32) for _ in range(4)]
+    nc, ncu, nu = (np.zeros(1, dtype=np.int32) for _ in range(3))
+    _check(lib().slslam_po_structure(C.byref(cg), _ip(slot), max_chains, _ip(nc), _ip(arr[0]), _ip(arr[1]), _ip(arr[2]), _ip(arr[3]),
+                                     _ip(ncu), _ip(nu)), "slslam_po_structure")
+    k = int(nc[0])
+    return {"slot": slot[:n], "chains": [tuple(int(a[c]) for a in arr) for c in range(k)],
+            "num_chain_unknowns": int(ncu[0]), "num_unknowns": int(nu[0])}

@@ -315,3 +315,32 @@ done:
   (void)hipFree(arena);
   return rc;
 }
+
+
+extern "C" int slslam_po_structure(const slslam_po_graph* g, int* slot_out, int max_chains, int* num_chains, int* chain_start,
+                                   int* chain_len, int* chain_left, int* chain_right, int* num_chain_unknowns, int* num_unknowns) {
+  if (!g || !slot_out || !num_chains || g->num_poses < 0 || g->num_edges < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
+  const int N = g->num_poses, E = g->num_edges;
+  if (E > 0 && (!g->pose_index_1 || !g->pose_index_2)) return SLSLAM_ERR_INVALID_ARGUMENT;
+  for (int e = 0; e < E; ++e) {
+    const int a = g->pose_index_1[e], b = g->pose_index_2[e];
+    if (a < 0 || a >= N || b < 0 || b >= N || a == b) return SLSLAM_ERR_INVALID_ARGUMENT;
+  }
+  std::vector<int> slot(N, -1), used(N, 0);
+  for (int e = 0; e < E; ++e) { used[g->pose_index_1[e]] = 1; used[g->pose_index_2[e]] = 1; }
+  std::vector<PoChain> chains;
+  int n_chain = 0, n = 0;
+  if (E > 0) order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, g->pose_index_1[0], slot, chains, &n_chain, &n);
+  for (int k = 0; k < N; ++k) slot_out[k] = slot[k];
+  *num_chains = (int)chains.size();
+  if (num_chain_unknowns) *num_chain_unknowns = n_chain;
+  if (num_unknowns) *num_unknowns = n;
+  if ((int)chains.size() > max_chains) return SLSLAM_ERR_UNSUPPORTED;
+  for (size_t c = 0; c < chains.size(); ++c) {
+    if (chain_start) chain_start[c] = chains[c].start;
+    if (chain_len) chain_len[c] = chains[c].len;
+    if (chain_left) chain_left[c] = chains[c].jl;
+    if (chain_right) chain_right[c] = chains[c].jr;
+  }
+  return SLSLAM_OK;
+}

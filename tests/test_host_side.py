@@ -236,3 +236,76 @@ def test_argument_validation_comes_before_the_device():
     assert status(capi.ransac_motion, fr["obs0"], fr["obs1"], fr["lines"], fr["samples"]) == ok
     poses, obs, lines, _ = synth.make_ransac_frame(1, num_lines=10, num_hypotheses=3)
     assert status(capi.ransac_score, poses, obs, lines) == ok
+
+
+def _check_po_structure(g, st):
+    """invariants of the chains-first ordering (slslam_po_structure)"""
+    N = int(g["num_poses"])
+    gauge = int(g["pose_index_1"][0])
+    used = np.zeros(N, bool)
+    used[g["pose_index_1"]] = True; used[g["pose_index_2"]] = True
+    free = used.copy(); free[gauge] = False
+    slot = st["slot"]
+    assert np.array_equal(slot >= 0, free)
+    assert sorted(slot[free]) == list(range(0, 6 * int(free.sum()), 6)) and st["num_unknowns"] == 6 * int(free.sum())
+    pose_of = {int(s): k for k, s in enumerate(slot) if s >= 0}
+    adj = {k: set() for k in range(N) if free[k]}
+    for a, b in zip(g["pose_index_1"], g["pose_index_2"]):
+        a, b = int(a), int(b)
+        if free[a] and free[b]:
+            adj[a].add(b); adj[b].add(a)
+    in_chain = {}
+    covered = 0
+    for ci, (start, ln, left, right) in enumerate(st["chains"]):
+        assert 1 <= ln <= 32 and start == covered                      # chains are laid out back to back, cut at 32 poses
+        covered += 6 * ln
+        poses = [pose_of[start + 6 * i] for i in range(ln)]
+        for i, v in enumerate(poses):
+            in_chain[v] = ci
+            nb = set(adj[v])
+            if i > 0:
+                assert poses[i - 1] in nb; nb.discard(poses[i - 1])     # consecutive poses of a chain are connected
+            if i + 1 < ln:
+                assert poses[i + 1] in nb; nb.discard(poses[i + 1])
+            ends = set()
+            if i == 0 and left >= 0:
+                ends.add(pose_of[left])
+            if i == ln - 1 and right >= 0:
+                ends.add(pose_of[right])
+            assert nb == ends, (v, nb, ends)                            # every other neighbour is the junction at that end
+        for j in (left, right):
+            assert j < 0 or j >= st["num_chain_unknowns"]               # junction slots come after all chain slots
+        assert left < 0 or left != right
+    assert covered == st["num_chain_unknowns"]
+    for k in range(N):                                                  # what is not on a chain is a junction
+        if free[k] and k not in in_chain:
+            assert slot[k] >= st["num_chain_unknowns"]
+
+
+def test_po_structure_topologies():
+    """Host-side symbolic analysis of the structured pose-graph factorisation, no device needed."""
+    from slslam_amd import capi
+    rng = np.random.default_rng(3)
+
+    def graph(n, extra):
+        p1 = list(range(n - 1)) + [min(a, b) for a, b in extra]
+        p2 = list(range(1, n)) + [max(a, b) for a, b in extra]
+        order = sorted(range(len(p1)), key=lambda i: (p1[i], p2[i]))
+        return {"num_poses": n, "pose_index_1": np.array([p1[i] for i in order], dtype=np.int32),
+                "pose_index_2": np.array([p2[i] for i in order], dtype=np.int32)}
+    cases = [graph(50, []), graph(30, [(1, 29)]), graph(30, [(5, 14), (5, 20)]), graph(40, [(10, k) for k in (15, 20, 25, 30, 35, 39)]),
+             graph(120, [(3, 110), (7, 100)]), graph(60, [(i, i + 7) for i in range(1, 50, 3)]), graph(2, []), graph(300, [])]
+    for _ in range(20):
+        n = int(rng.integers(3, 200))
+        extra = [tuple(sorted(rng.choice(n, 2, replace=False))) for _ in range(int(rng.integers(0, 12)))]
+        cases.append(graph(n, [e for e in extra if e[1] - e[0] > 1]))
+    for g in cases:
+        _check_po_structure(g, capi.po_structure(g))
+    st = capi.po_structure(graph(300, []))
+    assert len(st["chains"]) == 10 and st["num_unknowns"] - st["num_chain_unknowns"] == 6 * 9      # 299 free poses: cut every 32
+    # malformed graphs
+    bad = graph(5, [])
+    bad["pose_index_2"] = bad["pose_index_2"].copy(); bad["pose_index_2"][1] = 7
+    with pytest.raises(capi.SlslamError) as e:
+        capi.po_structure(bad)
+    assert e.value.status == 1
