@@ -546,10 +546,10 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
           for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
-              double v = 0.0;
+              double v = 0.0;                       // - F_j F_i^T: the sign rides on the fma's operand modifier
 #pragma unroll
-              for (int m = 0; m < 4; ++m) v += Fj[4 * a + m] * Fi[4 * b + m];
-              lds_add(&blk[6 * a + b], -v);
+              for (int m = 0; m < 4; ++m) v -= Fj[4 * a + m] * Fi[4 * b + m];
+              lds_add(&blk[6 * a + b], v);
             }
         } else {               // the same camera observes the line twice: symmetric part
           for (int a = 0; a < 6; ++a)
