@@ -402,6 +402,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
   const double radius = st->radius;
   const double inv_radius = 1.0 / radius;
   const bool need_grad = st->need_grad_check != 0;
+  const bool same_point = !INIT && st->same_point != 0;   // g_c and diag(J_c^T J_c) in the slab are still those of this point
   const int n = wd.n, ncf = n / 6, nsys = sys_doubles(n);
   double* camtab = smem;
   double* camscale = camtab + wd.C * kCamTab;
@@ -509,8 +510,10 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ga += L.Jc[6 * r + a] * L.rs[r]; ha += L.Jc[6 * r + a] * L.Jc[6 * r + a]; }
         const double fu = F[4 * a] * u[0] + F[4 * a + 1] * u[1] + F[4 * a + 2] * u[2] + F[4 * a + 3] * u[3];
-        lds_add(&rec[kRecG + a], ga);
-        lds_add(&rec[kRecH + a], ha);
+        if (!same_point) {
+          lds_add(&rec[kRecG + a], ga);
+          lds_add(&rec[kRecH + a], ha);
+        }
         lds_add(&rec[kRecB + a], ga - fu);
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
@@ -565,7 +568,11 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
 
   __syncthreads();
   double* slab = p.slab + ck.slab_off;
-  for (int q = lane; q < nsys; q += 64) slab[q] = S[q];
+  for (int q = lane; q < nsys; q += 64) {
+    // after a rejected step the gradient / column-norm entries of the camera records were not accumulated: keep the slab's
+    if (same_point && q < ncf * kCamAcc && (q % kCamAcc) >= kRecG) continue;
+    slab[q] = S[q];
+  }
   const double c_sum = wave_sum(acc_cost), f_sum = wave_sum(acc_fixed), x_sum = wave_sum(acc_xn2);
   const double g_max = wave_max(acc_gmax);
   const int any_fail = __any(fail);
@@ -1300,7 +1307,9 @@ __global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol) {
     st->cost = new_cost;
     st->x_norm = sqrt(xn2);
     st->need_grad_check = 1;      // the next linearisation supplies the gradient at the new point
+    st->same_point = 0;
   } else {
+    st->same_point = 1;           // only the radius changes: gradient and column norms of the cameras stay valid
     st->n_unsuccess++;
     if (rec.step_is_valid) { st->radius = st->radius / st->decrease_factor; st->decrease_factor *= 2.0; }
     else st->radius *= 0.5;
@@ -1369,7 +1378,7 @@ __global__ __launch_bounds__(256) void k_reset(BatchPtrs p, Policy pol) {
     z.radius = pol.initial_radius; z.decrease_factor = 2.0; z.cost = 0; z.x_norm = 0; z.fixed_cost = 0;
     z.initial_cost = 0; z.min_cost = 0; z.abs_grad_tol = 0; z.grad_max = 0; z.cam_model = 0; z.cam_dn2 = 0; z.cam_xn2 = 0;
     z.status = kRunning; z.cur = 0; z.iter = 0; z.n_success = 0; z.n_unsuccess = 0; z.n_invalid = 0;
-    z.solve_failed = 0; z.need_grad_check = 0; z.ntrace = 0; z.pad = 0;
+    z.solve_failed = 0; z.need_grad_check = 0; z.ntrace = 0; z.same_point = 0;
     *st = z;
   }
 }

@@ -73,7 +73,7 @@ struct LMState {
   int solve_failed;
   int need_grad_check;      // gradient at the accepted point not yet tested
   int ntrace;
-  int pad;
+  int same_point;           // the last step was rejected: the next linearisation is at the same point (new radius only)
 };
 
 struct IterRec {            // same fields as slslam_iteration
