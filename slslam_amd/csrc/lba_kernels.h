@@ -1,23 +1,23 @@
 // slslam_amd/csrc/lba_kernels.h — hand-written CDNA4 (gfx950) kernels of the batched line
-// bundle adjustment.  One LM iteration of every window of the batch is six launches:
+// bundle adjustment.  One LM iteration of every window of the batch is four launches:
 //
 //   k_linearise_schur  one 64-lane wave per chunk of a window's lines; lane <-> observation,
-//                      a line owns a 2^g-lane group (segmented xor-shuffle reductions), per-wave
-//                      private partial of the reduced camera system in LDS (ds_add_f64)
+//                      a line owns a 2^g-lane group (DPP reductions), per-wave private partial of the
+//                      reduced camera system in LDS (ds_add_f64); keeps each line's 4x4 factor
 //   k_reduced_solve    one workgroup per window: ordered reduction of the chunk partials, LM damping,
 //                      blocked in-LDS Cholesky of the (6 Cf)^2 system on v_mfma_f64_16x16x4_f64,
 //                      candidate camera poses
-//   k_backsub          same sweep as the first kernel, back-substitutes every line, writes the
-//                      candidate line parameters (+ their sin/cos table) and the step statistics and,
-//                      with the observation still in registers, the cost at the candidate point
+//   k_backsub          second sweep over the observations: back-substitutes every line with the kept factor,
+//                      writes the candidate line parameters (+ their sin/cos table) and the step statistics
+//                      and, with the observation still in registers, the cost at the candidate point
 //   k_lm_update        per window: gain ratio, accept/reject, radius update, convergence tests
 //
 // What this replaces: everything ceres::Solve does for the problem LBAProblem::build wires up
 // (reference src/lba_problem.cpp:54-132, call sites src/slam.cpp:663,944).  Ceres evaluates
 // Jet<double,10> functors block by block, forms the sparse normal equations and factors them with
 // CHOLMOD on one thread; here the block structure (4x4 line blocks, 6x4 off-diagonal blocks,
-// 6x6 camera blocks) is exploited directly and nothing but observations and parameters is ever
-// read from HBM: Jacobians are recomputed per sweep instead of stored.
+// 6x6 camera blocks) is exploited directly; Jacobians are recomputed per sweep instead of stored, only the
+// per-line 4x4 factors (144 B per line) travel from the first sweep to the second.
 #ifndef SLSLAM_LBA_KERNELS_H_
 #define SLSLAM_LBA_KERNELS_H_
 
