@@ -31,6 +31,7 @@ from slslam_amd import capi, synth  # noqa: E402
 from slslam_amd.dist import allreduce_summary  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector (and matrix) peak
 
 
 def algorithmic_bytes_linearise(counts):
@@ -38,6 +39,18 @@ def algorithmic_bytes_linearise(counts):
     SURVEY.md 8d per-window figure for one of the three observation sweeps,
     M*(64+8) + L*32 + C*48 + (6 Cf)^2*8, summed over the windows the launch processes."""
     return sum(72 * m + 32 * l + 48 * c + 8 * (6 * cf) ** 2 for (c, cf, l, m) in counts)
+
+
+def algorithmic_flops_linearise(windows):
+    """Algorithmic fp64 flops of ONE launch of the dominant kernel (secondary figure): per
+    observation ~600 (residual + analytic Jacobian) + ~520 (block products), per line 288 k^2 for the Schur outer
+    products over its k free-camera observations."""
+    total = 0.0
+    for w in windows:
+        free_obs = np.asarray(w["fixed_index"]).reshape(-1, 2)[:, 0] == 0
+        kf = np.bincount(np.asarray(w["line_index"])[free_obs], minlength=int(w["num_lines"]))
+        total += 1120.0 * len(w["camera_index"]) + 288.0 * float((kf.astype(np.float64) ** 2).sum())
+    return total
 
 
 def cpu_baseline(windows, budget_s=12.0):
@@ -242,9 +255,15 @@ def main():
                         traffic = tj.get("hbm_bytes_per_launch") * (B / ns) / tj.get("windows")
                 except Exception:
                     traffic = None
+            flops_launch = algorithmic_flops_linearise(windows) / ns
+            tflops = flops_launch / (ms / n * 1e-3) / 1e12
             out["roofline"] = {"bound": "hbm", "kernel": "k_linearise_schur", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": ms / n, "launches": n}
+                               "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": ms / n, "launches": n,
+                               # secondary view: the kernel's arithmetic intensity (~28 flop / algorithmic byte) is above the
+                               # fp64 ridge (78.6 TF / 8 TB/s ~ 10 flop / B), so the vector-fp64 roofline is the nearer one
+                               "fp64_vector": {"algorithmic_flops_per_launch": flops_launch, "achieved": tflops,
+                                               "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS}}
             out["kernel_ms_per_step"] = {k: v[0] / max(args.steps, 1) for k, v in kt.items() if v[1] > 0}
         if world == 1 and not args.no_cpu_baseline:
             v, sample, outs = cpu_baseline(windows)
