@@ -255,6 +255,14 @@ int slslam_ransac_motion(const slslam_ransac_trials* trials, const double* lines
                          double prob_free_outliers, int max_trials, int* best_score_io, int* trial_cnt,
                          double* best_pose, unsigned long long* best_inlier_bits);
 
+/* slslam_ransac_motion for many frames at once (sequence replay, several cameras): one upload, two launches per
+ * frame enqueued back to back, one download.  frames[F], lines[F] (pointer per frame), best_score_io[F] in/out,
+ * trial_cnt[F], best_pose[12 F], best_inlier_bits[F] (pointer per frame; the array or an entry may be NULL). */
+int slslam_ransac_motion_batch(int num_frames, const slslam_ransac_trials* frames, const double* const* lines,
+                               double baseline, double error_thr, double prob_free_outliers, int max_trials,
+                               int* best_score_io, int* trial_cnt, double* best_pose,
+                               unsigned long long* const* best_inlier_bits);
+
 /* ------------------------------------------------------------------ misc */
 int         slslam_device_count(void);          /* 0 when no HIP device is usable */
 const char* slslam_version(void);

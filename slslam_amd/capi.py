@@ -82,7 +82,7 @@ EXPORTS = [
     "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
-    "slslam_po_solve", "slslam_po_structure", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_device_count", "slslam_version", "slslam_status_string",
+    "slslam_po_solve", "slslam_po_structure", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_version", "slslam_status_string",
 ]
 
 _lib = None
@@ -125,6 +125,8 @@ def lib():
     L.slslam_ransac_generate.argtypes = [C.POINTER(RansacTrials), C.c_double, dp, ip]
     L.slslam_ransac_motion.argtypes = [C.POINTER(RansacTrials), dp, C.c_double, C.c_double, C.c_double, C.c_int, ip, ip, dp,
                                        C.POINTER(C.c_ulonglong)]
+    L.slslam_ransac_motion_batch.argtypes = [C.c_int, C.POINTER(RansacTrials), C.POINTER(dp), C.c_double, C.c_double, C.c_double,
+                                             C.c_int, ip, ip, dp, C.POINTER(C.POINTER(C.c_ulonglong))]
     L.slslam_device_count.restype = C.c_int
     L.slslam_version.restype = C.c_char_p
     L.slslam_status_string.argtypes = [C.c_int]
@@ -392,3 +394,34 @@ def po_structure(g, max_chains=4096):
     k = int(nc[0])
     return {"slot": slot[:n], "chains": [tuple(int(a[c]) for a in arr) for c in range(k)],
             "num_chain_unknowns": int(ncu[0]), "num_unknowns": int(nu[0])}
+
+
+def ransac_motion_batch(frames, baseline=0.12, error_thr=5.0 / 406.05, prob_free_outliers=0.999, max_trials=1000):
+    """slslam_ransac_motion_batch: frames = list of dicts with obs0, obs1, lines, samples (as make_ransac_pair returns).
+    Returns a list of (trial_cnt, best_score, best_pose [12], inlier mask [K]) per frame."""
+    n = len(frames)
+    keep, trs, lns, bitbufs = [], (RansacTrials * max(n, 1))(), (C.POINTER(C.c_double) * max(n, 1))(), []
+    bitptrs = (C.POINTER(C.c_ulonglong) * max(n, 1))()
+    for i, fr in enumerate(frames):
+        tr, k = _trials(fr["obs0"], fr["obs1"], fr["samples"])
+        ln = np.ascontiguousarray(fr["lines"], dtype=np.float64).reshape(-1, 6)
+        keep.append((k, ln))
+        trs[i] = tr
+        lns[i] = _dp(ln)
+        bits = np.zeros(max((tr.num_lines + 63) // 64, 1), dtype=np.uint64)
+        bitbufs.append(bits)
+        bitptrs[i] = bits.ctypes.data_as(C.POINTER(C.c_ulonglong))
+    bs = np.zeros(max(n, 1), dtype=np.int32)
+    tc = np.zeros(max(n, 1), dtype=np.int32)
+    poses = np.zeros((max(n, 1), 12))
+    _check(lib().slslam_ransac_motion_batch(n, trs, lns, float(baseline), float(error_thr), float(prob_free_outliers), int(max_trials),
+                                            _ip(bs), _ip(tc), _dp(poses), bitptrs), "slslam_ransac_motion_batch")
+    out = []
+    for i in range(n):
+        k = trs[i].num_lines
+        mask = np.zeros(k, dtype=bool)
+        for w in range((k + 63) // 64):
+            m = min(64, k - 64 * w)
+            mask[64 * w:64 * w + m] = ((bitbufs[i][w] >> np.arange(m, dtype=np.uint64)) & np.uint64(1)).astype(bool)
+        out.append((int(tc[i]), int(bs[i]), poses[i].copy(), mask))
+    return out

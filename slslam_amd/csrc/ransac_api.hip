@@ -356,3 +356,85 @@ extern "C" int slslam_ransac_motion(const slslam_ransac_trials* tr, const double
   }
   return SLSLAM_OK;
 }
+
+
+// Many frames at once (replay of a sequence, several cameras): one device allocation, one upload, two launches
+// per frame enqueued back to back without host synchronisation, one download of every frame's scores, then the
+// per-frame trial loops on the host and one gather of the winners.  Per frame the results are those of
+// slslam_ransac_motion.
+extern "C" int slslam_ransac_motion_batch(int num_frames, const slslam_ransac_trials* frames, const double* const* lines,
+                                          double baseline, double error_thr, double prob_free_outliers, int max_trials,
+                                          int* best_score_io, int* trial_cnt, double* best_pose,
+                                          unsigned long long* const* best_inlier_bits) {
+  if (num_frames < 0 || (num_frames > 0 && (!frames || !lines || !best_score_io || !trial_cnt || !best_pose)))
+    return SLSLAM_ERR_INVALID_ARGUMENT;
+  struct Off { size_t o0, o1, ln, smp, poses, valid, scores, bits; int H, K, s, words; };
+  std::vector<Off> off(num_frames);
+  size_t nd = 0, ni = 0, nb = 0;       // doubles, ints, 64-bit words
+  for (int f = 0; f < num_frames; ++f) {
+    const slslam_ransac_trials& tr = frames[f];
+    if (tr.num_trials < 0 || tr.num_lines < 0 || tr.sample_size < 1 || tr.sample_size > 16) return SLSLAM_ERR_INVALID_ARGUMENT;
+    const int H = tr.num_trials, K = tr.num_lines, s = tr.sample_size;
+    if (H > 0 && K > 0 && (!tr.samples || !tr.observations0 || !tr.observations1 || !lines[f])) return SLSLAM_ERR_INVALID_ARGUMENT;
+    for (long long i = 0; i < (long long)H * s; ++i)
+      if (K == 0 || tr.samples[i] < 0 || tr.samples[i] >= K) return SLSLAM_ERR_INVALID_ARGUMENT;
+    Off& o = off[f];
+    o.H = H; o.K = K; o.s = s; o.words = (K + 63) / 64;
+    o.o0 = nd; nd += 8 * (size_t)K; o.o1 = nd; nd += 8 * (size_t)K; o.ln = nd; nd += 6 * (size_t)K; o.poses = nd; nd += 12 * (size_t)H;
+    o.smp = ni; ni += (size_t)H * s; o.valid = ni; ni += H; o.scores = ni; ni += H;
+    o.bits = nb; nb += (size_t)H * o.words;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SLSLAM_ERR_NO_DEVICE;
+  for (int f = 0; f < num_frames; ++f) trial_cnt[f] = 0;
+  if (num_frames == 0) return SLSLAM_OK;
+  std::vector<double> hd(nd ? nd : 1, 0.0);
+  std::vector<int> hi(ni ? ni : 1, 0);
+  for (int f = 0; f < num_frames; ++f) {
+    const slslam_ransac_trials& tr = frames[f];
+    const Off& o = off[f];
+    if (o.H == 0 || o.K == 0) continue;
+    std::copy(tr.observations0, tr.observations0 + 8 * (size_t)o.K, hd.begin() + o.o0);
+    std::copy(tr.observations1, tr.observations1 + 8 * (size_t)o.K, hd.begin() + o.o1);
+    std::copy(lines[f], lines[f] + 6 * (size_t)o.K, hd.begin() + o.ln);
+    std::copy(tr.samples, tr.samples + (size_t)o.H * o.s, hi.begin() + o.smp);
+  }
+  DevArr<double> dd;
+  DevArr<int> di;
+  DevArr<unsigned long long> db;
+  RM_TRY(dd.alloc(nd)); RM_TRY(di.alloc(ni)); RM_TRY(db.alloc(nb));
+  RM_TRY(hipMemcpy(dd.p, hd.data(), sizeof(double) * hd.size(), hipMemcpyHostToDevice));
+  RM_TRY(hipMemcpy(di.p, hi.data(), sizeof(int) * hi.size(), hipMemcpyHostToDevice));     // scores arrive zeroed
+  for (int f = 0; f < num_frames; ++f) {
+    const Off& o = off[f];
+    if (o.H == 0 || o.K == 0) continue;
+    hipLaunchKernelGGL(k_ransac_generate, dim3((unsigned)((o.H + 63) / 64)), dim3(64), 0, 0, o.H, o.s, di.p + o.smp, dd.p + o.o0,
+                       dd.p + o.o1, -baseline, dd.p + o.poses, di.p + o.valid);
+    hipLaunchKernelGGL(k_ransac_score, dim3((unsigned)o.words, (unsigned)o.H), dim3(64), 0, 0, o.H, o.K, o.words, dd.p + o.poses,
+                       dd.p + o.o1, dd.p + o.ln, baseline, error_thr, di.p + o.scores, db.p + o.bits, (const int*)(di.p + o.valid));
+  }
+  RM_TRY(hipGetLastError());
+  RM_TRY(hipMemcpy(hi.data(), di.p, sizeof(int) * hi.size(), hipMemcpyDeviceToHost));
+  for (int f = 0; f < num_frames; ++f) {
+    const Off& o = off[f];
+    if (o.H == 0 || o.K == 0) continue;
+    const int* scores = hi.data() + o.scores;
+    int best = best_score_io[f], best_h = -1, ransac_trial = o.K, t = 0;
+    for (; t < ransac_trial && t <= max_trials && t < o.H; ++t) {
+      if (scores[t] > best) {
+        best = scores[t]; best_h = t;
+        const double prob_s_outliers = 1 - std::pow(best / (double)o.K, o.s);
+        ransac_trial = (int)(std::log(1 - prob_free_outliers) / std::log(std::min(1 - 1e-6, std::max(1e-6, prob_s_outliers))));
+      }
+    }
+    trial_cnt[f] = t;
+    best_score_io[f] = best;
+    if (best_h >= 0) {
+      RM_TRY(hipMemcpy(best_pose + 12 * (size_t)f, dd.p + o.poses + 12 * (size_t)best_h, sizeof(double) * 12, hipMemcpyDeviceToHost));
+      if (best_inlier_bits && best_inlier_bits[f])
+        RM_TRY(hipMemcpy(best_inlier_bits[f], db.p + o.bits + (size_t)best_h * o.words, sizeof(unsigned long long) * o.words,
+                         hipMemcpyDeviceToHost));
+    }
+  }
+  return SLSLAM_OK;
+}

@@ -103,3 +103,19 @@ def test_gpu_motion_generator_and_trial_loop(hip, oracle, seed, K, T):
     t0 = oracle.ransac_motion(o0, fr["obs1"], fr["lines"], fr["samples"])
     t1 = hip.ransac_motion(o0, fr["obs1"], fr["lines"], fr["samples"])
     assert t0[:2] == t1[:2] and np.array_equal(t0[3], t1[3])
+
+
+@pytest.mark.gpu
+def test_gpu_ransac_motion_batch_equals_single_calls(hip, oracle):
+    """slslam_ransac_motion_batch: many frames in one call give, per frame, what slslam_ransac_motion and the
+    sequential oracle loop give (ragged frames, an empty one included)."""
+    frames = [synth.make_ransac_pair(40 + i, num_lines=30 + 17 * i, noise_px=0.4, outlier_frac=0.3, num_trials=50 + 31 * i) for i in range(6)]
+    empty = dict(frames[0], samples=frames[0]["samples"][:0])
+    batch = hip.ransac_motion_batch(frames + [empty])
+    assert len(batch) == 7 and batch[6][0] == 0 and batch[6][1] == 0
+    for fr, (tc, best, pose, mask) in zip(frames, batch[:6]):
+        t1 = hip.ransac_motion(fr["obs0"], fr["obs1"], fr["lines"], fr["samples"])
+        t0 = oracle.ransac_motion(fr["obs0"], fr["obs1"], fr["lines"], fr["samples"])
+        assert (tc, best) == t1[:2] == t0[:2]
+        assert np.array_equal(mask, t1[3]) and np.array_equal(mask, t0[3])
+        assert np.array_equal(pose, t1[2])
