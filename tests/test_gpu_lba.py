@@ -269,9 +269,9 @@ def test_batched_motion_only(hip, oracle):
 def test_randomised_shapes_against_oracle(hip, oracle):
     """60 random small windows (2..24 keyframes, 2..20 free, 3..120 lines, track lengths, noise levels, scrambled
     observation order, constant lines, loss on / off, iteration caps): initial evaluation, program reduction and
-    the first iterations agree with the oracle on every one (tools/fuzz_parity.py, run with 800 cases in round 1)."""
+    the first iterations agree with the oracle on every one (tests/tools/fuzz_parity.py, run with 800 cases in round 1)."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "fuzz_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     bad, worst = mod.run(60, seed=3, verbose=True)

@@ -1,4 +1,4 @@
-"""Developer tool: randomised parity sweep of the HIP LBA path against the oracle on many small windows of
+"""Developer tool (lives under tests/ because it uses the oracle as the checker / timed CPU reference): randomised parity sweep of the HIP LBA path against the oracle on many small windows of
 varied shape (keyframe counts, free / fixed split, track lengths, noise, robust loss on / off, constant lines,
 scrambled observation order).  python tools/fuzz_parity.py [cases]"""
 import os
@@ -6,7 +6,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slslam_amd import capi, synth  # noqa: E402
 from oracle import pyoracle as O     # noqa: E402  (developer tool: the oracle is the checker)
 

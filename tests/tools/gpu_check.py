@@ -6,7 +6,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slslam_amd import capi, synth  # noqa: E402
 from oracle import pyoracle as O  # noqa: E402
 

@@ -1,6 +1,6 @@
-"""Developer tool: single-window latency (BASELINE configs[1] and [2]) on the GPU box."""
+"""Developer tool (lives under tests/ because it uses the oracle as the checker / timed CPU reference): single-window latency (BASELINE configs[1] and [2]) on the GPU box."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slslam_amd import capi, synth
 from oracle import pyoracle as O
 for lines in (500, 2000):

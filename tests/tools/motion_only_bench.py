@@ -1,6 +1,6 @@
-"""Developer tool: throughput of batched motion-only BA."""
+"""Developer tool (lives under tests/ because it uses the oracle as the checker / timed CPU reference): throughput of batched motion-only BA."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slslam_amd import capi, synth
 from oracle import pyoracle as O
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -1,6 +1,6 @@
-"""Developer tool: RANSAC trial loops of many frames, one call per frame vs one batched call."""
+"""Developer tool (lives under tests/ because it uses the oracle as the checker / timed CPU reference): RANSAC trial loops of many frames, one call per frame vs one batched call."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slslam_amd import capi, synth
 from oracle import pyoracle as O
 frames = [synth.make_ransac_pair(100 + i, num_lines=200, noise_px=0.4, outlier_frac=0.3, num_trials=1001) for i in range(64)]

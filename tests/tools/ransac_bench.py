@@ -1,6 +1,6 @@
-"""Developer tool: RANSAC scoring throughput (hypothesis x line evaluations per second)."""
+"""Developer tool (lives under tests/ because it uses the oracle as the checker / timed CPU reference): RANSAC scoring throughput (hypothesis x line evaluations per second)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from slslam_amd import capi, synth
 from oracle import pyoracle as O
