@@ -168,7 +168,8 @@ int  slslam_lba_batch_counts(const slslam_lba_batch* b, long long* num_windows, 
 /* Device time (ms) spent in each kernel family during the last solve, measured with HIP events
  * on the solve stream while profiling is enabled (solves are then launched eagerly instead of
  * replaying the captured graph); times accumulate over solves until set_profiling is called again.
- * names: 0 linearise+schur, 1 reduced solve, 2 back-substitution, 3 line trig, 4 candidate cost,
+ * names: 0 linearise+schur, 1 reduced solve, 2 back-substitution (includes the candidate cost and the candidate
+ * lines' sin/cos table unless reuse_elimination is set), 3 line trig, 4 candidate cost (reuse_elimination only),
  * 5 LM update, 6 init.  launches[i] receives the number of launches. */
 int  slslam_lba_batch_set_profiling(slslam_lba_batch* b, int enable);
 int  slslam_lba_batch_kernel_times(const slslam_lba_batch* b, double ms[8], int launches[8]);
