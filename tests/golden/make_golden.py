@@ -11,6 +11,10 @@ The reference ships no golden vectors for this path and its solver (Ceres 1.7.0)
                         scipy.optimize.least_squares (trust-region reflective, numerical Jacobian)
                         on that transcription.
 * `po_optimum.npz`     a small pose graph and its least-squares optimum, same method.
+* `lba_lm_trace.npz`   iteration trace (cost, trust-region radius, gain ratio, accept / reject) of a Levenberg-
+                        Marquardt loop written here in numpy from the Ceres 1.7.0 policy table on the
+                        numpy transcription of the residual, central-difference Jacobians, dense normal equations:
+                        a second, independent statement of the trust-region bookkeeping the oracle's lm_core.c restates.
 * `traj_excerpt.txt`   DATA excerpt (25 lines) of two trajectory files the reference ships as results
                         (matlab_script/traj_slslam_itbt3f_basize10_wolc.txt lines 1-12 and
                         traj_slslam_myungdong_basize10_wlc.txt lines 100-112): output of the reference's
@@ -154,6 +158,87 @@ def make_po(rng):
     print("po optimum: cost %.6e -> %.6e, |grad|inf %.2e" % (0.5 * np.sum(fun(x0[6:]) ** 2), 0.5 * np.sum(sol.fun ** 2), np.abs(sol.grad).max()))
 
 
+def make_lm_trace():
+    w = synth.make_window(13, num_lines=20, num_kf=6, num_free=3, noise_px=0.6, mean_track=5.0)
+    C, L = w["num_cameras"], w["num_lines"]
+    cam_idx, line_idx, obs = w["camera_index"], w["line_index"], w["observations"]
+    fi = w["fixed_index"].reshape(-1, 2)
+    cam_const = np.array([fi[cam_idx == c, 0].any() for c in range(C)])
+    free_cams = [c for c in range(C) if not cam_const[c] and (cam_idx == c).any()]
+    cols = {("c", c): 6 * k for k, c in enumerate(free_cams)}
+    for l in range(L):
+        cols[("l", l)] = 6 * len(free_cams) + 4 * l
+    n = 6 * len(free_cams) + 4 * L
+    x = w["parameters"].copy()
+
+    def blocks(xv):
+        """robustified residuals and Jacobian (dense) + cost = sum rho / 2"""
+        r_all, J, cost = np.zeros(4 * len(cam_idx)), np.zeros((4 * len(cam_idx), n)), 0.0
+        for i, (c, l) in enumerate(zip(cam_idx, line_idx)):
+            cam, ln = xv[6 * c:6 * c + 6], xv[6 * C + 4 * l:6 * C + 4 * l + 4]
+            r = line_residual_np(cam, ln, obs[i])
+            sq = r @ r
+            if sq > A_HUBER ** 2:
+                rho, rp = 2 * A_HUBER * np.sqrt(sq) - A_HUBER ** 2, A_HUBER / np.sqrt(sq)
+            else:
+                rho, rp = sq, 1.0
+            cost += 0.5 * rho
+            sr = np.sqrt(rp)                          # corrector for rho'' <= 0: scale r and J by sqrt(rho')
+            r_all[4 * i:4 * i + 4] = sr * r
+            if ("c", c) in cols:
+                J[4 * i:4 * i + 4, cols[("c", c)]:cols[("c", c)] + 6] = sr * central(lambda q: line_residual_np(q, ln, obs[i]), cam)
+            J[4 * i:4 * i + 4, cols[("l", l)]:cols[("l", l)] + 4] = sr * central(lambda q: line_residual_np(cam, q, obs[i]), ln)
+        return r_all, J, cost
+
+    def pack(xv):
+        return np.concatenate([np.concatenate([xv[6 * c:6 * c + 6] for c in free_cams]), xv[6 * C:]])
+
+    def unpack(xv, z):
+        out = xv.copy()
+        for k, c in enumerate(free_cams):
+            out[6 * c:6 * c + 6] = z[6 * k:6 * k + 6]
+        out[6 * C:] = z[6 * len(free_cams):]
+        return out
+    r, J, cost = blocks(x)
+    scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0)))                      # Jacobi scaling, once at x0
+    g0 = np.abs(J.T @ r).max()
+    radius, dec = 1e4, 2.0
+    trace = [(0, cost, radius, 0.0, 0)]
+    for it in range(1, 11):
+        Js = J * scale
+        g = Js.T @ r
+        H = Js.T @ Js
+        d2 = np.clip(np.diag(H), 1e-6, 1e32) / radius
+        y = np.linalg.solve(H + np.diag(d2), g)
+        delta = -scale * y
+        model = 0.5 * y @ (g + d2 * y)
+        z = pack(x)
+        if np.linalg.norm(delta) <= 1e-8 * (np.linalg.norm(z) + 1e-8):
+            break
+        xc = unpack(x, z + delta)
+        rc, Jc, costc = blocks(xc)
+        change = cost - costc
+        if abs(change) < 1e-6 * cost:
+            break
+        rho = change / model
+        ok = rho > 1e-3
+        if ok:
+            radius = min(radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), 1e16)
+            dec = 2.0
+            x, r, J, cost = xc, rc, Jc, costc
+        else:
+            radius /= dec
+            dec *= 2.0
+        trace.append((it, cost, radius, rho, int(ok)))
+        if ok and np.abs(J.T @ r).max() <= 1e-10 * max(g0, 1e-12):
+            break
+    tr = np.array(trace)
+    np.savez(os.path.join(HERE, "lba_lm_trace.npz"), num_cameras=C, num_lines=L, camera_index=cam_idx, line_index=line_idx,
+             fixed_index=w["fixed_index"], observations=obs, parameters=w["parameters"], iteration=tr[:, 0].astype(int), cost=tr[:, 1],
+             radius=tr[:, 2], relative_decrease=tr[:, 3], successful=tr[:, 4].astype(int), final_parameters=x)
+    print("lm trace: %d records, cost %.6e -> %.6e, %d rejected" % (len(tr), tr[0, 1], tr[-1, 1], int((tr[1:, 4] == 0).sum())))
+
+
 def make_traj_excerpt():
     ref = "/root/reference/matlab_script"
     a = open(os.path.join(ref, "traj_slslam_itbt3f_basize10_wolc.txt")).read().splitlines(True)[:12]
@@ -163,6 +248,7 @@ def make_traj_excerpt():
 
 if __name__ == "__main__":
     make_traj_excerpt()
+    make_lm_trace()
     rng = np.random.default_rng(20260927)
     make_kat(rng)
     make_lba(rng)

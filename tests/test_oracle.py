@@ -174,3 +174,24 @@ def test_generator_is_deterministic_and_well_formed(seed):
     free_obs = np.bincount(a["line_index"][a["camera_index"] < 10], minlength=100)
     assert free_obs.min() >= 2                                          # slam.cpp:839-840
     assert np.array_equal(a["fixed_index"][0::2], (a["camera_index"] >= 10).astype(np.int32))
+
+
+def test_lm_trace_matches_independent_numpy_lm(oracle):
+    """tests/golden/lba_lm_trace.npz: a Levenberg-Marquardt loop written in numpy from the Ceres 1.7.0 policy table on the
+    numpy transcription of the residual (central-difference Jacobians, dense normal equations).  The oracle's
+    trust-region bookkeeping (lm_core.c) must walk the same path: same accept / reject decisions, radii and costs."""
+    z = np.load(os.path.join(GOLD, "lba_lm_trace.npz"))
+    w = {k: z[k] for k in ("camera_index", "line_index", "fixed_index", "observations", "parameters")}
+    w["num_cameras"], w["num_lines"] = int(z["num_cameras"]), int(z["num_lines"])
+    x, s, tr = oracle.lba_solve(w, linear_solver=0)
+    assert len(tr) == len(z["iteration"])
+    assert int((z["successful"][1:] == 0).sum()) >= 1                   # the path has rejected steps to follow
+    for k, rec in enumerate(tr):
+        assert rec["iteration"] == int(z["iteration"][k]) and rec["step_is_successful"] == int(z["successful"][k])
+        assert abs(rec["cost"] - z["cost"][k]) <= 2e-6 * z["cost"][k]     # finite-difference Jacobians on the numpy side
+        assert abs(rec["trust_region_radius"] - z["radius"][k]) <= 1e-4 * z["radius"][k]
+        if k:
+            assert abs(rec["relative_decrease"] - z["relative_decrease"][k]) <= 5e-4 * max(1.0, abs(z["relative_decrease"][k]))
+    assert np.abs(x - z["final_parameters"]).max() < 1e-5
+    x1, s1, tr1 = oracle.lba_solve(w, linear_solver=1)                  # the Schur back-end walks it too
+    assert [r["step_is_successful"] for r in tr1] == [int(v) for v in z["successful"]]
