@@ -274,7 +274,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   for (int wi = 0; wi < B; ++wi) {
     LMState& s = b->h_state0[wi];
     std::memset(&s, 0, sizeof(s));
-    s.radius = b->pol.initial_radius; s.decrease_factor = 2.0; s.status = kRunning;
+    s.radius = b->pol.initial_radius; s.decrease_factor = 2.0; s.status = kRunning; s.fresh = 1;
   }
 
   // ---- upload
@@ -397,8 +397,12 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     if ((rc = L.end())) return rc;                         \
   } while (0)
   if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 0));
-  if (b->nchunk > 0) LAUNCH(FAM_INIT, hipLaunchKernelGGL(k_linearise_schur<true>, g_chunk, blk64, b->lds_lin, s, p, pol));
-  LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_init, g_win, blk64, 0, s, p, pol));
+  // Ceres' initial evaluation (cost, gradient, column norms at x0 -> Jacobi scale, trace record 0) rides on the first
+  // LM iteration's sweeps (LMState.fresh); only a solve that may not iterate at all needs it as a pass of its own
+  if (pol.max_num_iterations <= 0 || pol.store_f) {     // (the streaming variant keeps F blocks in the first sweep's coordinates)
+    if (b->nchunk > 0) LAUNCH(FAM_INIT, hipLaunchKernelGGL(k_linearise_schur<true>, g_chunk, blk64, b->lds_lin, s, p, pol));
+    LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_init, g_win, blk64, 0, s, p, pol));
+  }
   for (int it = 0; it < pol.max_num_iterations; ++it) {
     // long solves (the reference's max_num_iter = 1000 study): every 16 iterations ask the device
     // whether any window is still iterating and stop enqueueing when none is

@@ -170,7 +170,7 @@ template <bool SCALED>
 __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy& pol, const double* camtab,
                                                const double* camscale, const signed char* camcf, int ls, int j, int k, int o0, bool line_ok,
                                                int lflags, int cur, int safe_obs, LaneLin& L, double (&ob)[8],
-                                               const ObsPref* pf = nullptr) {
+                                               const ObsPref* pf = nullptr, bool unit_line = false) {
   L.valid = line_ok && j < k;
   const int lsafe = line_ok ? ls : 0;
   double trig[7];
@@ -215,7 +215,7 @@ __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy&
 #pragma unroll
     for (int a = 0; a < 6; ++a) sc[a] = cs[a] * sr;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) sl[a] = lsc[a] * sr;
+    for (int a = 0; a < 4; ++a) sl[a] = unit_line ? sr : lsc[a] * sr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -363,9 +363,9 @@ __device__ __forceinline__ void lane_F(const LaneLin& L, const double K[10], dou
 }
 
 // Camera table of one window in LDS.  WITH_JAC: R and JL at buffer `buf`; else R only.
-template <bool WITH_JAC, bool UNIT_SCALE>
+template <bool WITH_JAC>
 __device__ __forceinline__ void load_cam_table(const BatchPtrs& p, const WinDesc& wd, int buf, int lane,
-                                               double* camtab, double* camscale, signed char* camcf) {
+                                               double* camtab, double* camscale, signed char* camcf, bool unit_scale) {
   for (int c = lane; c < wd.C; c += 64) {
     const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + buf) * kCamRec;
     double w[3] = { x[0], x[1], x[2] }, R[9], JL[9];
@@ -376,7 +376,7 @@ __device__ __forceinline__ void load_cam_table(const BatchPtrs& p, const WinDesc
     ct[18] = x[3]; ct[19] = x[4]; ct[20] = x[5];
     const int cf = p.cam_cf[wd.cam_off + c];
     if (cf >= 0)
-      for (int a = 0; a < 6; ++a) camscale[6 * cf + a] = UNIT_SCALE ? 1.0 : p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
+      for (int a = 0; a < 6; ++a) camscale[6 * cf + a] = unit_scale ? 1.0 : p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
     camcf[c] = (signed char)cf;
   }
 }
@@ -408,7 +408,8 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
   double* camscale = camtab + wd.C * kCamTab;
   double* S = camscale + (n > 0 ? n : 6);
   signed char* camcf = (signed char*)(S + nsys);
-  load_cam_table<true, INIT>(p, wd, cur, lane, camtab, camscale, camcf);
+  const bool fresh = !INIT && st->fresh != 0;              // this sweep is also the initial evaluation: see below
+  load_cam_table<true>(p, wd, cur, lane, camtab, camscale, camcf, INIT || fresh);
   for (int q = lane; q < nsys; q += 64) S[q] = 0.0;
   __syncthreads();
 
@@ -426,9 +427,9 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     const bool line_ok = tc.line_ok;
     LaneLin L;
     double ob[8];
-    lane_linearise<!INIT>(p, pol, camtab, camscale, camcf, ls, j, k, o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob, &pf);
+    lane_linearise<!INIT>(p, pol, camtab, camscale, camcf, ls, j, k, o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob, &pf, fresh);
     if (L.kept) acc_cost += L.cost;
-    if (INIT && L.valid && !L.kept) acc_fixed += L.cost;
+    if ((INIT || fresh) && L.valid && !L.kept) acc_fixed += L.cost;
 
     double H[10], g[4];
     line_block(L, width, H, g);
@@ -456,6 +457,32 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       }
       prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
       continue;
+    }
+
+    if (fresh) {
+      // first sweep of a solve: H, g are those of the UNSCALED line columns.  Jacobi scale of the line from them
+      // (1 / (1 + ||J_col||), Ceres: once at x0), the line's share of the initial gradient norm and of |x|, then the
+      // block, the gradient and the lane's line Jacobian go to scaled coordinates and the elimination proceeds
+      double sl[4];
+      const double d[4] = { H[0], H[2], H[5], H[9] };
+#pragma unroll
+      for (int a = 0; a < 4; ++a) sl[a] = (pol.jacobi_scaling && line_active) ? 1.0 / (1.0 + sqrt(d[a])) : 1.0;
+      if (line_ok && j == 0) {
+        double* lsc = p.line_scale + (long long)ls * 4;
+        const double* ul = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
+        for (int a = 0; a < 4; ++a) {
+          lsc[a] = sl[a];
+          if (line_active) { acc_gmax = fmax(acc_gmax, fabs(g[a])); acc_xn2 += ul[a] * ul[a]; }
+        }
+      }
+      H[0] *= sl[0] * sl[0]; H[1] *= sl[1] * sl[0]; H[2] *= sl[1] * sl[1]; H[3] *= sl[2] * sl[0]; H[4] *= sl[2] * sl[1];
+      H[5] *= sl[2] * sl[2]; H[6] *= sl[3] * sl[0]; H[7] *= sl[3] * sl[1]; H[8] *= sl[3] * sl[2]; H[9] *= sl[3] * sl[3];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) g[a] *= sl[a];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) L.Jl[4 * q + a] *= sl[a];
     }
 
     // ---- eliminate the line: A = H + D^2, A^-1 = K^T K
@@ -594,6 +621,11 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
 //      the one dense contraction of the LBA path (n = 6 Cf = 60: 64 MFMA per factorisation)
 //   4. block forward / backward substitution with the diagonal-tile inverses
 //   5. step statistics of the camera block, candidate camera poses
+__device__ __forceinline__ void push_trace(BatchPtrs& p, int w, LMState* st, const IterRec& r) {
+  if (st->ntrace < kMaxTrace) p.trace[(long long)w * kMaxTrace + st->ntrace] = r;
+  st->ntrace++;
+}
+
 __host__ __device__ inline int solve_pad(int n) { return ((n + 15) / 16) * 16; }
 __host__ __device__ inline int solve_stride(int n) { return ((solve_pad(n) + 30) / 32) * 32 + 1; }  // == 1 (mod 32) doubles
 // The inverse of a diagonal tile's factor is kept IN the tile: strictly lower part transposed into the tile's
@@ -625,6 +657,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
   const double radius = st->radius;
   const int need_grad_check = st->need_grad_check;
   const double abs_grad_tol = st->abs_grad_tol;
+  const int fresh = st->fresh;            // read before the barriers below: wave 0 clears it in step 1b
 
   for (int q = tid; q < N * ld; q += 256) A[q] = 0.0;
   for (int q = tid; q < 6 * N; q += 256) bvec[q] = 0.0;
@@ -671,6 +704,71 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
     if (sc[kScFail] != 0.0) fail = 1;
   }
   __syncthreads();
+
+  // ---- 1b. first iteration of a solve: the elimination sweep ran with unit camera scale, so the system just read is in
+  // UNSCALED camera coordinates.  Do what Ceres' initial evaluation does (cost, gradient max-norm, |x|, Jacobi scale of the
+  // camera columns from diag(J^T J) at x0, trace record 0, the tests that can end a solve before its first step), then
+  // bring S, b, g, diag to scaled coordinates (a congruence with diag(scale)) and carry on as in every other iteration.
+  if (fresh) {
+    if (wave == 0) {
+      double cost = 0.0, fixed = 0.0, xn2 = 0.0, gmax = 0.0;
+      if (lane == 0) {
+        for (int k = 0; k < wd.nchunks; ++k) {
+          const double* sc = p.slab + p.chunks[wd.chunk_off + k].slab_off + nsys;
+          cost += sc[kScCost]; fixed += sc[kScFixedCost]; xn2 += sc[kScXn2Line];
+        }
+        gmax = gmax_line;
+      }
+      for (int q = lane; q < N; q += 64) tvec[q] = 1.0;
+      for (int q = lane; q < 6 * wd.C; q += 64) {
+        const int c = q / 6, a = q - 6 * c;
+        const int cf = p.cam_cf[wd.cam_off + c];
+        double sc = 1.0;
+        if (cf >= 0) {
+          const double x = p.cam_x[((long long)(wd.cam_off + c) * 2 + cur) * kCamRec + a];
+          gmax = fmax(gmax, fabs(gvec[6 * cf + a]));
+          xn2 += x * x;
+          if (pol.jacobi_scaling) sc = 1.0 / (1.0 + sqrt(hvec[6 * cf + a]));
+          tvec[6 * cf + a] = sc;
+        }
+        p.cam_scale[(long long)(wd.cam_off + c) * 6 + a] = sc;
+      }
+      cost = wave_sum(cost); fixed = wave_sum(fixed); xn2 = wave_sum(xn2); gmax = wave_max(gmax);
+      if (lane == 0) {
+        st->cost = cost; st->fixed_cost = fixed; st->initial_cost = cost + fixed; st->min_cost = cost + fixed;
+        st->x_norm = sqrt(xn2);
+        st->grad_max = gmax;
+        st->abs_grad_tol = pol.gradient_tolerance * (gmax > 1e-12 ? gmax : 1e-12);
+        st->need_grad_check = 0;
+        st->fresh = 0;
+        int status = kRunning;
+        if (wd.nfree_params == 0) status = 2;                    // FUNCTION_TOLERANCE: no free blocks
+        else if (!isfinite(cost)) status = 4;
+        else if (gmax <= st->abs_grad_tol) status = 1;
+        if (status == kRunning) {
+          IterRec rec;
+          rec.pad = 0;
+          rec.iteration = 0; rec.step_is_valid = 0; rec.step_is_successful = 0;
+          rec.cost = cost + fixed; rec.cost_change = 0; rec.gradient_max_norm = gmax; rec.step_norm = 0;
+          rec.relative_decrease = 0; rec.trust_region_radius = st->radius; rec.model_cost_change = 0;
+          push_trace(p, w, st, rec);
+        }
+        st->status = status;
+        red[1] = (double)status;
+      }
+    }
+    __syncthreads();
+    if (red[1] != (double)kRunning) return;
+    for (int q = tid; q < n * ld; q += 256) {
+      const int r = q / ld, c = q - r * ld;
+      if (c <= r) A[q] *= tvec[r] * tvec[c];
+    }
+    for (int q = tid; q < n; q += 256) {
+      const double sc = tvec[q];
+      bvec[q] *= sc; gvec[q] *= sc; hvec[q] *= sc * sc;
+    }
+    __syncthreads();
+  }
 
   // ---- 2. gradient max-norm at the accepted point: gvec holds the SCALED gradient J'^T r, the true
   // gradient is g / scale.  Ceres tests it right after accepting a step.
@@ -1150,7 +1248,7 @@ __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) 
   double* camtab = smem;
   double* camscale = camtab + wd.C * kCamTab;
   signed char* camcf = (signed char*)(camscale + (wd.n > 0 ? wd.n : 6));
-  load_cam_table<false, true>(p, wd, cand, lane, camtab, camscale, camcf);
+  load_cam_table<false>(p, wd, cand, lane, camtab, camscale, camcf, true);
   __syncthreads();
   double acc = 0.0;
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
@@ -1193,10 +1291,6 @@ __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) 
 
 // ------------------------------------------------------------------------------------------
 // Kernel 6: the trust-region bookkeeping of one window (one lane) after an LM iteration.
-__device__ __forceinline__ void push_trace(BatchPtrs& p, int w, LMState* st, const IterRec& r) {
-  if (st->ntrace < kMaxTrace) p.trace[(long long)w * kMaxTrace + st->ntrace] = r;
-  st->ntrace++;
-}
 
 // After the initial evaluation (Ceres: cost, gradient and column norms at x0): one wave per window,
 // lane <-> camera column; the chunk partials of a column are summed in chunk order with the loads in flight together.
@@ -1248,6 +1342,7 @@ __global__ __launch_bounds__(64) void k_lm_init(BatchPtrs p, Policy pol) {
   const double g0 = gmax > 1e-12 ? gmax : 1e-12;
   st->abs_grad_tol = pol.gradient_tolerance * g0;
   st->need_grad_check = 0;
+  st->fresh = 0;
   if (wd.nfree_params == 0) { st->status = 2 /* FUNCTION_TOLERANCE: no free blocks */; return; }
   if (!isfinite(cost)) { st->status = 4; return; }
   if (gmax <= st->abs_grad_tol) { st->status = 1; return; }
@@ -1309,7 +1404,9 @@ __global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol) {
     st->need_grad_check = 1;      // the next linearisation supplies the gradient at the new point
     st->same_point = 0;
   } else {
-    st->same_point = 1;           // only the radius changes: gradient and column norms of the cameras stay valid
+    // only the radius changes: gradient and column norms of the cameras stay valid - except after the very first
+    // sweep of a solve, whose camera entries are in unscaled coordinates (it doubled as the initial evaluation)
+    st->same_point = st->iter > 0 ? 1 : 0;
     st->n_unsuccess++;
     if (rec.step_is_valid) { st->radius = st->radius / st->decrease_factor; st->decrease_factor *= 2.0; }
     else st->radius *= 0.5;
@@ -1337,7 +1434,7 @@ __global__ __launch_bounds__(64) void k_debug_linearise(BatchPtrs p, Policy pol,
   double* camtab = smem;
   double* camscale = camtab + wd.C * kCamTab;
   signed char* camcf = (signed char*)(camscale + (wd.n > 0 ? wd.n : 6));
-  load_cam_table<true, true>(p, wd, cur, lane, camtab, camscale, camcf);
+  load_cam_table<true>(p, wd, cur, lane, camtab, camscale, camcf, true);
   __syncthreads();
   double acc = 0.0;
   for (int l = 0; l < wd.L; ++l) {
@@ -1378,7 +1475,7 @@ __global__ __launch_bounds__(256) void k_reset(BatchPtrs p, Policy pol) {
     z.radius = pol.initial_radius; z.decrease_factor = 2.0; z.cost = 0; z.x_norm = 0; z.fixed_cost = 0;
     z.initial_cost = 0; z.min_cost = 0; z.abs_grad_tol = 0; z.grad_max = 0; z.cam_model = 0; z.cam_dn2 = 0; z.cam_xn2 = 0;
     z.status = kRunning; z.cur = 0; z.iter = 0; z.n_success = 0; z.n_unsuccess = 0; z.n_invalid = 0;
-    z.solve_failed = 0; z.need_grad_check = 0; z.ntrace = 0; z.same_point = 0;
+    z.solve_failed = 0; z.need_grad_check = 0; z.ntrace = 0; z.same_point = 0; z.fresh = 1; z.pad = 0;
     *st = z;
   }
 }

@@ -74,6 +74,8 @@ struct LMState {
   int need_grad_check;      // gradient at the accepted point not yet tested
   int ntrace;
   int same_point;           // the last step was rejected: the next linearisation is at the same point (new radius only)
+  int fresh;                // no evaluation yet: the first elimination sweep also plays the role of Ceres' initial evaluation
+  int pad;
 };
 
 struct IterRec {            // same fields as slslam_iteration
