@@ -441,7 +441,7 @@ extern "C" int slslam_lba_batch_solve(slslam_lba_batch* b, void* stream) {
   if (b->profiling) return enqueue_solve(b, s, true);   // events accumulate until set_profiling()
   if (!b->opt.use_graph || b->opt.max_num_iterations > 16) return enqueue_solve(b, s, false);
   if (!b->graph_exec) {
-    // capture the whole solve (3 + 4 * max_iter launches) once; replay costs one host call
+    // capture the whole solve (1 + 4 * max_iter launches) once; replay costs one host call
     HIP_TRY(hipStreamCreateWithFlags(&b->capture_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamBeginCapture(b->capture_stream, hipStreamCaptureModeThreadLocal));
     const int rc = enqueue_solve(b, b->capture_stream, false, true);
