@@ -34,6 +34,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector (and matrix) peak
 
 
+def baseline_metric():
+    """The metric string of BASELINE.json (the driver matches on it)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "LBA iterations/sec (10-KF window, ~2k lines) at 1/2/4/8 GPU; traj RMSE vs ref"
+
+
 def algorithmic_bytes_linearise(counts):
     """Algorithmic HBM bytes of ONE launch of the dominant kernel (linearise + Schur sweep):
     SURVEY.md 8d per-window figure for one of the three observation sweeps,
@@ -222,7 +230,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "LBA iterations/sec (10-KF window, ~2k lines)",
+            "metric": baseline_metric(),
             "value": iters_total / elapsed,
             "unit": "LM iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
