@@ -123,7 +123,7 @@ struct slslam_lba_batch {
   std::vector<int> h_ob_orig_off;          // per window offset into d_ob_orig
   bool downloaded = false;
   // device
-  DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<uint8_t> d_items;
+  DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<uint8_t> d_items; DevBuf<uint16_t> d_lane_map;
   DevBuf<unsigned long long> d_iter_counter;
   DevBuf<unsigned int> d_active;
   DevBuf<double> d_cam_x, d_cam_x0, d_cam_scale; DevBuf<int> d_cam_cf, d_cam_win;
@@ -146,7 +146,7 @@ struct slslam_lba_batch {
   std::vector<std::pair<int, int>> ev_used;   // (family, index of start event); stop = start + 1
 
   void release() {
-    d_wins.release(); d_tiles.release(); d_chunks.release(); d_items.release();
+    d_wins.release(); d_tiles.release(); d_chunks.release(); d_items.release(); d_lane_map.release();
     d_cam_x.release(); d_cam_x0.release(); d_cam_scale.release(); d_cam_cf.release(); d_cam_win.release();
     d_line_x.release(); d_line_x0.release(); d_line_scale.release(); d_line_ptr.release(); d_line_flags.release();
     d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release();
@@ -204,7 +204,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   const int B = (int)b->wins.size();
 
   // ---- global layout
-  std::vector<Tile> tiles; std::vector<Chunk> chunks; std::vector<uint8_t> items;
+  std::vector<Tile> tiles; std::vector<Chunk> chunks; std::vector<uint8_t> items; std::vector<uint16_t> lane_map;
   std::vector<double> cam_x, line_x, ob, cam_x0, line_u0; std::vector<int> cam_cf, cam_win, line_ptr, line_flags, line_win, line_orig, ob_cam, ob_orig;
   long long ncam = 0, nline = 0, nobs = 0, sys = 0, slab = 0, param_off = 0;
   long long total_tiles = 0;
@@ -244,6 +244,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     const int item_base = (int)(items.size() / 2);
     for (Tile t : P.tiles) { t.line_begin += (int)nline; t.item_off += item_base; tiles.push_back(t); }
     items.insert(items.end(), P.items.begin(), P.items.end());
+    lane_map.insert(lane_map.end(), P.lane_map.begin(), P.lane_map.end());
     for (int c = 0; c < P.C; ++c) {
       for (int buf = 0; buf < 2; ++buf) for (int a = 0; a < 6; ++a) cam_x.push_back(P.cam_x[6 * (size_t)c + a]);
       for (int a = 0; a < 6; ++a) cam_x0.push_back(P.cam_x[6 * (size_t)c + a]);
@@ -284,6 +285,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if ((rc = b->d_chunks.upload(chunks))) return rc;
   if (items.empty()) items.push_back(0);
   if ((rc = b->d_items.upload(items))) return rc;
+  if (lane_map.empty()) lane_map.assign(64, (uint16_t)0x00FF);
+  if ((rc = b->d_lane_map.upload(lane_map))) return rc;
   if (cam_x.empty()) cam_x.assign(12, 0.0);
   if ((rc = b->d_cam_x.upload(cam_x))) return rc;
   if (cam_x0.empty()) cam_x0.assign(6, 0.0);
@@ -326,7 +329,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   HIP_TRY(hipMemset(b->d_line_scale.p, 0, b->d_line_scale.n * sizeof(double)));
 
   BatchPtrs& p = b->ptrs;
-  p.wins = b->d_wins.p; p.tiles = b->d_tiles.p; p.chunks = b->d_chunks.p; p.items = b->d_items.p;
+  p.wins = b->d_wins.p; p.tiles = b->d_tiles.p; p.chunks = b->d_chunks.p; p.items = b->d_items.p; p.lane_map = b->d_lane_map.p;
   p.cam_x = b->d_cam_x.p; p.cam_scale = b->d_cam_scale.p; p.cam_cf = b->d_cam_cf.p;
   p.line_x = b->d_line_x.p; p.line_scale = b->d_line_scale.p; p.line_ptr = b->d_line_ptr.p;
   p.line_flags = b->d_line_flags.p; p.line_win = b->d_line_win.p;

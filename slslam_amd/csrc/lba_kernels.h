@@ -43,9 +43,6 @@ __device__ __forceinline__ int pair_base(int ncf, int cj, int ci) { return ncf *
 
 __device__ __forceinline__ int tri_index(int r, int c) { return (r * (r + 1)) / 2 + c; }  // r >= c
 
-// Sum over a 2^g-lane group, result in every lane of the group (bitwise identical across the
-// group).  Widths up to 16 stay on the VALU with DPP (quad_perm / row_half_mirror / row_mirror);
-// only the rare 32- and 64-lane groups go through ds_bpermute.
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -53,31 +50,73 @@ __device__ __forceinline__ double dpp_move(double v) {
   hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-// N values at once, step-major: one wave-uniform branch per reduction step for the whole batch
-// (value-major order made the compiler emit a branch ladder and a drained wait per value).
+// row_shr: lane i reads lane i - d of its 16-lane row; lanes whose source is outside the row read 0
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift0(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bperm64(double v, int byte_addr) {
+  const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// Where a lane sits in its line's run of lanes (Tile / lane_map in lba_types.h).
+struct SegCtx {
+  int j;            // position in the run (0 for idle lanes)
+  int first4;       // byte address (lane * 4) of the run's first lane
+  int rl4;          // byte address of the last lane of the run inside this lane's row
+  int r0, r1;       // first and last row of the run
+  int kk;           // min(run length, 4): lanes of the run that evaluate sin/cos
+  int max_run;      // longest in-row run of the tile (wave-uniform)
+  int rounds;       // sin/cos rounds of the tile (wave-uniform): 1 when every run has >= 4 lanes
+  bool multirow;    // some run of the tile spans several rows (wave-uniform)
+};
+
+// Sum over the lanes of a line's run, result in every lane of the run (bitwise identical across the run).
+// Inclusive prefix along the 16-lane row restricted to the lane's own run (row_shr by 1, 2, 4, 8 on the VALU; the
+// source is in the same run iff j >= d), then every lane fetches the total from the run's last lane in the row.
+// Runs that span rows (lines with more than 16 observations, rare) add their row totals in row order.
+// N values at once, step-major: one wave-uniform branch per step for the whole batch.
 template <int N>
-__device__ __forceinline__ void group_sum_n(double (&v)[N], int width) {
+__device__ __forceinline__ void seg_sum_n(double (&v)[N], const SegCtx& s) {
+  if (s.max_run > 1) {
+    const bool m = s.j >= 1;
 #pragma unroll
-  for (int q = 0; q < N; ++q) v[q] += dpp_move<0xB1>(v[q]);                    // quad_perm [1,0,3,2]
-  if (width > 2) {
-#pragma unroll
-    for (int q = 0; q < N; ++q) v[q] += dpp_move<0x4E>(v[q]);                  // quad_perm [2,3,0,1]
+    for (int q = 0; q < N; ++q) { const double t = dpp_shift0<0x111>(v[q]); v[q] += m ? t : 0.0; }
   }
-  if (width > 4) {
+  if (s.max_run > 2) {
+    const bool m = s.j >= 2;
 #pragma unroll
-    for (int q = 0; q < N; ++q) v[q] += dpp_move<0x141>(v[q]);                 // row_half_mirror: i <-> 7 - i
+    for (int q = 0; q < N; ++q) { const double t = dpp_shift0<0x112>(v[q]); v[q] += m ? t : 0.0; }
   }
-  if (width > 8) {
+  if (s.max_run > 4) {
+    const bool m = s.j >= 4;
 #pragma unroll
-    for (int q = 0; q < N; ++q) v[q] += dpp_move<0x140>(v[q]);                 // row_mirror: i <-> 15 - i
+    for (int q = 0; q < N; ++q) { const double t = dpp_shift0<0x114>(v[q]); v[q] += m ? t : 0.0; }
   }
-  if (width > 16) {
+  if (s.max_run > 8) {
+    const bool m = s.j >= 8;
 #pragma unroll
-    for (int q = 0; q < N; ++q) v[q] += __shfl_xor(v[q], 16);
+    for (int q = 0; q < N; ++q) { const double t = dpp_shift0<0x118>(v[q]); v[q] += m ? t : 0.0; }
   }
-  if (width > 32) {
 #pragma unroll
-    for (int q = 0; q < N; ++q) v[q] += __shfl_xor(v[q], 32);
+  for (int q = 0; q < N; ++q) v[q] = bperm64(v[q], s.rl4);
+  if (s.multirow) {
+    const bool spans = s.r1 > s.r0;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      double tot = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double x = bperm64(v[q], 64 * r);      // lane 16 r belongs to the run whenever the run covers row r
+        if (r >= s.r0 && r <= s.r1) tot += x;
+      }
+      if (spans) v[q] = tot;
+    }
   }
 }
 __device__ __forceinline__ double wave_sum(double v) {
@@ -107,22 +146,38 @@ struct LaneLin {
 // What a lane needs to know before it can touch its observation: fetched one tile AHEAD so that
 // the dependent chain  tile descriptor -> line_ptr -> observation  is off the critical path.
 struct TileCtx {
-  int glog2, ls, j, o0, k, lflags, nitems, item_off;
+  int flags, ls, j, o0, k, lflags, nitems, item_off;
   bool line_ok;
 };
 __device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_end, int lane) {
   TileCtx c;
-  c.glog2 = 1; c.ls = 0; c.j = 0; c.o0 = 0; c.k = 0; c.lflags = 1; c.nitems = 0; c.item_off = 0; c.line_ok = false;
+  c.flags = 0; c.ls = 0; c.j = 0; c.o0 = 0; c.k = 0; c.lflags = 1; c.nitems = 0; c.item_off = 0; c.line_ok = false;
   if (t < t_end) {
     const Tile tl = p.tiles[t];
-    c.glog2 = tl.glog2; c.nitems = tl.nitems; c.item_off = tl.item_off;
-    const int lsub = lane >> tl.glog2;
-    c.j = lane & ((1 << tl.glog2) - 1);
-    c.ls = tl.line_begin + lsub;
-    c.line_ok = lsub < tl.nlines;
-    if (c.line_ok) { c.o0 = p.line_ptr[c.ls]; c.k = p.line_ptr[c.ls + 1] - c.o0; c.lflags = p.line_flags[c.ls]; }
+    const int m = p.lane_map[(long long)t * 64 + lane];
+    c.flags = tl.flags; c.nitems = tl.nitems; c.item_off = tl.item_off;
+    c.line_ok = (m & 0xff) != 0xff;
+    if (c.line_ok) {
+      c.j = m >> 8;
+      c.ls = tl.line_begin + (m & 0xff);
+      c.o0 = p.line_ptr[c.ls]; c.k = p.line_ptr[c.ls + 1] - c.o0; c.lflags = p.line_flags[c.ls];
+    }
   }
   return c;
+}
+__device__ __forceinline__ SegCtx make_seg(const TileCtx& c, int lane) {
+  SegCtx s;
+  const int run = c.k > 1 ? c.k : 1;
+  const int first = lane - c.j, last = first + run - 1;
+  s.j = c.j;
+  s.first4 = first * 4;
+  s.rl4 = (last < (lane | 15) ? last : (lane | 15)) * 4;
+  s.r0 = first >> 4; s.r1 = last >> 4;
+  s.kk = run < 4 ? run : 4;
+  s.max_run = tile_max_run(c.flags);
+  s.rounds = tile_trig_rounds(c.flags);
+  s.multirow = (c.flags & kTileMultiRow) != 0;
+  return s;
 }
 
 // What a lane reads from HBM for its observation: the four endpoint pairs, the camera id and the sin/cos table
@@ -274,9 +329,9 @@ __device__ __forceinline__ void lane_linearise_bs(const BatchPtrs& p, const Poli
   }
 }
 
-// Per-line normal-equation block, summed over the line's group of lanes (every lane of the group
+// Per-line normal-equation block, summed over the line's run of lanes (every lane of the run
 // ends with the same values): H = sum Jl^T Jl (lower triangle, 10 values), g = sum Jl^T r.
-__device__ __forceinline__ void line_block(const LaneLin& L, int width, double H[10], double g[4]) {
+__device__ __forceinline__ void line_block(const LaneLin& L, const SegCtx& sg, double H[10], double g[4]) {
   const bool m = L.valid && L.line_free;
   double v[14];
   int q = 0;
@@ -297,7 +352,7 @@ __device__ __forceinline__ void line_block(const LaneLin& L, int width, double H
     for (int r = 0; r < 4; ++r) ga += L.Jl[4 * r + a] * L.rs[r];
     v[10 + a] = m ? ga : 0.0;
   }
-  group_sum_n<14>(v, width);
+  seg_sum_n<14>(v, sg);
 #pragma unroll
   for (int i = 0; i < 10; ++i) H[i] = v[i];
 #pragma unroll
@@ -422,7 +477,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     const TileCtx tc = nxt;
     const ObsPref pf = pfn;
     nxt = fetch_tile(p, t + 1, ck.tile_end, lane);      // in flight while this tile is processed
-    const int width = 1 << tc.glog2;
+    const SegCtx sg = make_seg(tc, lane);
     const int j = tc.j, ls = tc.ls, o0 = tc.o0, k = tc.k;
     const bool line_ok = tc.line_ok;
     LaneLin L;
@@ -432,8 +487,8 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     if ((INIT || fresh) && L.valid && !L.kept) acc_fixed += L.cost;
 
     double H[10], g[4];
-    line_block(L, width, H, g);
-    const bool line_active = L.line_free && k > 0;   // group-uniform
+    line_block(L, sg, H, g);
+    const bool line_active = L.line_free && k > 0;   // uniform over the line's run
 
     if (INIT) {
       // Jacobi scaling of the line's columns: 1 / (1 + ||J_col||), estimated once at x0
@@ -973,29 +1028,37 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
 enum { kCandTab = 13 };   // doubles per camera of the candidate table: R[9] t[3]; odd stride in 8-byte units
 __host__ __device__ inline int lds_doubles_backsub(int C, int n) { (void)n; return C * (kBsTab + kCandTab) + (C + 7) / 8; }
 
-// sin/cos table of a candidate line, computed cooperatively: every lane of a line's group holds the
-// same u[4]; lane (j & 3) evaluates the sin/cos of angle (j & 3) and the quad shares the results
-// (DPP quad_perm).  Groups of two lanes need two rounds.  Same expressions as line_trig().
-__device__ __forceinline__ void group_line_trig(const double u[4], int lane, int width, double trig[7]) {
-  double s3, c3;
-  if (width >= 4) {
-    const int a = lane & 3;
+// sin/cos table of a candidate line, computed cooperatively: every lane of a line's run holds the same u[4];
+// lane j < 4 of the run evaluates the sin/cos of angle j and the run shares the results (ds_bpermute from the
+// run's first lanes).  Runs shorter than 4 lanes (lines with 1-3 observations, kept in tiles of their own by the
+// packer) take 2 or 4 rounds: lane j evaluates angles j, j + kk, ...  Same expressions as line_trig().
+__device__ __forceinline__ void seg_line_trig(const double u[4], const SegCtx& s, double trig[7]) {
+  double sc[8];      // sin, cos of the four angles
+  if (s.rounds == 1) {
+    const int a = s.j < 3 ? s.j : 3;
     const double ang = a == 0 ? u[0] : a == 1 ? u[1] : a == 2 ? u[2] : u[3];
     const double sv = sin(ang), cv = cos(ang);
-    trig[0] = dpp_move<0x00>(sv); trig[1] = dpp_move<0x00>(cv);     // quad_perm [0,0,0,0]
-    trig[2] = dpp_move<0x55>(sv); trig[3] = dpp_move<0x55>(cv);     // quad_perm [1,1,1,1]
-    trig[4] = dpp_move<0xAA>(sv); trig[5] = dpp_move<0xAA>(cv);     // quad_perm [2,2,2,2]
-    s3 = dpp_move<0xFF>(sv); c3 = dpp_move<0xFF>(cv);               // quad_perm [3,3,3,3]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sc[2 * q] = bperm64(sv, s.first4 + 4 * q); sc[2 * q + 1] = bperm64(cv, s.first4 + 4 * q); }
   } else {
-    const int a = lane & 1;
-    const double a0 = a ? u[1] : u[0], a1 = a ? u[3] : u[2];
-    const double sv0 = sin(a0), cv0 = cos(a0), sv1 = sin(a1), cv1 = cos(a1);
-    trig[0] = dpp_move<0xA0>(sv0); trig[1] = dpp_move<0xA0>(cv0);   // quad_perm [0,0,2,2]
-    trig[2] = dpp_move<0xF5>(sv0); trig[3] = dpp_move<0xF5>(cv0);   // quad_perm [1,1,3,3]
-    trig[4] = dpp_move<0xA0>(sv1); trig[5] = dpp_move<0xA0>(cv1);
-    s3 = dpp_move<0xF5>(sv1); c3 = dpp_move<0xF5>(cv1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sc[q] = 0.0;
+    for (int r = 0; r < s.rounds; ++r) {
+      const int a = s.j + r * s.kk;                       // this lane's angle of round r (if < 4)
+      const int as = a < 3 ? a : 3;
+      const double ang = as == 0 ? u[0] : as == 1 ? u[1] : as == 2 ? u[2] : u[3];
+      const double sv = sin(ang), cv = cos(ang);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                       // angle q of this run comes from lane q % kk in round q / kk
+        const int src = s.first4 + 4 * (q % s.kk);
+        const double xs = bperm64(sv, src), xc = bperm64(cv, src);
+        if (q / s.kk == r) { sc[2 * q] = xs; sc[2 * q + 1] = xc; }
+      }
+    }
   }
-  trig[6] = c3 / s3;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) trig[q] = sc[q];
+  trig[6] = sc[7] / sc[6];
 }
 
 __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
@@ -1048,7 +1111,7 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
     const TileCtx tc = nxt;
     const ObsPref pf = pfn;
     nxt = fetch_tile(p, t + 1, ck.tile_end, lane);
-    const int width = 1 << tc.glog2;
+    const SegCtx sg = make_seg(tc, lane);
     const int j = tc.j, ls = tc.ls, k = tc.k;
     const bool line_ok = tc.line_ok;
     // what the elimination kernel kept for this line at this linearisation point and radius: K = chol(H_ll + D^2)^-1,
@@ -1071,7 +1134,7 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) wv[a] = L.Jl[a] * jy[0] + L.Jl[4 + a] * jy[1] + L.Jl[8 + a] * jy[2] + L.Jl[12 + a] * jy[3];
     }
-    group_sum_n<4>(wv, width);
+    seg_sum_n<4>(wv, sg);
     // the next tile's loads go out here (the Jacobian is dead), see prefetch_obs
     prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
     __builtin_amdgcn_sched_barrier(0);
@@ -1104,7 +1167,7 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
       }
     }
     double trig[7];
-    group_line_trig(xn, lane, width, trig);
+    seg_line_trig(xn, sg, trig);
     if (head) {
       double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
       for (int a = 0; a < 4; ++a) xc[a] = xn[a];
@@ -1156,13 +1219,10 @@ __global__ __launch_bounds__(64) void k_backsub_stream(BatchPtrs p, Policy pol) 
 
   double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0;
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
-    const Tile tl = p.tiles[t];
-    const int width = 1 << tl.glog2;
-    const int lsub = lane >> tl.glog2, j = lane & (width - 1);
-    const int ls = tl.line_begin + lsub;
-    const bool line_ok = lsub < tl.nlines;
-    int o0 = 0, k = 0, lflags = 1;
-    if (line_ok) { o0 = p.line_ptr[ls]; k = p.line_ptr[ls + 1] - o0; lflags = p.line_flags[ls]; }
+    const TileCtx tc = fetch_tile(p, t, ck.tile_end, lane);
+    const SegCtx sg = make_seg(tc, lane);
+    const int j = tc.j, ls = tc.ls, o0 = tc.o0, k = tc.k, lflags = tc.lflags;
+    const bool line_ok = tc.line_ok;
     const bool line_active = line_ok && !(lflags & 1) && k > 0;
     const bool valid = line_ok && j < k;
     double v[4] = { 0, 0, 0, 0 };
@@ -1180,7 +1240,7 @@ __global__ __launch_bounds__(64) void k_backsub_stream(BatchPtrs p, Policy pol) 
         }
       }
     }
-    group_sum_n<4>(v, width);
+    seg_sum_n<4>(v, sg);
     if (line_ok && j == 0) {
       const double* xl = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
       double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
@@ -1252,13 +1312,9 @@ __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) 
   __syncthreads();
   double acc = 0.0;
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
-    const Tile tl = p.tiles[t];
-    const int width = 1 << tl.glog2;
-    const int lsub = lane >> tl.glog2, j = lane & (width - 1);
-    const int ls = tl.line_begin + lsub;
-    const bool line_ok = lsub < tl.nlines;
-    int o0 = 0, k = 0;
-    if (line_ok) { o0 = p.line_ptr[ls]; k = p.line_ptr[ls + 1] - o0; }
+    const TileCtx tc = fetch_tile(p, t, ck.tile_end, lane);
+    const int j = tc.j, ls = tc.ls, o0 = tc.o0, k = tc.k;
+    const bool line_ok = tc.line_ok;
     const bool valid = line_ok && j < k;
     const int o = valid ? o0 + j : wd.obs_off;
     double ob[8];

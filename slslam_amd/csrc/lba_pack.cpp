@@ -37,17 +37,70 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   if (P.Cf > kMaxFreeCams) return SLSLAM_ERR_UNSUPPORTED;
   P.cam_x.assign(w->parameters, w->parameters + (size_t)6 * C);
 
-  // group width class per line
-  std::vector<int> glog2(L);
+  // lane runs: a line takes max(k, 1) consecutive lanes.  Runs are bin-packed (first fit, decreasing) into
+  // 16-lane rows, rows into 4-row tiles; the sorted line order is the order in which lines appear in the tiles.
+  //   * lines with more than 16 observations take whole rows of one tile,
+  //   * lines with 4..16 observations share rows; the rows are dealt to the tiles so that every tile gets about
+  //     the same number of off-diagonal pair items (the pair passes of a tile cost ceil(items / 64)),
+  //   * lines with fewer than 4 observations (which need more than one sin/cos round per lane in the
+  //     back-substitution) are kept in tiles of their own.
+  std::vector<int> kfree(L, 0);
+  for (int i = 0; i < M; ++i) if (P.cam_cf[w->camera_index[i]] >= 0) kfree[w->line_index[i]]++;
+  auto lanes_of = [&](int l) { return std::max(line_cnt[l], 1); };
+  auto items_of = [&](int l) { return line_const[l] ? 0 : (kfree[l] * (kfree[l] - 1)) / 2; };
+  struct Row { int used = 0, items = 0; std::vector<int> lines; };
+  auto pack_rows = [&](std::vector<int> ls) {
+    std::stable_sort(ls.begin(), ls.end(), [&](int x, int y) { return lanes_of(x) > lanes_of(y); });
+    std::vector<Row> rows;
+    std::vector<int> open_by_room[17];          // rows indexed by remaining room, oldest first
+    for (int l : ls) {
+      const int need = lanes_of(l);
+      int best = -1;
+      for (int room = need; room <= 16; ++room)
+        for (int r : open_by_room[room]) if (best < 0 || r < best) best = r;
+      if (best < 0) { best = (int)rows.size(); rows.push_back(Row()); }
+      else { auto& v = open_by_room[16 - rows[best].used]; v.erase(std::find(v.begin(), v.end(), best)); }
+      rows[best].used += need; rows[best].items += items_of(l); rows[best].lines.push_back(l);
+      if (rows[best].used < 16) open_by_room[16 - rows[best].used].push_back(best);
+    }
+    return rows;
+  };
+  std::vector<int> big, mid, small;
   for (int l = 0; l < L; ++l) {
     if (line_cnt[l] > 64) return SLSLAM_ERR_UNSUPPORTED;
-    int g = 1;
-    while ((1 << g) < line_cnt[l]) ++g;
-    glog2[l] = g;
+    (line_cnt[l] > 16 ? big : line_cnt[l] >= 4 ? mid : small).push_back(l);
   }
-  P.line_order.resize(L);
-  std::iota(P.line_order.begin(), P.line_order.end(), 0);
-  std::stable_sort(P.line_order.begin(), P.line_order.end(), [&](int a, int b) { return glog2[a] < glog2[b]; });
+  struct TileRows { std::vector<std::vector<int>> rows; };   // a multi-row line is one entry of `rows` holding one line
+  std::vector<TileRows> tplan;
+  {
+    int used_rows = 4;
+    std::stable_sort(big.begin(), big.end(), [&](int x, int y) { return line_cnt[x] > line_cnt[y]; });
+    for (int l : big) {
+      const int nr = (line_cnt[l] + 15) / 16;
+      if (used_rows + nr > 4) { tplan.push_back(TileRows()); used_rows = 0; }
+      tplan.back().rows.push_back(std::vector<int>(1, l));
+      used_rows += nr;
+    }
+  }
+  {
+    std::vector<Row> rows = pack_rows(mid);
+    std::stable_sort(rows.begin(), rows.end(), [](const Row& x, const Row& y) { return x.items > y.items; });
+    const int R = (int)rows.size(), T = (R + 3) / 4, base = (int)tplan.size();
+    tplan.resize(base + T);
+    for (int r = 0; r < R; ++r) {                 // boustrophedon deal: heavy rows meet light rows
+      const int pass = r / T, pos = r % T;
+      tplan[base + ((pass & 1) ? T - 1 - pos : pos)].rows.push_back(rows[r].lines);
+    }
+  }
+  {
+    const std::vector<Row> rows = pack_rows(small);
+    for (size_t r = 0; r < rows.size(); ++r) {
+      if (r % 4 == 0) tplan.push_back(TileRows());
+      tplan.back().rows.push_back(rows[r].lines);
+    }
+  }
+  P.line_order.clear();
+  for (const TileRows& tr : tplan) for (const auto& row : tr.rows) for (int l : row) P.line_order.push_back(l);
   std::vector<int> line_pos(L);
   for (int s = 0; s < L; ++s) line_pos[P.line_order[s]] = s;
 
@@ -88,27 +141,38 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
     if (!(cam_const[w->camera_index[i]] && line_const[w->line_index[i]])) ++P.nkept;
   }
 
-  // tiles and their off-diagonal camera-pair work items
-  for (int s = 0; s < L;) {
-    const int g = glog2[P.line_order[s]];
-    const int per_tile = 64 >> g;
-    int e = s;
-    while (e < L && e - s < per_tile && glog2[P.line_order[e]] == g) ++e;
-    Tile t;
-    t.line_begin = s; t.nlines = (int16_t)(e - s); t.glog2 = (int16_t)g;
-    t.item_off = (int)(P.items.size() / 2);
-    for (int q = s; q < e; ++q) {
-      if (P.line_flags[q] & 1) continue;                   // constant line: nothing to eliminate
-      const int base_lane = (q - s) << g;
-      const int k = P.line_ptr[q + 1] - P.line_ptr[q];
-      int kf = 0;                                          // free-camera observations come first
-      while (kf < k && P.cam_cf[P.ob_cam[P.line_ptr[q] + kf]] >= 0) ++kf;
-      for (int i = 0; i < kf; ++i)
-        for (int j = i + 1; j < kf; ++j) { P.items.push_back((uint8_t)(base_lane + i)); P.items.push_back((uint8_t)(base_lane + j)); }
+  // tiles, their lane maps and their off-diagonal camera-pair work items
+  {
+    int s = 0;
+    for (const TileRows& tr : tplan) {
+      Tile t;
+      t.line_begin = s; t.item_off = (int)(P.items.size() / 2);
+      std::vector<uint16_t> map(64, (uint16_t)0x00FF);
+      int lane = 0, nl = 0, min_lanes = 64, max_run = 1, multi = 0;
+      for (const auto& row : tr.rows) {
+        lane = (lane + 15) & ~15;                            // every entry of the plan starts a row
+        for (size_t q = 0; q < row.size(); ++q, ++s, ++nl) {
+          const int k = P.line_ptr[s + 1] - P.line_ptr[s], run = std::max(k, 1);
+          for (int j = 0; j < run; ++j) map[lane + j] = (uint16_t)(nl | (j << 8));
+          min_lanes = std::min(min_lanes, run);
+          max_run = std::max(max_run, std::min(run, 16));
+          if (run > 16) multi = 1;
+          if (!(P.line_flags[s] & 1)) {
+            int kf = 0;                                      // free-camera observations come first
+            while (kf < k && P.cam_cf[P.ob_cam[P.line_ptr[s] + kf]] >= 0) ++kf;
+            for (int i = 0; i < kf; ++i)
+              for (int j = i + 1; j < kf; ++j) { P.items.push_back((uint8_t)(lane + i)); P.items.push_back((uint8_t)(lane + j)); }
+          }
+          lane += run;
+        }
+      }
+      const int rounds_log2 = min_lanes >= 4 ? 0 : min_lanes >= 2 ? 1 : 2;
+      t.nlines = (int16_t)nl;
+      t.flags = (int16_t)(multi | (rounds_log2 << 1) | (max_run << 3));
+      t.nitems = (int)(P.items.size() / 2) - t.item_off;
+      P.tiles.push_back(t);
+      P.lane_map.insert(P.lane_map.end(), map.begin(), map.end());
     }
-    t.nitems = (int)(P.items.size() / 2) - t.item_off;
-    P.tiles.push_back(t);
-    s = e;
   }
   return SLSLAM_OK;
 }

@@ -5,10 +5,10 @@
 // block per observation wired to camera block camera_index[i] and line block line_index[i]
 // (:83-84), a block is constant if ANY observation flags it (:88-91).  Instead of M heap-allocated
 // cost functions the build emits:
-//   * lines sorted by observation count class (group width 2^g), observations grouped by line with
-//     the free-camera observations first (ascending free index),
-//   * tiles (one 64-lane pass each), the balanced list of off-diagonal camera-pair work items per
-//     tile, and chunks (runs of tiles handled by one wave).
+//   * lines bin-packed into the 16-lane rows of 64-lane tiles (a line owns one lane per observation),
+//     observations grouped by line with the free-camera observations first (ascending free index),
+//   * per tile the lane map and the list of off-diagonal camera-pair work items, and chunks (runs of
+//     tiles handled by one wave).
 // Pure host C++ (no HIP), so the CPU test-suite can check its invariants.
 #ifndef SLSLAM_LBA_PACK_H_
 #define SLSLAM_LBA_PACK_H_
@@ -33,6 +33,7 @@ struct PackedWindow {
   std::vector<int> ob_cam;          // [M]  sorted
   std::vector<double> ob;           // [8*M] SoA: ob[q*M + o]
   std::vector<Tile> tiles;          // line_begin window-local; item_off window-local
+  std::vector<uint16_t> lane_map;   // [64 per tile] lane -> line slot | position << 8 (0x00FF: idle)
   std::vector<uint8_t> items;       // 2 bytes per item
   std::vector<double> params0;      // caller's original parameter vector (for lines/cams never touched)
 };

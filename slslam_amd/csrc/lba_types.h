@@ -37,15 +37,22 @@ struct WinDesc {
   int pad;
 };
 
-// A tile is one 64-lane pass: 64 >> glog2 consecutive (sorted) lines, each owning a group of
-// 1 << glog2 lanes; lane (l, j) handles observation line_ptr[l] + j.
+// A tile is one 64-lane pass over a run of consecutive (sorted) lines.  Every line owns a run of
+// max(k, 1) consecutive lanes (k = its observations), lane j of the run handles observation
+// line_ptr[l] + j.  Runs are bin-packed into the four 16-lane rows of the wave so that a run only
+// crosses a row boundary when it starts on one (lines with more than 16 observations), which keeps the
+// per-line reductions on row-local DPP shifts.  lane_map[64 t + lane] = slot | j << 8 with slot = line - line_begin
+// (0xFF: idle lane).
+enum { kTileMultiRow = 1 };             // Tile.flags bit 0: some line of the tile spans several rows
 struct Tile {
   int line_begin;         // global sorted line index of the first line
   int16_t nlines;
-  int16_t glog2;
+  int16_t flags;          // bit 0 kTileMultiRow | bits 1-2: log2(sin/cos rounds) = lines with < 4 lanes | bits 3-7: longest in-row run
   int item_off;           // off-diagonal camera-pair work items of this tile
   int nitems;
 };
+constexpr int tile_trig_rounds(int flags) { return 1 << ((flags >> 1) & 3); }
+constexpr int tile_max_run(int flags) { return (flags >> 3) & 31; }
 
 struct Chunk {
   int win;
@@ -98,6 +105,7 @@ struct BatchPtrs {
   const WinDesc* wins;
   const Tile* tiles;
   const Chunk* chunks;
+  const uint16_t* lane_map;   // [ntile][64] lane -> (line slot, position in the line's run), see Tile
   const uint8_t* items;       // 2 bytes per item: (lane_i, lane_j), camera(lane_i) <= camera(lane_j)
   // cameras
   double* cam_x;              // [ncam][2][6]

@@ -30,8 +30,8 @@ extern "C" {
 // Packs one window and copies the layout into caller buffers (sized generously by the test).
 int hm_pack(int C, int L, int M, const int* cam, const int* line, const int* fixed, const double* obs, double* params,
             int* out_counts /*Cf, ntiles, nitems, nfree_params, nkept*/, int* line_order, int* line_ptr, int* ob_orig,
-            int* ob_cam, int* tiles /*4 ints per tile: line_begin,nlines,glog2,nitems*/, unsigned char* items, int* cam_cf,
-            int max_tiles, int max_items) {
+            int* ob_cam, int* tiles /*4 ints per tile: line_begin,nlines,flags,nitems*/, unsigned char* items, int* cam_cf,
+            int max_tiles, int max_items, unsigned short* lane_map /*64 per tile*/) {
   slslam_lba_window w{C, L, M, cam, line, fixed, obs, params};
   slslam::PackedWindow P;
   const int rc = slslam::pack_window(&w, &P);
@@ -46,9 +46,10 @@ int hm_pack(int C, int L, int M, const int* cam, const int* line, const int* fix
   std::memcpy(cam_cf, P.cam_cf.data(), sizeof(int) * C);
   for (size_t t = 0; t < P.tiles.size(); ++t) {
     tiles[4 * t] = P.tiles[t].line_begin; tiles[4 * t + 1] = P.tiles[t].nlines;
-    tiles[4 * t + 2] = P.tiles[t].glog2; tiles[4 * t + 3] = P.tiles[t].nitems;
+    tiles[4 * t + 2] = P.tiles[t].flags; tiles[4 * t + 3] = P.tiles[t].nitems;
   }
   std::memcpy(items, P.items.data(), P.items.size());
+  std::memcpy(lane_map, P.lane_map.data(), P.lane_map.size() * sizeof(unsigned short));
   return 0;
 }
 }

@@ -84,11 +84,14 @@ def _pack(host_math, w):
     max_tiles, max_items = L + 8, 64 * M + 8
     tiles = np.zeros(4 * max_tiles, dtype=np.int32)
     items = np.zeros(2 * max_items, dtype=np.uint8)
+    lane_map = np.zeros(64 * max_tiles, dtype=np.uint16)
     rc = host_math.hm_pack(Cn, L, M, _ip(cam), _ip(line), _ip(fixed), _dp(obs), _dp(prm), _ip(counts), _ip(lo), _ip(lp),
-                           _ip(oo), _ip(oc), _ip(tiles), items.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cf), max_tiles, max_items)
+                           _ip(oo), _ip(oc), _ip(tiles), items.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cf), max_tiles, max_items,
+                           lane_map.ctypes.data_as(C.POINTER(C.c_ushort)))
     return rc, dict(Cf=int(counts[0]), ntiles=int(counts[1]), nitems=int(counts[2]), nfree=int(counts[3]), nkept=int(counts[4]),
                     line_order=lo[:L], line_ptr=lp, ob_orig=oo[:M], ob_cam=oc[:M], cam_cf=cf[:Cn],
-                    tiles=tiles[:4 * int(counts[1])].reshape(-1, 4), items=items[:2 * int(counts[2])].reshape(-1, 2))
+                    tiles=tiles[:4 * int(counts[1])].reshape(-1, 4), items=items[:2 * int(counts[2])].reshape(-1, 2),
+                    lane_map=lane_map[:64 * int(counts[1])].reshape(-1, 64))
 
 
 def test_pack_invariants(host_math):
@@ -108,25 +111,61 @@ def test_pack_invariants(host_math):
         nf = int((cf >= 0).sum())
         assert np.all(cf[:nf] >= 0) and np.all(cf[nf:] < 0) and np.all(np.diff(cf[:nf]) >= 0)   # free first, ascending
     assert np.array_equal(P["ob_cam"], w["camera_index"][P["ob_orig"]])
-    # tiles cover the sorted lines exactly once; group width fits the line's observations
-    covered, expect_items, it = 0, 0, 0
-    for lb, nl, g, ni in P["tiles"]:
-        assert lb == covered and 1 <= nl <= (64 >> g)
-        for s in range(lb, lb + nl):
-            k = P["line_ptr"][s + 1] - P["line_ptr"][s]
-            assert k <= (1 << g) and (g == 1 or k > (1 << (g - 1)))
+    _check_tiles(P, w, L)
+
+
+def _check_tiles(P, w, L):
+    """Tiles cover the sorted lines exactly once; every line owns a run of max(k, 1) consecutive lanes that stays inside
+    one 16-lane row unless it starts on a row boundary; the pair items name the lanes of the run's free cameras."""
+    covered, it = 0, 0
+    for t, (lb, nl, flags, ni) in enumerate(P["tiles"]):
+        assert lb == covered and 1 <= nl <= 64
+        m = P["lane_map"][t]
+        slot, pos = m & 0xFF, m >> 8
+        want, min_run, max_run, multi = set(), 64, 1, 0
+        for q in range(nl):
+            s = lb + q
+            k = int(P["line_ptr"][s + 1] - P["line_ptr"][s])
+            run = max(k, 1)
+            lanes = np.nonzero(slot == q)[0]
+            assert len(lanes) == run and np.array_equal(lanes, lanes[0] + np.arange(run))
+            assert np.array_equal(pos[lanes], np.arange(run))
+            assert lanes[0] // 16 == lanes[-1] // 16 or lanes[0] % 16 == 0
+            if q: assert lanes[0] > np.nonzero(slot == q - 1)[0][-1]          # runs in line order
+            min_run, max_run, multi = min(min_run, run), max(max_run, min(run, 16)), multi or run > 16
             sel = P["ob_orig"][P["line_ptr"][s]:P["line_ptr"][s + 1]]
             kf = int((P["cam_cf"][w["camera_index"][sel]] >= 0).sum())
-            base = (s - lb) << g
-            want = {(base + i, base + j) for i in range(kf) for j in range(i + 1, kf)}
-            got = {tuple(x) for x in P["items"][it + expect_items - expect_items:it + ni]} if ni else set()
-            expect_items += len(want)
-            assert want <= {tuple(x) for x in P["items"][it:it + ni]}
-        assert expect_items == ni
+            if not np.any(np.asarray(w["fixed_index"]).reshape(-1, 2)[sel, 1]):
+                want |= {(lanes[0] + i, lanes[0] + j) for i in range(kf) for j in range(i + 1, kf)}
+        assert np.all(slot[slot != 0xFF] < nl)
+        assert (flags & 1) == int(multi) and (flags >> 3) & 31 == max_run
+        assert 1 << ((flags >> 1) & 3) == (1 if min_run >= 4 else 2 if min_run >= 2 else 4)
+        got = [tuple(int(v) for v in x) for x in P["items"][it:it + ni]]
+        assert len(got) == len(set(got)) and set(got) == want
         it += ni
-        expect_items = 0
         covered += nl
     assert covered == L and it == P["nitems"]
+
+
+def test_pack_long_and_short_lines(host_math):
+    """Lines with more than 16 observations take whole rows; lines with fewer than 4 keep to tiles of their own."""
+    rng = np.random.default_rng(5)
+    Cn, L = 40, 60
+    counts = np.concatenate([rng.integers(17, 41, 6), rng.integers(4, 17, 30), rng.integers(0, 4, 24)])
+    cam, line = [], []
+    for l, k in enumerate(counts):
+        cam += list(rng.choice(Cn, size=k, replace=False)); line += [l] * k
+    M = len(cam)
+    fixed = np.zeros((M, 2), dtype=np.int32); fixed[np.asarray(cam) >= 12, 0] = 1
+    w = dict(num_cameras=Cn, num_lines=L, camera_index=np.asarray(cam, dtype=np.int32), line_index=np.asarray(line, dtype=np.int32),
+             fixed_index=fixed.reshape(-1), observations=rng.normal(size=(M, 8)), parameters=rng.normal(size=6 * Cn + 4 * L))
+    rc, P = _pack(host_math, w)
+    assert rc == 0 and P["Cf"] == 12
+    _check_tiles(P, w, L)
+    runs = {}
+    for t, (lb, nl, flags, ni) in enumerate(P["tiles"]):
+        ks = [max(int(P["line_ptr"][s + 1] - P["line_ptr"][s]), 1) for s in range(lb, lb + nl)]
+        assert max(ks) < 4 or min(ks) >= 4                     # short lines never share a tile with the others
 
 
 def test_pack_edge_cases(host_math):
