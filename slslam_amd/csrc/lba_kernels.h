@@ -81,27 +81,32 @@ struct SegCtx {
 // source is in the same run iff j >= d), then every lane fetches the total from the run's last lane in the row.
 // Runs that span rows (lines with more than 16 observations, rare) add their row totals in row order.
 // N values at once, step-major: one wave-uniform branch per step for the whole batch.
-template <int N>
+// FMA_MASK: the mask rides on an fma (x += t * 1.0 or t * 0.0) instead of two v_cndmask per value.  A non-finite t
+// from a neighbouring line would leak through 0 * t, but a non-finite block already invalidates the whole window's
+// step, so the outcome is the same.  (Not used by the elimination kernel: there the fma form costs the few registers
+// that separate 2 waves per SIMD from 1.)
+template <int CTRL, bool FMA_MASK>
+__device__ __forceinline__ double seg_step(double v, bool m) {
+  const double t = dpp_shift0<CTRL>(v);
+  return FMA_MASK ? fma(t, m ? 1.0 : 0.0, v) : v + (m ? t : 0.0);
+}
+template <int N, bool FMA_MASK = false>
 __device__ __forceinline__ void seg_sum_n(double (&v)[N], const SegCtx& s) {
   if (s.max_run > 1) {
-    const bool m = s.j >= 1;
 #pragma unroll
-    for (int q = 0; q < N; ++q) { const double t = dpp_shift0<0x111>(v[q]); v[q] += m ? t : 0.0; }
+    for (int q = 0; q < N; ++q) v[q] = seg_step<0x111, FMA_MASK>(v[q], s.j >= 1);
   }
   if (s.max_run > 2) {
-    const bool m = s.j >= 2;
 #pragma unroll
-    for (int q = 0; q < N; ++q) { const double t = dpp_shift0<0x112>(v[q]); v[q] += m ? t : 0.0; }
+    for (int q = 0; q < N; ++q) v[q] = seg_step<0x112, FMA_MASK>(v[q], s.j >= 2);
   }
   if (s.max_run > 4) {
-    const bool m = s.j >= 4;
 #pragma unroll
-    for (int q = 0; q < N; ++q) { const double t = dpp_shift0<0x114>(v[q]); v[q] += m ? t : 0.0; }
+    for (int q = 0; q < N; ++q) v[q] = seg_step<0x114, FMA_MASK>(v[q], s.j >= 4);
   }
   if (s.max_run > 8) {
-    const bool m = s.j >= 8;
 #pragma unroll
-    for (int q = 0; q < N; ++q) { const double t = dpp_shift0<0x118>(v[q]); v[q] += m ? t : 0.0; }
+    for (int q = 0; q < N; ++q) v[q] = seg_step<0x118, FMA_MASK>(v[q], s.j >= 8);
   }
 #pragma unroll
   for (int q = 0; q < N; ++q) v[q] = bperm64(v[q], s.rl4);
@@ -1134,7 +1139,7 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) wv[a] = L.Jl[a] * jy[0] + L.Jl[4 + a] * jy[1] + L.Jl[8 + a] * jy[2] + L.Jl[12 + a] * jy[3];
     }
-    seg_sum_n<4>(wv, sg);
+    seg_sum_n<4, true>(wv, sg);
     // the next tile's loads go out here (the Jacobian is dead), see prefetch_obs
     prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
     __builtin_amdgcn_sched_barrier(0);
