@@ -2,7 +2,7 @@
 // bundle adjustment.  One LM iteration of every window of the batch is four launches:
 //
 //   k_linearise_schur  one 64-lane wave per chunk of a window's lines; lane <-> observation,
-//                      a line owns a 2^g-lane group (DPP reductions), per-wave private partial of the
+//                      a line owns a run of lanes (segmented DPP scans), per-wave private partial of the
 //                      reduced camera system in LDS (ds_add_f64); keeps each line's 4x4 factor
 //   k_reduced_solve    one workgroup per window: ordered reduction of the chunk partials, LM damping,
 //                      blocked in-LDS Cholesky of the (6 Cf)^2 system on v_mfma_f64_16x16x4_f64,
@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
     const int j = tc.j, ls = tc.ls, k = tc.k;
     const bool line_ok = tc.line_ok;
     // what the elimination kernel kept for this line at this linearisation point and radius: K = chol(H_ll + D^2)^-1,
-    // D^2, g_l (the same values this sweep would recompute); every lane of the line's group reads the same record
+    // D^2, g_l (the same values this sweep would recompute); every lane of the line's run reads the same record
     double K[10], D2[4], g[4];
     {
       const double* le = p.line_elim + (long long)(tc.line_ok ? tc.ls : 0) * kLineElim;
@@ -1143,8 +1143,8 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
     // the next tile's loads go out here (the Jacobian is dead), see prefetch_obs
     prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
     __builtin_amdgcn_sched_barrier(0);
-    // every lane of the group holds the same H, g, w: all of them take the step (the candidate
-    // parameters are needed by every lane below); lane 0 of the group writes and accumulates
+    // every lane of the run holds the same H, g, w: all of them take the step (the candidate
+    // parameters are needed by every lane below); lane 0 of the run writes and accumulates
     const int lsafe = line_ok ? ls : 0;
     double xn[4] = { pf.u[0], pf.u[1], pf.u[2], pf.u[3] };
     const bool head = line_ok && j == 0;

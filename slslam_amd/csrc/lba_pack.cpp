@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <set>
 
 namespace slslam {
 
@@ -52,16 +53,16 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   auto pack_rows = [&](std::vector<int> ls) {
     std::stable_sort(ls.begin(), ls.end(), [&](int x, int y) { return lanes_of(x) > lanes_of(y); });
     std::vector<Row> rows;
-    std::vector<int> open_by_room[17];          // rows indexed by remaining room, oldest first
+    std::set<int> open_by_room[17];             // rows indexed by remaining room
     for (int l : ls) {
       const int need = lanes_of(l);
-      int best = -1;
+      int best = -1;                            // first fit: the oldest row with enough room
       for (int room = need; room <= 16; ++room)
-        for (int r : open_by_room[room]) if (best < 0 || r < best) best = r;
+        if (!open_by_room[room].empty() && (best < 0 || *open_by_room[room].begin() < best)) best = *open_by_room[room].begin();
       if (best < 0) { best = (int)rows.size(); rows.push_back(Row()); }
-      else { auto& v = open_by_room[16 - rows[best].used]; v.erase(std::find(v.begin(), v.end(), best)); }
+      else open_by_room[16 - rows[best].used].erase(best);
       rows[best].used += need; rows[best].items += items_of(l); rows[best].lines.push_back(l);
-      if (rows[best].used < 16) open_by_room[16 - rows[best].used].push_back(best);
+      if (rows[best].used < 16) open_by_room[16 - rows[best].used].insert(best);
     }
     return rows;
   };
