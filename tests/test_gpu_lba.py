@@ -69,6 +69,32 @@ def test_solve_trace_matches_oracle(hip, oracle, seed, lines, kf, free):
     assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-7 * s0["final_cost"]
 
 
+def test_long_and_short_line_runs(hip, oracle):
+    """Lane layout corner cases of the packer: lines observed by more than 16 keyframes (their run of lanes spans
+    several 16-lane rows of a tile) and lines with 1-3 observations (several sin/cos rounds per lane in the
+    back-substitution), alone and mixed with ordinary lines in one window."""
+    long_w = synth.make_window(11, num_lines=60, num_kf=24, num_free=12, mean_track=40.0)
+    counts = np.bincount(long_w["line_index"], minlength=long_w["num_lines"])
+    assert counts.max() > 16
+    short_w = synth.make_window(12, num_lines=90, num_kf=8, num_free=6, mean_track=2.0)
+    # thin some tracks of the mixed window down to a single observation (the line stays in the problem)
+    mixed = synth.make_window(13, num_lines=120, num_kf=24, num_free=12, mean_track=12.0)
+    keep = np.ones(len(mixed["camera_index"]), dtype=bool)
+    for l in range(0, 120, 7):
+        idx = np.nonzero(mixed["line_index"] == l)[0]
+        keep[idx[1:]] = False
+    mixed = dict(mixed, camera_index=mixed["camera_index"][keep], line_index=mixed["line_index"][keep],
+                 observations=mixed["observations"][keep], fixed_index=mixed["fixed_index"].reshape(-1, 2)[keep].reshape(-1))
+    cm = np.bincount(mixed["line_index"], minlength=120)
+    assert cm.min() == 1 and cm.max() > 16
+    for w in (long_w, short_w, mixed):
+        x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+        x1, s1, t1 = hip.lba_solve(w)
+        _assert_trace_parity(t0, t1, n=3)
+        _assert_summary_parity(s0, s1)
+        assert np.abs(x0 - x1).max() < 1e-5
+
+
 def test_one_iteration_is_roundoff_exact(hip, oracle):
     w = synth.make_window(11, num_lines=300)
     x0, s0, t0 = oracle.lba_solve(w, linear_solver=0, max_num_iterations=1)      # dense normal equations
