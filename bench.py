@@ -107,7 +107,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap-run", action="store_true", help="skip the informational two-stream measurement")
     ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph (no per-kernel events)")
-    ap.add_argument("--mfma", type=int, default=-1, help="1 / 0: matrix-core / pairwise Schur accumulation (-1 = library default)")
     ap.add_argument("--chunks", type=int, default=0, help="waves cooperating on one window (0 = library default)")
     ap.add_argument("--streams", type=int, default=1,
                     help="the rank's windows are split into this many batches on separate HIP streams, so that the "
@@ -137,7 +136,6 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    mfma_opt = {} if args.mfma < 0 else {"lba_mfma_schur": args.mfma}
     # ---- synthetic inputs of the named shape, distinct per rank, resident in HBM before timing
     B = args.windows
     windows = [synth.make_window(1_000_000 * rank + i, num_lines=args.lines) for i in range(B)]
@@ -149,7 +147,7 @@ def main():
         for wi in range(si, B, ns):
             bt.add(windows[wi])
             owner.append((wi, si, len(bt.sizes) - 1))
-        bt.finalize(use_graph=1 if args.graph else 0, chunks_per_window=args.chunks, **mfma_opt)
+        bt.finalize(use_graph=1 if args.graph else 0, chunks_per_window=args.chunks)
         bt.set_profiling(not args.graph)
         batches.append(bt)
     where = {wi: (si, li) for wi, si, li in owner}
@@ -197,7 +195,7 @@ def main():
             bt = capi.LBABatch(device=local_rank)
             for wi in range(si, B, 2):
                 bt.add(windows[wi])
-            bt.finalize(use_graph=1, chunks_per_window=args.chunks, **mfma_opt)
+            bt.finalize(use_graph=1, chunks_per_window=args.chunks)
             obatches.append(bt)
 
         def orun():

@@ -75,10 +75,6 @@ typedef struct slslam_solver_options {
   int    po_dense_factor;               /* pose graph only: 0 (default) = structured factorisation: chains of poses
                                            eliminated concurrently (block tridiagonal), dense MFMA Cholesky of the
                                            junction poses only; 1 = dense MFMA Cholesky of the whole normal matrix   */
-  int    lba_mfma_schur;                /* line bundle adjustment: 1 = the Schur outer products of the elimination sweep are
-                                           accumulated on the matrix cores (v_mfma_f64_16x16x4_f64, one rank-4 update per
-                                           line) instead of camera pair by camera pair with LDS atomics; applies to batches
-                                           whose windows have at most 10 free cameras, others use the pairwise path         */
 } slslam_solver_options;
 
 /* Fills every field with the configuration the reference runs (robust loss on, 10 iterations). */

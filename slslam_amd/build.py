@@ -10,10 +10,7 @@ LIB = os.path.join(LIB_DIR, "libslslam_hip.so")
 SOURCES = ["lba_api.hip", "lba_pack.cpp", "po_api.hip", "ransac_api.hip"]
 HEADERS = ["lba_kernels.h", "lba_math.h", "lba_types.h", "lba_pack.h", "po_kernels.h",
            os.path.join("..", "..", "include", "slslam_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
-         # MFMA accumulators in the (unified) VGPR file, allocated by liveness with everything else: the matrix-core
-         # variant of the elimination sweep keeps 2 waves per SIMD (the AGPR form adds 82 registers on top of the peak)
-         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 import os as _os
 FLAGS += _os.environ.get("SLSLAM_EXTRA_FLAGS", "").split()
 

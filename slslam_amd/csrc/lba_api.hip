@@ -46,7 +46,6 @@ extern "C" void slslam_default_options(slslam_solver_options* o) {
   o->reuse_elimination = 0;
   o->po_factor_fp32 = 0;
   o->po_dense_factor = 0;
-  o->lba_mfma_schur = 0;
 }
 
 extern "C" int slslam_device_count(void) {
@@ -135,8 +134,6 @@ struct slslam_lba_batch {
   BatchPtrs ptrs;
   int nchunk = 0, nline = 0, ncam = 0;
   long long nobs = 0;
-  bool mfma_schur = false;
-  size_t lds_lin_mfma = 0;
   size_t lds_lin = 0, lds_solve = 0, lds_bs = 0, lds_bs_stream = 0, lds_cost = 0;
   // graph
   hipGraphExec_t graph_exec = nullptr;
@@ -213,8 +210,6 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   long long total_tiles = 0;
   for (const PackedWindow& P : b->wins) total_tiles += (long long)P.tiles.size();
   int maxC = 1, maxn = 0;
-  bool any_dup = false;
-  for (const PackedWindow& P : b->wins) any_dup = any_dup || P.dup_cam;
   b->h_wins.resize(B); b->h_param_off.resize(B); b->h_ob_orig_off.resize(B);
   for (const PackedWindow& P : b->wins) nobs += P.M;
   b->nobs = nobs;
@@ -346,10 +341,6 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.nwin = B; p.nchunk = b->nchunk; p.nline = b->nline; p.ncam = b->ncam;
 
   b->lds_lin = sizeof(double) * (size_t)lds_doubles_linearise(maxC, maxn);
-  // matrix-core variant of the elimination sweep: every window of the batch must fit the 60-row tile region and no
-  // line may be observed twice by the same camera (two blocks would land on the same panel rows)
-  b->mfma_schur = b->opt.lba_mfma_schur && maxn <= 60 && !any_dup;
-  b->lds_lin_mfma = sizeof(double) * (size_t)lds_doubles_linearise_mfma(maxC, maxn);
   b->lds_solve = sizeof(double) * (size_t)lds_doubles_solve(maxn);
   b->lds_bs = sizeof(double) * (size_t)lds_doubles_backsub(maxC, maxn);
   b->lds_bs_stream = sizeof(double) * (size_t)lds_doubles_backsub_stream(maxC, maxn);
@@ -360,8 +351,6 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
     HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
   }
-  if (b->mfma_schur && b->lds_lin_mfma > 48 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin_mfma));
   if (b->lds_solve > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
   b->h_state.assign(B, LMState());
@@ -427,10 +416,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       if (active == 0) break;
     }
     if (!capturing && ((it + 1) % 16) == 0) HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
-    if (b->nchunk > 0) {
-      if (b->mfma_schur) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_linearise_schur<false, true>), g_chunk, blk64, b->lds_lin_mfma, s, p, pol));
-      else LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_linearise_schur<false>, g_chunk, blk64, b->lds_lin, s, p, pol));
-    }
+    if (b->nchunk > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_linearise_schur<false>, g_chunk, blk64, b->lds_lin, s, p, pol));
     LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve, g_win, blk256, b->lds_solve, s, p, pol));
     if (b->nchunk > 0) {
       if (pol.store_f) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub_stream, g_chunk, blk64, b->lds_bs_stream, s, p, pol));

@@ -25,9 +25,6 @@
 #include "lba_math.h"
 #include "lba_types.h"
 
-#ifndef SLSLAM_EXP
-#define SLSLAM_EXP 0
-#endif
 namespace slslam {
 
 enum { kCamTab = 21 };   // doubles per camera in LDS: R[9] JL[9] t[3]; odd stride (42 dwords): conflict-free
@@ -154,16 +151,16 @@ struct LaneLin {
 // What a lane needs to know before it can touch its observation: fetched one tile AHEAD so that
 // the dependent chain  tile descriptor -> line_ptr -> observation  is off the critical path.
 struct TileCtx {
-  int flags, ls, j, o0, k, lflags, nitems, item_off, slot, nlines;
+  int flags, ls, j, o0, k, lflags, nitems, item_off;
   bool line_ok;
 };
 __device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_end, int lane) {
   TileCtx c;
-  c.flags = 0; c.ls = 0; c.j = 0; c.o0 = 0; c.k = 0; c.lflags = 1; c.nitems = 0; c.item_off = 0; c.slot = 0xff; c.nlines = 0; c.line_ok = false;
+  c.flags = 0; c.ls = 0; c.j = 0; c.o0 = 0; c.k = 0; c.lflags = 1; c.nitems = 0; c.item_off = 0; c.line_ok = false;
   if (t < t_end) {
     const Tile tl = p.tiles[t];
     const int m = p.lane_map[(long long)t * 64 + lane];
-    c.flags = tl.flags; c.nitems = tl.nitems; c.item_off = tl.item_off; c.nlines = tl.nlines; c.slot = m & 0xff;
+    c.flags = tl.flags; c.nitems = tl.nitems; c.item_off = tl.item_off;
     c.line_ok = (m & 0xff) != 0xff;
     if (c.line_ok) {
       c.j = m >> 8;
@@ -444,31 +441,6 @@ __device__ __forceinline__ void load_cam_table(const BatchPtrs& p, const WinDesc
   }
 }
 
-// ---- MFMA variant of the elimination (windows with at most 10 free cameras, n <= 60): the Schur outer products
-// sum_lines F F^T are accumulated per tile on v_mfma_f64_16x16x4_f64 (one k = 4 step per line: the 60 x 4 panel of the
-// line's F blocks times its transpose) instead of pair by pair with LDS atomics.  The lower triangle of the 60 x 60
-// sum lives in a tile region of the wave's LDS: diagonal 16 x 16 tiles packed (lower, column-major, heights 16 16 16 12),
-// then the off-diagonal tiles (1,0) (2,0) (2,1) with 256 entries and (3,0) (3,1) (3,2) with 192 (12 rows), every
-// off-diagonal tile laid out so that the entries a lane holds after the MFMA (rows g + 4 q of column c) are contiguous.
-typedef double solve_acc_t __attribute__((ext_vector_type(4)));
-enum { kTileReg = 1830, kPanelHalfRows = 30, kPanel = 4 * kPanelHalfRows };
-__host__ __device__ constexpr int treg_diag_base(int t) { return t * 136; }
-__host__ __device__ constexpr int treg_off_base(int rt, int ct) { return 486 + (rt == 1 ? 0 : rt == 2 ? 256 * (1 + ct) : 768 + 192 * ct); }
-// value of (sum F F^T)[row][col], row >= col, from the tile region
-__device__ __forceinline__ double treg_value(const double* T, int row, int col) {
-  const int rt = row >> 4, ct = col >> 4, r = row & 15, c = col & 15;
-  if (rt == ct) {
-    const int H = rt < 3 ? 16 : 12;
-    return T[treg_diag_base(rt) + c * H - (c * (c - 1)) / 2 + (r - c)];
-  }
-  const int base = 486 + (rt == 1 ? 0 : rt == 2 ? 256 * (1 + ct) : 768 + 192 * ct);
-  return rt < 3 ? T[base + c * 16 + (r & 3) * 4 + (r >> 2)] : T[base + c * 12 + (r & 3) * 3 + (r >> 2)];
-}
-__host__ __device__ inline int lds_doubles_linearise_mfma(int C, int n) {
-  // camera table + scale table + camera records (diagonal triangle of J_c^T J_c, b, g, hdiag) + tile region + panel
-  return C * kCamTab + (n > 0 ? n : 6) + (n / 6) * kCamAcc + 1 + kTileReg + kPanel + (C + 7) / 8;   // + 1: 16-byte alignment of the tile region
-}
-
 __host__ __device__ inline int lds_doubles_linearise(int C, int n) {
   // camera table + scale table (one unused slot when no camera is free) + partial system ; free-index bytes appended
   return C * kCamTab + (n > 0 ? n : 6) + sys_doubles(n) + (C + 7) / 8;
@@ -478,7 +450,7 @@ __host__ __device__ inline int lds_doubles_linearise(int C, int n) {
 // Kernel 1: linearise + per-line Schur elimination, partial reduced system per chunk.
 // INIT = initial evaluation (Ceres: cost, gradient and column norms at x0 for the Jacobi scaling):
 // no elimination, unit scaling, writes the per-line scale.
-template <bool INIT, bool MFMA = false>
+template <bool INIT>
 __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
@@ -495,21 +467,17 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
   double* camtab = smem;
   double* camscale = camtab + wd.C * kCamTab;
   double* S = camscale + (n > 0 ? n : 6);
-  const int nlds = MFMA ? ncf * kCamAcc + 1 + kTileReg : nsys;   // accumulators to clear
-  double* T = S + ncf * kCamAcc;                                  // MFMA: tile region (16-byte aligned), then the panel
-  if ((T - smem) & 1) ++T;
-  double* panel = T + kTileReg;
-  signed char* camcf = (signed char*)(MFMA ? panel + kPanel : S + nsys);
+  signed char* camcf = (signed char*)(S + nsys);
   const bool fresh = !INIT && st->fresh != 0;              // this sweep is also the initial evaluation: see below
   load_cam_table<true>(p, wd, cur, lane, camtab, camscale, camcf, INIT || fresh);
-  for (int q = lane; q < nlds; q += 64) S[q] = 0.0;
+  for (int q = lane; q < nsys; q += 64) S[q] = 0.0;
   __syncthreads();
 
   double acc_cost = 0.0, acc_fixed = 0.0, acc_gmax = 0.0, acc_xn2 = 0.0;
   int fail = 0;
   TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
   ObsPref pfn;
-  prefetch_obs<false, !INIT && !MFMA>(p, nxt, cur, wd.obs_off, pfn, lane);
+  prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
     const TileCtx tc = nxt;
     const ObsPref pf = pfn;
@@ -547,7 +515,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
           lds_add(&rec[kRecH + a], ha);
         }
       }
-      prefetch_obs<false, !INIT && !MFMA>(p, nxt, cur, wd.obs_off, pfn, lane);
+      prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
       continue;
     }
 
@@ -619,7 +587,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       }
     }
 
-    prefetch_obs<false, !INIT && !MFMA>(p, nxt, cur, wd.obs_off, pfn, lane);
+    prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
     __builtin_amdgcn_sched_barrier(0);
     if (cam_free) {
       double* rec = S + L.cf * kCamAcc;
@@ -639,138 +607,15 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
           double v = 0.0;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v += L.Jc[6 * r + a] * L.Jc[6 * r + b];
-          if (!MFMA) {              // MFMA variant: the F F^T part comes out of the tile region
 #pragma unroll
-            for (int m = 0; m < 4; ++m) v -= F[4 * a + m] * F[4 * b + m];
-          }
+          for (int m = 0; m < 4; ++m) v -= F[4 * a + m] * F[4 * b + m];
           lds_add(&rec[tri_index(a, b)], v);
         }
       }
     }
 
-    if (MFMA) {
-      // ---- sum over the tile's lines of F F^T on the matrix cores.  One line at a time: the lanes of its free
-      // cameras lay their 6 x 4 blocks into the LDS panel (k-major, rows 6 cf + a; two halves of 30 rows), every lane
-      // picks up the operand entry of its (row, k) for the four 16-row tiles, one MFMA per touched tile pair.
-      solve_acc_t acc[10];
-#pragma unroll
-      for (int t = 0; t < 10; ++t) acc[t] = solve_acc_t{ 0.0, 0.0, 0.0, 0.0 };
-      const int m16 = lane & 15, kq = lane >> 4;
-      const int cf = L.cf;
-      const int t_lo = elim ? (6 * cf) >> 4 : -1, t_hi = elim ? (6 * cf + 5) >> 4 : -1;
-      const bool in0 = t_lo == 0 || t_hi == 0, in1 = t_lo == 1 || t_hi == 1, in2 = t_lo == 2 || t_hi == 2, in3 = t_lo == 3 || t_hi == 3;
-      int used = SLSLAM_EXP == 3 ? 15 : 0;                       // tiles of the region this 64-lane tile touched (wave-uniform)
-      // two-stage pipeline over the lines: the LDS traffic that builds line q's operands is issued before the MFMAs of the
-      // line before it, so that its latency hides behind them (LDS executes a wave's instructions in order: no waits needed
-      // between the panel writes and the reads that follow them)
-      double C0 = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0;
-      int tmc = 0;
-      int q = 0;
-      for (;;) {
-        double P0 = 0.0, P1 = 0.0, P2 = 0.0, P3 = 0.0;
-        int tm = 0;
-        while (q < (SLSLAM_EXP == 3 ? 0 : tc.nlines) && tm == 0) {
-          const bool writer = elim && tc.slot == q;
-          ++q;
-          const unsigned long long wA = __ballot(writer && cf < 5), wB = __ballot(writer && cf >= 5);
-          if (!(wA | wB)) continue;
-          tm = (__ballot(writer && in0) ? 1 : 0) | (__ballot(writer && in1) ? 2 : 0) | (__ballot(writer && in2) ? 4 : 0) | (__ballot(writer && in3) ? 8 : 0);
-          if (wA) {
-            if (lane < 2 * kPanelHalfRows) reinterpret_cast<double2*>(panel)[lane] = make_double2(0.0, 0.0);
-            if (writer && cf < 5) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int a2 = 0; a2 < 3; ++a2)
-                  *reinterpret_cast<double2*>(panel + k * kPanelHalfRows + 6 * cf + 2 * a2) = make_double2(F[8 * a2 + k], F[8 * a2 + 4 + k]);
-            }
-            asm volatile("" ::: "memory");
-            P0 = panel[kq * kPanelHalfRows + m16];
-            const double p1a = panel[kq * kPanelHalfRows + (m16 < 14 ? 16 + m16 : 0)];
-            P1 = m16 < 14 ? p1a : 0.0;
-            asm volatile("" ::: "memory");
-          }
-          if (wB) {
-            if (lane < 2 * kPanelHalfRows) reinterpret_cast<double2*>(panel)[lane] = make_double2(0.0, 0.0);
-            if (writer && cf >= 5) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int a2 = 0; a2 < 3; ++a2)
-                  *reinterpret_cast<double2*>(panel + k * kPanelHalfRows + 6 * (cf - 5) + 2 * a2) = make_double2(F[8 * a2 + k], F[8 * a2 + 4 + k]);
-            }
-            asm volatile("" ::: "memory");
-            const double p1b = panel[kq * kPanelHalfRows + (m16 >= 14 ? m16 - 14 : 0)];     // rows 30, 31
-            if (m16 >= 14) P1 = p1b;
-            P2 = panel[kq * kPanelHalfRows + 2 + m16];                                       // rows 32..47
-            const double p3 = panel[kq * kPanelHalfRows + (m16 < 12 ? 18 + m16 : 0)];        // rows 48..59
-            P3 = m16 < 12 ? p3 : 0.0;
-            asm volatile("" ::: "memory");
-          }
-        }
-        if (tmc && SLSLAM_EXP != 1) {
-          if (tmc & 1) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(C0, C0, acc[0], 0, 0, 0);
-          if ((tmc & 3) == 3) acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(C1, C0, acc[1], 0, 0, 0);
-          if (tmc & 2) acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(C1, C1, acc[2], 0, 0, 0);
-          if ((tmc & 5) == 5) acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(C2, C0, acc[3], 0, 0, 0);
-          if ((tmc & 6) == 6) acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(C2, C1, acc[4], 0, 0, 0);
-          if (tmc & 4) acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(C2, C2, acc[5], 0, 0, 0);
-          if ((tmc & 9) == 9) acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(C3, C0, acc[6], 0, 0, 0);
-          if ((tmc & 10) == 10) acc[7] = __builtin_amdgcn_mfma_f64_16x16x4f64(C3, C1, acc[7], 0, 0, 0);
-          if ((tmc & 12) == 12) acc[8] = __builtin_amdgcn_mfma_f64_16x16x4f64(C3, C2, acc[8], 0, 0, 0);
-          if (tmc & 8) acc[9] = __builtin_amdgcn_mfma_f64_16x16x4f64(C3, C3, acc[9], 0, 0, 0);
-          used |= tmc;
-        }
-        if (!tm) break;
-        C0 = P0; C1 = P1; C2 = P2; C3 = P3; tmc = tm;
-      }
-      // ---- add the tile's sums into the tile region (plain read-modify-write: every entry has one owner lane; all the
-      // loads of a group go out before its first store)
-      {
-        const int tri_t[4] = { 0, 2, 5, 9 };
-        double dv[16];
-        double* Dp[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {                 // diagonal tiles: rows g + 4 q >= c of column c
-          const int H = t < 3 ? 16 : 12;
-          Dp[t] = T + treg_diag_base(t) + m16 * H - (m16 * (m16 - 1)) / 2 - m16;
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int r = kq + 4 * qq;
-            dv[4 * t + qq] = (((used >> t) & 1) && r >= m16 && r < H) ? Dp[t][r] : 0.0;
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int H = t < 3 ? 16 : 12;
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int r = kq + 4 * qq;
-            if (((used >> t) & 1) && r >= m16 && r < H) Dp[t][r] = dv[4 * t + qq] + acc[tri_t[t]][qq];
-          }
-        }
-        const int off_t[6] = { 1, 3, 4, 6, 7, 8 };
-        const int off_rt[6] = { 1, 2, 2, 3, 3, 3 }, off_ct[6] = { 0, 0, 1, 0, 1, 2 };
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          const bool touched = SLSLAM_EXP != 2 && ((used >> off_rt[u]) & (used >> off_ct[u]) & 1) != 0;      // wave-uniform
-          if (!touched) continue;
-          if (off_rt[u] < 3) {
-            double2* D = reinterpret_cast<double2*>(T + treg_off_base(off_rt[u], off_ct[u]) + m16 * 16 + kq * 4);
-            double2 d0 = D[0], d1 = D[1];
-            d0.x += acc[off_t[u]][0]; d0.y += acc[off_t[u]][1]; d1.x += acc[off_t[u]][2]; d1.y += acc[off_t[u]][3];
-            D[0] = d0; D[1] = d1;
-          } else {
-            double* D = T + treg_off_base(off_rt[u], off_ct[u]) + m16 * 12 + kq * 3;
-            const double e0 = D[0], e1 = D[1], e2 = D[2];
-            D[0] = e0 + acc[off_t[u]][0]; D[1] = e1 + acc[off_t[u]][1]; D[2] = e2 + acc[off_t[u]][2];
-          }
-        }
-      }
-    }
-
     // ---- off-diagonal camera pairs of the tile, balanced over the lanes
-    for (int base_it = 0; base_it < (MFMA ? 0 : tc.nitems); base_it += 64) {
+    for (int base_it = 0; base_it < tc.nitems; base_it += 64) {
       const int it = base_it + lane;
       const bool has = it < tc.nitems;
       int li = 0, lj = 0;
@@ -813,28 +658,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
   for (int q = lane; q < nsys; q += 64) {
     // after a rejected step the gradient / column-norm entries of the camera records were not accumulated: keep the slab's
     if (same_point && q < ncf * kCamAcc && (q % kCamAcc) >= kRecG) continue;
-    if (!MFMA) { slab[q] = S[q]; continue; }
-    // MFMA variant: the slab keeps the block layout the reduced solve reads; the Schur part comes from the tile region
-    if (q < ncf * kCamAcc) {
-      const int cf = q / kCamAcc, e = q - cf * kCamAcc;
-      double v = S[q];
-      if (e < kRecB) {
-        const int a = e >= 15 ? 5 : e >= 10 ? 4 : e >= 6 ? 3 : e >= 3 ? 2 : e >= 1 ? 1 : 0;
-        v -= treg_value(T, 6 * cf + a, 6 * cf + (e - tri_index(a, 0)));
-      }
-      slab[q] = v;
-    } else {
-      const int pq = q - ncf * kCamAcc, pr = pq / kPairAcc, e = pq - pr * kPairAcc;
-      double v = 0.0;
-      if (e < 36) {
-        int cj = (int)((sqrt(8.0 * pr + 1.0) + 1.0) * 0.5);
-        while ((cj * (cj - 1)) / 2 > pr) --cj;
-        while (((cj + 1) * cj) / 2 <= pr) ++cj;
-        const int ci = pr - (cj * (cj - 1)) / 2;
-        v = -treg_value(T, 6 * cj + e / 6, 6 * ci + (e % 6));
-      }
-      slab[q] = v;
-    }
+    slab[q] = S[q];
   }
   const double c_sum = wave_sum(acc_cost), f_sum = wave_sum(acc_fixed), x_sum = wave_sum(acc_xn2);
   const double g_max = wave_max(acc_gmax);
@@ -871,6 +695,7 @@ __host__ __device__ inline int lds_doubles_solve(int n) {
   const int N = solve_pad(n);
   return N * solve_stride(n) + 6 * N + 16;
 }
+typedef double solve_acc_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];

@@ -132,9 +132,6 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
                        [&](int a, int b) { return key(a) < key(b); });
     }
   }
-  for (int s = 0; s < L && !P.dup_cam; ++s)      // inside a line the observations are sorted by camera key
-    for (int o = P.line_ptr[s] + 1; o < P.line_ptr[s + 1]; ++o)
-      if (w->camera_index[P.ob_orig[o]] == w->camera_index[P.ob_orig[o - 1]]) { P.dup_cam = true; break; }
   P.ob_cam.resize(M);
   P.ob.resize((size_t)8 * M);
   P.nkept = 0;

@@ -23,7 +23,6 @@ namespace slslam {
 struct PackedWindow {
   int C = 0, Cf = 0, L = 0, M = 0;
   int nfree_params = 0, nkept = 0;
-  bool dup_cam = false;             // some line is observed twice by the same camera
   std::vector<int> cam_cf;          // [C]  free index or -1
   std::vector<double> cam_x;        // [C*6] initial
   std::vector<int> line_order;      // [L]  sorted position -> original line
