@@ -291,17 +291,20 @@ __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy&
   }
 }
 
-// Back-substitution form of lane_linearise: same residual and (robustified, Jacobi-scaled) line Jacobian, but the
-// camera Jacobian only as its product with the camera step, jy = Jc' y_c (obs_linearise_jy): the camera table
-// of the back-substitution holds R[9] t[3] | JL (s_w o y_w) [3] | s_t o y_t [3] per camera (kBsTab doubles).
+// Back-substitution form of lane_linearise: the residual (for the robust weight) and this observation's term of
+// w = sum_i H_cl,i^T y_c, i.e. J_l^T (J_c y_c) with the robustified, Jacobi-scaled Jacobians - contracted on the fly
+// (obs_backsub_w), neither Jacobian is formed.  The camera table of the back-substitution holds
+// R[9] t[3] | JL (s_w o y_w) [3] | s_t o y_t [3] per camera (kBsTab doubles).
 enum { kBsTab = 19 };
-__device__ __forceinline__ void lane_linearise_bs(const BatchPtrs& p, const Policy& pol, const double* bstab,
-                                                  const signed char* camcf, int ls, int j, int k, int o0, bool line_ok,
-                                                  int lflags, int cur, int safe_obs, LaneLin& L, double (&ob)[8], double (&jy)[4],
-                                                  const ObsPref& pf) {
-  (void)o0; (void)cur; (void)safe_obs;
+struct LaneBs {
+  double cost;       // rho/2 of this block at the accepted point (unused by the caller today)
+  int cam, cf;
+  bool valid, kept, line_free;
+};
+__device__ __forceinline__ void lane_linearise_bs(const Policy& pol, const double* bstab, const signed char* camcf,
+                                                  int j, int k, bool line_ok, int lflags, LaneBs& L, double (&ob)[8],
+                                                  double (&w)[4], const ObsPref& pf) {
   L.valid = line_ok && j < k;
-  const int lsafe = line_ok ? ls : 0;
   double trig[7];
 #pragma unroll
   for (int q = 0; q < 8; ++q) ob[q] = pf.ob[q];
@@ -319,19 +322,12 @@ __device__ __forceinline__ void lane_linearise_bs(const BatchPtrs& p, const Poli
   L.kept = L.valid && !(L.cf < 0 && !L.line_free);
   double cp[3], dv[3], dcp[12], ddv[9], r[4];
   line_points_jac<double>(trig, cp, dv, dcp, ddv);
-  obs_linearise_jy<double>(R, t, vw, yt, cp, dv, dcp, ddv, ob, pol.baseline, r, jy, L.Jl);
+  obs_backsub_w<double>(R, t, vw, yt, cp, dv, dcp, ddv, ob, pol.baseline, r, w);
   const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
   const double sr = huber_scale<double>(s, pol.huber_delta, &L.cost);
-  double sl[4];
+  const double sr2 = sr * sr;                    // both Jacobians carry the factor sqrt(rho')
 #pragma unroll
-  for (int a = 0; a < 4; ++a) sl[a] = pf.lsc[a] * sr;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    L.rs[q] = r[q] * sr;
-    jy[q] *= sr;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) L.Jl[4 * q + a] *= sl[a];
-  }
+  for (int a = 0; a < 4; ++a) w[a] *= pf.lsc[a] * sr2;
 }
 
 // Per-line normal-equation block, summed over the line's run of lanes (every lane of the run
@@ -1129,15 +1125,15 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { D2[q] = le[14 + q]; g[q] = le[18 + q]; }
     }
-    LaneLin L;
-    double ob[8], jy[4];
-    lane_linearise_bs(p, pol, bstab, camcf, ls, j, k, tc.o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob, jy, pf);
+    LaneBs L;
+    double ob[8], wo[4];
+    lane_linearise_bs(pol, bstab, camcf, j, k, line_ok, tc.lflags, L, ob, wo, pf);
     const bool line_active = L.line_free && k > 0;
     // w = sum_i (Jc_i^T Jl_i)^T y_c[cam_i] = sum_i Jl_i^T (Jc_i y_c)
     double wv[4] = { 0, 0, 0, 0 };
     if (L.valid && L.cf >= 0 && L.line_free) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) wv[a] = L.Jl[a] * jy[0] + L.Jl[4 + a] * jy[1] + L.Jl[8 + a] * jy[2] + L.Jl[12 + a] * jy[3];
+      for (int a = 0; a < 4; ++a) wv[a] = wo[a];
     }
     seg_sum_n<4, true>(wv, sg);
     // the next tile's loads go out here (the Jacobian is dead), see prefetch_obs

@@ -213,20 +213,22 @@ SLS_HD void obs_linearise(const T R[9], const T JL[9], const T t[3],
   }
 }
 
-// Back-substitution form: residuals, the line Jacobian Jl[4][4] and, instead of the camera Jacobian,
-// its product with the camera step:  jy[row] = (dr/dw) . yw + (dr/dt) . yt  with  dr/dw = tau^T JL,
-// i.e. jy = tau . (JL yw) + gP . yt.  The caller passes vw = JL yw (3) and yt (3): J_cam is never formed
-// (24 doubles fewer live per lane).
+// What the back-substitution needs of an observation, in one pass: the residual and  w = J_l^T (J_c y_c)  (4 values,
+// unscaled: the caller applies the Huber factor and the Jacobi scale of the line's columns).  Neither Jacobian is
+// formed: per residual row the gradients gP, gD w.r.t. the camera-frame point and direction give the row's
+// (J_c y_c) as in obs_linearise_jy, and because J_l's row is linear in (gP, gD),
+//   sum_rows (J_c y)_row J_l[row] = (R^T sum_rows (J_c y)_row gP)^T dcp + (R^T sum_rows (J_c y)_row gD)^T ddv.
 template <typename T>
-SLS_HD void obs_linearise_jy(const T R[9], const T t[3], const T vw[3], const T yt[3],
-                             const T cp[3], const T dv[3], const T dcp[12], const T ddv[9],
-                             const T ob[8], T baseline, T r[4], T jy[4], T Jl[16]) {
+SLS_HD void obs_backsub_w(const T R[9], const T t[3], const T vw[3], const T yt[3],
+                          const T cp[3], const T dv[3], const T dcp[12], const T ddv[9],
+                          const T ob[8], T baseline, T r[4], T w[4]) {
   T Q[3], P[3], dc[3];
   for (int i = 0; i < 3; ++i) {
     Q[i] = R[3 * i] * cp[0] + R[3 * i + 1] * cp[1] + R[3 * i + 2] * cp[2];
     P[i] = Q[i] + t[i];
     dc[i] = R[3 * i] * dv[0] + R[3 * i + 1] * dv[1] + R[3 * i + 2] * dv[2];
   }
+  T GP[3] = { T(0), T(0), T(0) }, GD[3] = { T(0), T(0), T(0) };
   for (int k = 0; k < 2; ++k) {
     if (k == 1) P[0] -= baseline;
     const T n0 = P[1] * dc[2] - P[2] * dc[1];
@@ -245,19 +247,19 @@ SLS_HD void obs_linearise_jy(const T R[9], const T t[3], const T vw[3], const T 
       const T tau[3] = { Q[1] * gP[2] - Q[2] * gP[1] + dc[1] * gD[2] - dc[2] * gD[1],
                          Q[2] * gP[0] - Q[0] * gP[2] + dc[2] * gD[0] - dc[0] * gD[2],
                          Q[0] * gP[1] - Q[1] * gP[0] + dc[0] * gD[1] - dc[1] * gD[0] };
-      jy[row] = tau[0] * vw[0] + tau[1] * vw[1] + tau[2] * vw[2] + gP[0] * yt[0] + gP[1] * yt[1] + gP[2] * yt[2];
-      T hP[3], hD[3];                                    // R^T gP, R^T gD
-      for (int i = 0; i < 3; ++i) {
-        hP[i] = R[i] * gP[0] + R[3 + i] * gP[1] + R[6 + i] * gP[2];
-        hD[i] = R[i] * gD[0] + R[3 + i] * gD[1] + R[6 + i] * gD[2];
-      }
-      T* jl = Jl + 4 * row;
-      for (int j = 0; j < 3; ++j)
-        jl[j] = hP[0] * dcp[3 * j] + hP[1] * dcp[3 * j + 1] + hP[2] * dcp[3 * j + 2]
-              + hD[0] * ddv[3 * j] + hD[1] * ddv[3 * j + 1] + hD[2] * ddv[3 * j + 2];
-      jl[3] = hP[0] * dcp[9] + hP[1] * dcp[10] + hP[2] * dcp[11];
+      const T jy = tau[0] * vw[0] + tau[1] * vw[1] + tau[2] * vw[2] + gP[0] * yt[0] + gP[1] * yt[1] + gP[2] * yt[2];
+      for (int i = 0; i < 3; ++i) { GP[i] += jy * gP[i]; GD[i] += jy * gD[i]; }
     }
   }
+  T hP[3], hD[3];                                        // R^T GP, R^T GD
+  for (int i = 0; i < 3; ++i) {
+    hP[i] = R[i] * GP[0] + R[3 + i] * GP[1] + R[6 + i] * GP[2];
+    hD[i] = R[i] * GD[0] + R[3 + i] * GD[1] + R[6 + i] * GD[2];
+  }
+  for (int j = 0; j < 3; ++j)
+    w[j] = hP[0] * dcp[3 * j] + hP[1] * dcp[3 * j + 1] + hP[2] * dcp[3 * j + 2]
+         + hD[0] * ddv[3 * j] + hD[1] * ddv[3 * j + 1] + hD[2] * ddv[3 * j + 2];
+  w[3] = hP[0] * dcp[9] + hP[1] * dcp[10] + hP[2] * dcp[11];
 }
 
 // ceres::HuberLoss(a) + Corrector for rho'' <= 0 (lba_problem.cpp:78-80): returns the factor

@@ -13,6 +13,16 @@ void hm_obs_linearise(const double* cam, const double* line, const double* obs, 
   slslam::line_points_jac<double>(trig, cp, dv, dcp, ddv);
   slslam::obs_linearise<double>(R, JL, cam + 3, cp, dv, dcp, ddv, obs, baseline, r, jc, jl);
 }
+// w = J_l^T (J_c y) of the back-substitution, contracted without forming the Jacobians (obs_backsub_w): y = (yw, yt)
+void hm_obs_backsub_w(const double* cam, const double* line, const double* obs, double baseline, const double* y,
+                      double* r, double* w) {
+  double R[9], JL[9], trig[7], cp[3], dv[3], dcp[12], ddv[9], vw[3];
+  slslam::cam_prepare<double>(cam, R, JL);
+  for (int i = 0; i < 3; ++i) vw[i] = JL[3 * i] * y[0] + JL[3 * i + 1] * y[1] + JL[3 * i + 2] * y[2];
+  slslam::line_trig<double>(line, trig);
+  slslam::line_points_jac<double>(trig, cp, dv, dcp, ddv);
+  slslam::obs_backsub_w<double>(R, cam + 3, vw, y + 3, cp, dv, dcp, ddv, obs, baseline, r, w);
+}
 void hm_obs_residual(const double* cam, const double* line, const double* obs, double baseline, double* r) {
   double R[9], trig[7], cp[3], dv[3];
   slslam::cam_rotation<double>(cam, R);

@@ -41,6 +41,24 @@ def test_analytic_jacobian_matches_oracle_dual_numbers(host_math, oracle):
     assert worst[0] < 1e-14 and worst[1] < 1e-13 and worst[2] < 1e-13
 
 
+def test_backsub_contraction_matches_jacobians(host_math):
+    """The back-substitution's w = J_l^T (J_c y_c), contracted on the fly (obs_backsub_w), equals the product of the
+    explicit analytic Jacobians."""
+    rng = np.random.default_rng(3)
+    w = synth.make_window(5, num_lines=40)
+    Cn, prm = w["num_cameras"], w["parameters"]
+    for i in range(0, len(w["camera_index"]), 3):
+        cam = prm[6 * w["camera_index"][i]:][:6].copy()
+        line = prm[6 * Cn + 4 * w["line_index"][i]:][:4].copy()
+        ob = w["observations"][i].copy()
+        y = rng.normal(size=6)
+        r, jc, jl, r2, wv = np.zeros(4), np.zeros((4, 6)), np.zeros((4, 4)), np.zeros(4), np.zeros(4)
+        host_math.hm_obs_linearise(_dp(cam), _dp(line), _dp(ob), C.c_double(0.12), _dp(r), _dp(jc), _dp(jl))
+        host_math.hm_obs_backsub_w(_dp(cam), _dp(line), _dp(ob), C.c_double(0.12), _dp(y), _dp(r2), _dp(wv))
+        want = jl.T @ (jc @ y)
+        assert abs(r - r2).max() < 1e-15 and abs(wv - want).max() < 1e-12 * (1 + abs(want).max())
+
+
 @pytest.mark.parametrize("scale", [0.0, 1e-12, 1e-3, 0.5, 3.0])
 def test_rotation_branches(host_math, oracle, scale):
     """theta == 0 (the identity keyframe, slam.cpp:1322) takes the first-order branch of
