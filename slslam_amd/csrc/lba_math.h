@@ -216,7 +216,7 @@ SLS_HD void obs_linearise(const T R[9], const T JL[9], const T t[3],
 // What the back-substitution needs of an observation, in one pass: the residual and  w = J_l^T (J_c y_c)  (4 values,
 // unscaled: the caller applies the Huber factor and the Jacobi scale of the line's columns).  Neither Jacobian is
 // formed: per residual row the gradients gP, gD w.r.t. the camera-frame point and direction give the row's
-// (J_c y_c) as in obs_linearise_jy, and because J_l's row is linear in (gP, gD),
+// (J_c y_c) = tau . (J_L y_w) + gP . y_t (tau = Q x gP + dc x gD: the rotation part through the camera's J_L), and because J_l's row is linear in (gP, gD),
 //   sum_rows (J_c y)_row J_l[row] = (R^T sum_rows (J_c y)_row gP)^T dcp + (R^T sum_rows (J_c y)_row gD)^T ddv.
 template <typename T>
 SLS_HD void obs_backsub_w(const T R[9], const T t[3], const T vw[3], const T yt[3],
