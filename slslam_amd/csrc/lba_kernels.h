@@ -1135,10 +1135,10 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) wv[a] = wo[a];
     }
-    seg_sum_n<4, true>(wv, sg);
-    // the next tile's loads go out here (the Jacobian is dead), see prefetch_obs
+    // the next tile's loads go out here (the linearisation's temporaries are dead), see prefetch_obs
     prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
     __builtin_amdgcn_sched_barrier(0);
+    seg_sum_n<4, true>(wv, sg);
     // every lane of the run holds the same H, g, w: all of them take the step (the candidate
     // parameters are needed by every lane below); lane 0 of the run writes and accumulates
     const int lsafe = line_ok ? ls : 0;
