@@ -4,7 +4,6 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
-#include <set>
 
 namespace slslam {
 
@@ -38,7 +37,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   if (P.Cf > kMaxFreeCams) return SLSLAM_ERR_UNSUPPORTED;
   P.cam_x.assign(w->parameters, w->parameters + (size_t)6 * C);
 
-  // lane runs: a line takes max(k, 1) consecutive lanes.  Runs are bin-packed (first fit, decreasing) into
+  // lane runs: a line takes max(k, 1) consecutive lanes.  Runs are bin-packed (best fit, decreasing) into
   // 16-lane rows, rows into 4-row tiles; the sorted line order is the order in which lines appear in the tiles.
   //   * lines with more than 16 observations take whole rows of one tile,
   //   * lines with 4..16 observations share rows; the rows are dealt to the tiles so that every tile gets about
@@ -49,59 +48,77 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   for (int i = 0; i < M; ++i) if (P.cam_cf[w->camera_index[i]] >= 0) kfree[w->line_index[i]]++;
   auto lanes_of = [&](int l) { return std::max(line_cnt[l], 1); };
   auto items_of = [&](int l) { return line_const[l] ? 0 : (kfree[l] * (kfree[l] - 1)) / 2; };
-  struct Row { int used = 0, items = 0; std::vector<int> lines; };
-  auto pack_rows = [&](std::vector<int> ls) {
-    std::stable_sort(ls.begin(), ls.end(), [&](int x, int y) { return lanes_of(x) > lanes_of(y); });
-    std::vector<Row> rows;
-    std::set<int> open_by_room[17];             // rows indexed by remaining room
-    for (int l : ls) {
-      const int need = lanes_of(l);
-      int best = -1;                            // first fit: the oldest row with enough room
-      for (int room = need; room <= 16; ++room)
-        if (!open_by_room[room].empty() && (best < 0 || *open_by_room[room].begin() < best)) best = *open_by_room[room].begin();
-      if (best < 0) { best = (int)rows.size(); rows.push_back(Row()); }
-      else open_by_room[16 - rows[best].used].erase(best);
-      rows[best].used += need; rows[best].items += items_of(l); rows[best].lines.push_back(l);
-      if (rows[best].used < 16) open_by_room[16 - rows[best].used].insert(best);
-    }
-    return rows;
+  struct Row { int used, items, head, tail; };       // the lines of a row are chained through `next`
+  std::vector<Row> rows;
+  std::vector<int> next(L, -1);
+  rows.reserve((size_t)L / 2 + 8);
+  auto append = [&](int r, int l) {
+    if (rows[r].head < 0) rows[r].head = l; else next[rows[r].tail] = l;
+    rows[r].tail = l; rows[r].used += lanes_of(l); rows[r].items += items_of(l);
   };
-  std::vector<int> big, mid, small;
+  // best fit over lines of decreasing length (counting sort by length, original order inside a length): a line goes to
+  // the fullest open row that still holds it, else it opens a row.  Returns the range of row ids created.
+  std::vector<int> by_len[17];
+  auto pack_rows = [&](int len_lo, int len_hi) {
+    const int first = (int)rows.size();
+    std::vector<int> open_by_room[17];
+    for (int len = len_hi; len >= len_lo; --len)
+      for (int l : by_len[len]) {
+        int r = -1;
+        for (int room = len; room <= 16 && r < 0; ++room)
+          if (!open_by_room[room].empty()) { r = open_by_room[room].back(); open_by_room[room].pop_back(); }
+        if (r < 0) { r = (int)rows.size(); rows.push_back(Row{0, 0, -1, -1}); }
+        append(r, l);
+        if (rows[r].used < 16) open_by_room[16 - rows[r].used].push_back(r);
+      }
+    return std::make_pair(first, (int)rows.size());
+  };
+  std::vector<int> big;
   for (int l = 0; l < L; ++l) {
     if (line_cnt[l] > 64) return SLSLAM_ERR_UNSUPPORTED;
-    (line_cnt[l] > 16 ? big : line_cnt[l] >= 4 ? mid : small).push_back(l);
+    if (line_cnt[l] > 16) big.push_back(l); else by_len[lanes_of(l)].push_back(l);
   }
-  struct TileRows { std::vector<std::vector<int>> rows; };   // a multi-row line is one entry of `rows` holding one line
-  std::vector<TileRows> tplan;
+  std::vector<int> tile_rows;                      // row ids, tile after tile
+  std::vector<int> tile_ptr(1, 0);
   {
     int used_rows = 4;
     std::stable_sort(big.begin(), big.end(), [&](int x, int y) { return line_cnt[x] > line_cnt[y]; });
-    for (int l : big) {
+    for (int l : big) {                            // a long line is a row entry of its own that spans (k + 15) / 16 rows
       const int nr = (line_cnt[l] + 15) / 16;
-      if (used_rows + nr > 4) { tplan.push_back(TileRows()); used_rows = 0; }
-      tplan.back().rows.push_back(std::vector<int>(1, l));
+      if (used_rows + nr > 4) { if (!tile_rows.empty()) tile_ptr.push_back((int)tile_rows.size()); used_rows = 0; }
+      rows.push_back(Row{0, 0, -1, -1});
+      append((int)rows.size() - 1, l);
+      tile_rows.push_back((int)rows.size() - 1);
       used_rows += nr;
     }
+    if (!tile_rows.empty()) tile_ptr.push_back((int)tile_rows.size());
   }
   {
-    std::vector<Row> rows = pack_rows(mid);
-    std::stable_sort(rows.begin(), rows.end(), [](const Row& x, const Row& y) { return x.items > y.items; });
-    const int R = (int)rows.size(), T = (R + 3) / 4, base = (int)tplan.size();
-    tplan.resize(base + T);
-    for (int r = 0; r < R; ++r) {                 // boustrophedon deal: heavy rows meet light rows
+    const std::pair<int, int> rr = pack_rows(4, 16);
+    std::vector<int> order(rr.second - rr.first);
+    std::iota(order.begin(), order.end(), rr.first);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rows[x].items > rows[y].items; });
+    const int R = (int)order.size(), T = (R + 3) / 4;
+    std::vector<int> slot((size_t)4 * T, -1);
+    for (int r = 0; r < R; ++r) {                  // boustrophedon deal: heavy rows meet light rows
       const int pass = r / T, pos = r % T;
-      tplan[base + ((pass & 1) ? T - 1 - pos : pos)].rows.push_back(rows[r].lines);
+      slot[(size_t)4 * ((pass & 1) ? T - 1 - pos : pos) + pass] = order[r];
+    }
+    for (int t = 0; t < T; ++t) {
+      for (int q = 0; q < 4; ++q) if (slot[(size_t)4 * t + q] >= 0) tile_rows.push_back(slot[(size_t)4 * t + q]);
+      tile_ptr.push_back((int)tile_rows.size());
     }
   }
   {
-    const std::vector<Row> rows = pack_rows(small);
-    for (size_t r = 0; r < rows.size(); ++r) {
-      if (r % 4 == 0) tplan.push_back(TileRows());
-      tplan.back().rows.push_back(rows[r].lines);
+    const std::pair<int, int> rr = pack_rows(1, 3);
+    for (int r = rr.first; r < rr.second; ++r) {
+      tile_rows.push_back(r);
+      if ((r - rr.first) % 4 == 3 || r + 1 == rr.second) tile_ptr.push_back((int)tile_rows.size());
     }
   }
   P.line_order.clear();
-  for (const TileRows& tr : tplan) for (const auto& row : tr.rows) for (int l : row) P.line_order.push_back(l);
+  P.line_order.reserve(L);
+  for (int r : tile_rows) for (int l = rows[r].head; l >= 0; l = next[l]) P.line_order.push_back(l);
   std::vector<int> line_pos(L);
   for (int s = 0; s < L; ++s) line_pos[P.line_order[s]] = s;
 
@@ -126,10 +143,16 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
       const int s = line_pos[w->line_index[i]];
       P.ob_orig[P.line_ptr[s] + fill[s]++] = i;
     }
-    for (int s = 0; s < L; ++s) {
-      auto key = [&](int i) { const int c = w->camera_index[i]; return P.cam_cf[c] >= 0 ? P.cam_cf[c] : P.Cf + c; };
-      std::stable_sort(P.ob_orig.begin() + P.line_ptr[s], P.ob_orig.begin() + P.line_ptr[s + 1],
-                       [&](int a, int b) { return key(a) < key(b); });
+    auto key = [&](int i) { const int c = w->camera_index[i]; return P.cam_cf[c] >= 0 ? P.cam_cf[c] : P.Cf + c; };
+    for (int s = 0; s < L; ++s) {                  // stable insertion sort of the (at most 64) observations of a line
+      int* o = P.ob_orig.data() + P.line_ptr[s];
+      const int k = P.line_ptr[s + 1] - P.line_ptr[s];
+      for (int a = 1; a < k; ++a) {
+        const int v = o[a], kv = key(v);
+        int b = a;
+        while (b > 0 && key(o[b - 1]) > kv) { o[b] = o[b - 1]; --b; }
+        o[b] = v;
+      }
     }
   }
   P.ob_cam.resize(M);
@@ -145,14 +168,18 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   // tiles, their lane maps and their off-diagonal camera-pair work items
   {
     int s = 0;
-    for (const TileRows& tr : tplan) {
+    P.tiles.reserve(tile_ptr.size());
+    { size_t ni = 0; for (int l = 0; l < L; ++l) ni += (size_t)items_of(l); P.items.reserve(2 * ni); }
+    P.lane_map.reserve(64 * tile_ptr.size());
+    uint16_t map[64];
+    for (size_t ti = 0; ti + 1 < tile_ptr.size(); ++ti) {
       Tile t;
       t.line_begin = s; t.item_off = (int)(P.items.size() / 2);
-      std::vector<uint16_t> map(64, (uint16_t)0x00FF);
+      for (int q = 0; q < 64; ++q) map[q] = (uint16_t)0x00FF;
       int lane = 0, nl = 0, min_lanes = 64, max_run = 1, multi = 0;
-      for (const auto& row : tr.rows) {
-        lane = (lane + 15) & ~15;                            // every entry of the plan starts a row
-        for (size_t q = 0; q < row.size(); ++q, ++s, ++nl) {
+      for (int ri = tile_ptr[ti]; ri < tile_ptr[ti + 1]; ++ri) {
+        lane = (lane + 15) & ~15;                            // every row entry starts a row
+        for (int l = rows[tile_rows[ri]].head; l >= 0; l = next[l], ++s, ++nl) {
           const int k = P.line_ptr[s + 1] - P.line_ptr[s], run = std::max(k, 1);
           for (int j = 0; j < run; ++j) map[lane + j] = (uint16_t)(nl | (j << 8));
           min_lanes = std::min(min_lanes, run);
@@ -172,7 +199,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
       t.flags = (int16_t)(multi | (rounds_log2 << 1) | (max_run << 3));
       t.nitems = (int)(P.items.size() / 2) - t.item_off;
       P.tiles.push_back(t);
-      P.lane_map.insert(P.lane_map.end(), map.begin(), map.end());
+      P.lane_map.insert(P.lane_map.end(), map, map + 64);
     }
   }
   return SLSLAM_OK;
