@@ -74,19 +74,55 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool in_arena = false;            // carved out of a DeviceArena: the arena frees it
   int alloc(size_t count) {
-    n = count;
+    n = count; in_arena = false;
     if (count == 0) { p = nullptr; return SLSLAM_OK; }
     HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
     return SLSLAM_OK;
   }
-  int upload(const std::vector<T>& h) {
-    int rc = alloc(h.size());
-    if (rc) return rc;
-    if (!h.empty()) HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  void release() { if (p && !in_arena) (void)hipFree(p); p = nullptr; n = 0; in_arena = false; }
+};
+
+// All device arrays of a batch in ONE allocation, everything the host fills in ONE host-to-device copy: the build of
+// a single window (slslam_lba_solve, the per-keyframe call of the reference) is dominated by per-call driver overheads
+// otherwise (~35 hipMalloc + ~20 synchronous hipMemcpy).
+struct DeviceArena {
+  struct Item { void** pp; size_t bytes; const void* host; int group; size_t off; };   // group 0 uploaded, 1 scratch, 2 zeroed
+  std::vector<Item> items;
+  char* base = nullptr;
+  template <typename T>
+  void add(DevBuf<T>& d, size_t count, const T* host, int group) {
+    d.n = count; d.in_arena = true; d.p = nullptr;
+    items.push_back(Item{ (void**)&d.p, count * sizeof(T), host, group, 0 });
+  }
+  template <typename T> void upload(DevBuf<T>& d, const std::vector<T>& h) { add(d, h.size(), h.data(), 0); }
+  template <typename T> void scratch(DevBuf<T>& d, size_t count) { add(d, count, (const T*)nullptr, 1); }
+  template <typename T> void zeroed(DevBuf<T>& d, size_t count) { add(d, count, (const T*)nullptr, 2); }
+  int commit() {
+    size_t off = 0, upload_end = 0, zero_begin = 0;
+    for (int group = 0; group < 3; ++group) {        // uploaded arrays first, then scratch, then the zero-initialised ones
+      if (group == 2) zero_begin = off;
+      for (Item& it : items) {
+        if (it.group != group) continue;
+        it.off = off;
+        off += (it.bytes + 255) & ~(size_t)255;
+      }
+      if (group == 0) upload_end = off;
+    }
+    if (off == 0) return SLSLAM_OK;
+    HIP_TRY(hipMalloc((void**)&base, off));
+    std::vector<char> stage(upload_end);
+    for (const Item& it : items) {
+      *it.pp = base + it.off;
+      if (it.host && it.bytes) std::memcpy(stage.data() + it.off, it.host, it.bytes);
+    }
+    if (upload_end) HIP_TRY(hipMemcpy(base, stage.data(), upload_end, hipMemcpyHostToDevice));
+    if (off > zero_begin) HIP_TRY(hipMemset(base + zero_begin, 0, off - zero_begin));
+    items.clear();
     return SLSLAM_OK;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void release() { if (base) (void)hipFree(base); base = nullptr; items.clear(); }
 };
 
 Policy make_policy(const slslam_solver_options& o) {
@@ -123,6 +159,7 @@ struct slslam_lba_batch {
   std::vector<int> h_ob_orig_off;          // per window offset into d_ob_orig
   bool downloaded = false;
   // device
+  DeviceArena arena;
   DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<uint8_t> d_items; DevBuf<uint16_t> d_lane_map;
   DevBuf<unsigned long long> d_iter_counter;
   DevBuf<unsigned int> d_active;
@@ -153,6 +190,7 @@ struct slslam_lba_batch {
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
     d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release(); d_active.release();
     d_fstore.release(); d_line_elim.release();
+    arena.release();
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     if (capture_stream) { (void)hipStreamDestroy(capture_stream); capture_stream = nullptr; }
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -278,55 +316,52 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     s.radius = b->pol.initial_radius; s.decrease_factor = 2.0; s.status = kRunning; s.fresh = 1;
   }
 
-  // ---- upload
+  // ---- one allocation, one upload
   int rc;
-  if ((rc = b->d_wins.upload(b->h_wins))) return rc;
-  if ((rc = b->d_tiles.upload(tiles))) return rc;
-  if ((rc = b->d_chunks.upload(chunks))) return rc;
+  DeviceArena& ar = b->arena;
+  ar.upload(b->d_wins, b->h_wins);
+  ar.upload(b->d_tiles, tiles);
+  ar.upload(b->d_chunks, chunks);
   if (items.empty()) items.push_back(0);
-  if ((rc = b->d_items.upload(items))) return rc;
+  ar.upload(b->d_items, items);
   if (lane_map.empty()) lane_map.assign(64, (uint16_t)0x00FF);
-  if ((rc = b->d_lane_map.upload(lane_map))) return rc;
+  ar.upload(b->d_lane_map, lane_map);
   if (cam_x.empty()) cam_x.assign(12, 0.0);
-  if ((rc = b->d_cam_x.upload(cam_x))) return rc;
+  ar.upload(b->d_cam_x, cam_x);
   if (cam_x0.empty()) cam_x0.assign(6, 0.0);
-  if ((rc = b->d_cam_x0.upload(cam_x0))) return rc;
-  if ((rc = b->d_cam_scale.alloc(std::max<size_t>(6, (size_t)6 * ncam)))) return rc;
+  ar.upload(b->d_cam_x0, cam_x0);
+  ar.zeroed(b->d_cam_scale, std::max<size_t>(6, (size_t)6 * ncam));
   if (cam_cf.empty()) { cam_cf.push_back(-1); cam_win.push_back(0); }
-  if ((rc = b->d_cam_cf.upload(cam_cf))) return rc;
-  if ((rc = b->d_cam_win.upload(cam_win))) return rc;
+  ar.upload(b->d_cam_cf, cam_cf);
+  ar.upload(b->d_cam_win, cam_win);
   if (line_x.empty()) line_x.assign(2 * kLineRec, 0.0);
-  if ((rc = b->d_line_x.upload(line_x))) return rc;
+  ar.upload(b->d_line_x, line_x);
   if (line_u0.empty()) line_u0.assign(4, 0.0);
-  if ((rc = b->d_line_x0.upload(line_u0))) return rc;
-  if ((rc = b->d_line_scale.alloc(std::max<size_t>(4, (size_t)4 * nline)))) return rc;
-  if ((rc = b->d_line_ptr.upload(line_ptr))) return rc;
+  ar.upload(b->d_line_x0, line_u0);
+  ar.zeroed(b->d_line_scale, std::max<size_t>(4, (size_t)4 * nline));
+  ar.upload(b->d_line_ptr, line_ptr);
   if (line_flags.empty()) { line_flags.push_back(1); line_win.push_back(0); line_orig.push_back(0); }
-  if ((rc = b->d_line_flags.upload(line_flags))) return rc;
-  if ((rc = b->d_line_win.upload(line_win))) return rc;
-  if ((rc = b->d_line_orig.upload(line_orig))) return rc;
+  ar.upload(b->d_line_flags, line_flags);
+  ar.upload(b->d_line_win, line_win);
+  ar.upload(b->d_line_orig, line_orig);
   if (ob.empty()) ob.assign(8, 0.0);
-  if ((rc = b->d_ob.upload(ob))) return rc;
+  ar.upload(b->d_ob, ob);
   if (ob_cam.empty()) { ob_cam.push_back(0); ob_orig.push_back(0); }
-  if ((rc = b->d_ob_cam.upload(ob_cam))) return rc;
-  if ((rc = b->d_ob_orig.upload(ob_orig))) return rc;
-  if ((rc = b->d_slab.alloc(std::max<size_t>(1, (size_t)slab)))) return rc;
-  if ((rc = b->d_bs_part.alloc(std::max<size_t>(1, (size_t)b->nchunk * kBsStride)))) return rc;
-  if ((rc = b->d_cost_part.alloc(std::max<size_t>(1, (size_t)b->nchunk)))) return rc;
-  if ((rc = b->d_ysys.alloc(std::max<size_t>(1, (size_t)sys)))) return rc;
-  if ((rc = b->d_fstore.alloc(b->opt.reuse_elimination ? (size_t)24 * (size_t)std::max<long long>(1, nobs) : 2))) return rc;
-  if ((rc = b->d_line_elim.alloc(std::max<size_t>(1, (size_t)nline * kLineElim)))) return rc;
-  if ((rc = b->d_params_out.alloc(std::max<size_t>(1, (size_t)param_off)))) return rc;
-  if ((rc = b->d_state.upload(b->h_state0))) return rc;
-  if ((rc = b->d_trace.alloc(std::max<size_t>(1, (size_t)B * kMaxTrace)))) return rc;
-  if ((rc = b->d_param_off.upload(b->h_param_off))) return rc;
-  if ((rc = b->d_iter_counter.alloc(1))) return rc;
-  HIP_TRY(hipMemset(b->d_iter_counter.p, 0, sizeof(unsigned long long)));
-  if ((rc = b->d_active.alloc(1))) return rc;
-  HIP_TRY(hipMemset(b->d_active.p, 0, sizeof(unsigned int)));
-  HIP_TRY(hipMemset(b->d_trace.p, 0, b->d_trace.n * sizeof(IterRec)));
-  HIP_TRY(hipMemset(b->d_cam_scale.p, 0, b->d_cam_scale.n * sizeof(double)));
-  HIP_TRY(hipMemset(b->d_line_scale.p, 0, b->d_line_scale.n * sizeof(double)));
+  ar.upload(b->d_ob_cam, ob_cam);
+  ar.upload(b->d_ob_orig, ob_orig);
+  ar.scratch(b->d_slab, std::max<size_t>(1, (size_t)slab));
+  ar.scratch(b->d_bs_part, std::max<size_t>(1, (size_t)b->nchunk * kBsStride));
+  ar.scratch(b->d_cost_part, std::max<size_t>(1, (size_t)b->nchunk));
+  ar.scratch(b->d_ysys, std::max<size_t>(1, (size_t)sys));
+  ar.scratch(b->d_fstore, b->opt.reuse_elimination ? (size_t)24 * (size_t)std::max<long long>(1, nobs) : 2);
+  ar.scratch(b->d_line_elim, std::max<size_t>(1, (size_t)nline * kLineElim));
+  ar.scratch(b->d_params_out, std::max<size_t>(1, (size_t)param_off));
+  ar.upload(b->d_state, b->h_state0);
+  ar.zeroed(b->d_trace, std::max<size_t>(1, (size_t)B * kMaxTrace));
+  ar.upload(b->d_param_off, b->h_param_off);
+  ar.zeroed(b->d_iter_counter, 1);
+  ar.zeroed(b->d_active, 1);
+  if ((rc = ar.commit())) return rc;
 
   BatchPtrs& p = b->ptrs;
   p.wins = b->d_wins.p; p.tiles = b->d_tiles.p; p.chunks = b->d_chunks.p; p.items = b->d_items.p; p.lane_map = b->d_lane_map.p;
@@ -631,17 +666,17 @@ extern "C" int slslam_lba_solve(const slslam_lba_window* w, const slslam_solver_
   slslam_solver_options o;
   if (opt) o = *opt; else slslam_default_options(&o);
   if (o.max_num_iterations < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
-  {   // malformed input is reported as such on any machine, before the device is looked for
-    PackedWindow probe;
-    const int prc = pack_window(w, &probe);
+  PackedWindow pw;   // malformed input is reported as such on any machine, before the device is looked for
+  {
+    const int prc = pack_window(w, &pw);
     if (prc != SLSLAM_OK) return prc;
   }
   slslam_lba_batch* b = nullptr;
   int rc = slslam_lba_batch_create(-1, &b);
   if (rc) return rc;
   o.use_graph = 0;   // a single solve is replayed once: capture would only add latency
-  if ((rc = slslam_lba_batch_add(b, w, nullptr)) == SLSLAM_OK &&
-      (rc = slslam_lba_batch_finalize(b, &o)) == SLSLAM_OK &&
+  b->wins.push_back(std::move(pw));
+  if ((rc = slslam_lba_batch_finalize(b, &o)) == SLSLAM_OK &&
       (rc = slslam_lba_batch_solve(b, nullptr)) == SLSLAM_OK &&
       (rc = slslam_lba_batch_download(b, nullptr)) == SLSLAM_OK) {
     rc = slslam_lba_batch_get_parameters(b, 0, w->parameters);
