@@ -9,7 +9,10 @@ __global__ __launch_bounds__(64) void k(double* out, int iters) {
   const int lane = threadIdx.x;
   for (int q = lane; q < 2048; q += 64) S[q] = 0.0;
   __syncthreads();
-  const int base = CONFLICT ? (lane % 12) * 39 : lane * 31;       // 12 "cameras" -> ~5 lanes per address
+  // CONFLICT 1: 12 "cameras" -> ~5 lanes per address, spread over the wave; 2: 4 lanes per address, one in each 16-lane
+  // row; 3: 4 adjacent lanes per address; 4: 2 lanes per address, 32 lanes apart; 5: 2 adjacent lanes per address
+  const int base = CONFLICT == 1 ? (lane % 12) * 39 : CONFLICT == 2 ? (lane & 15) * 39 : CONFLICT == 3 ? (lane >> 2) * 39
+                 : CONFLICT == 4 ? (lane & 31) * 39 : CONFLICT == 5 ? (lane >> 1) * 39 : lane * 31;
   double v = 1.0 + lane;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -41,6 +44,7 @@ template <int MODE, int CONFLICT> void run(const char* name) {
 }
 int main() {
   run<0, 0>("ds_add_f64"); run<0, 1>("ds_add_f64");
+  run<0, 2>("ds_add_f64"); run<0, 3>("ds_add_f64"); run<0, 4>("ds_add_f64"); run<0, 5>("ds_add_f64");
   run<1, 0>("ds_add_u64"); run<1, 1>("ds_add_u64");
   run<2, 0>("ds_add_u32"); run<2, 1>("ds_add_u32");
   run<4, 0>("ds_add_f32"); run<4, 1>("ds_add_f32");
