@@ -45,16 +45,18 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   //   * lines with fewer than 4 observations (which need more than one sin/cos round per lane in the
   //     back-substitution) are kept in tiles of their own.
   std::vector<int> kfree(L, 0);
-  for (int i = 0; i < M; ++i) if (P.cam_cf[w->camera_index[i]] >= 0) kfree[w->line_index[i]]++;
+  std::vector<unsigned> fmask(L, 0u);            // free cameras that see the line
+  for (int i = 0; i < M; ++i)
+    if (P.cam_cf[w->camera_index[i]] >= 0) { kfree[w->line_index[i]]++; fmask[w->line_index[i]] |= 1u << P.cam_cf[w->camera_index[i]]; }
   auto lanes_of = [&](int l) { return std::max(line_cnt[l], 1); };
   auto items_of = [&](int l) { return line_const[l] ? 0 : (kfree[l] * (kfree[l] - 1)) / 2; };
-  struct Row { int used, items, head, tail; };       // the lines of a row are chained through `next`
+  struct Row { int used, items, head, tail; unsigned mask; };   // the lines of a row are chained through `next`; mask: free cameras
   std::vector<Row> rows;
   std::vector<int> next(L, -1);
   rows.reserve((size_t)L / 2 + 8);
   auto append = [&](int r, int l) {
     if (rows[r].head < 0) rows[r].head = l; else next[rows[r].tail] = l;
-    rows[r].tail = l; rows[r].used += lanes_of(l); rows[r].items += items_of(l);
+    rows[r].tail = l; rows[r].used += lanes_of(l); rows[r].items += items_of(l); rows[r].mask |= fmask[l];
   };
   // best fit over lines of decreasing length (counting sort by length, original order inside a length): a line goes to
   // the fullest open row that still holds it, else it opens a row.  Returns the range of row ids created.
@@ -64,10 +66,17 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
     std::vector<int> open_by_room[17];
     for (int len = len_hi; len >= len_lo; --len)
       for (int l : by_len[len]) {
+        // the fullest open row that holds the line - and, among the rows of that fill, preferably one none of whose
+        // lines shares a free camera with it: the lanes of one 16-lane row that add to the same camera record
+        // serialise in the LDS (tools/micro/lds_atomic_bench.hip)
         int r = -1;
-        for (int room = len; room <= 16 && r < 0; ++room)
-          if (!open_by_room[room].empty()) { r = open_by_room[room].back(); open_by_room[room].pop_back(); }
-        if (r < 0) { r = (int)rows.size(); rows.push_back(Row{0, 0, -1, -1}); }
+        for (int pass = 0; pass < 2 && r < 0; ++pass)          // pass 0: rows without a common free camera only
+          for (int room = len; room <= 16 && r < 0; ++room) {
+            std::vector<int>& cand = open_by_room[room];
+            for (size_t c = cand.size(); c-- > 0 && cand.size() - c <= 32;)
+              if (pass == 1 || !(rows[cand[c]].mask & fmask[l])) { r = cand[c]; cand.erase(cand.begin() + c); break; }
+          }
+        if (r < 0) { r = (int)rows.size(); rows.push_back(Row{0, 0, -1, -1, 0u}); }
         append(r, l);
         if (rows[r].used < 16) open_by_room[16 - rows[r].used].push_back(r);
       }
@@ -86,7 +95,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
     for (int l : big) {                            // a long line is a row entry of its own that spans (k + 15) / 16 rows
       const int nr = (line_cnt[l] + 15) / 16;
       if (used_rows + nr > 4) { if (!tile_rows.empty()) tile_ptr.push_back((int)tile_rows.size()); used_rows = 0; }
-      rows.push_back(Row{0, 0, -1, -1});
+      rows.push_back(Row{0, 0, -1, -1, 0u});
       append((int)rows.size() - 1, l);
       tile_rows.push_back((int)rows.size() - 1);
       used_rows += nr;
