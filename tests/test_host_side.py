@@ -168,8 +168,8 @@ def _check_tiles(P, w, L):
 def test_pack_long_and_short_lines(host_math):
     """Lines with more than 16 observations take whole rows; lines with fewer than 4 keep to tiles of their own."""
     rng = np.random.default_rng(5)
-    Cn, L = 40, 60
-    counts = np.concatenate([rng.integers(17, 41, 6), rng.integers(4, 17, 30), rng.integers(0, 4, 24)])
+    Cn, L = 64, 60
+    counts = np.concatenate([[64, 49, 48, 33, 32, 17], rng.integers(4, 17, 28), [16, 16], rng.integers(0, 4, 24)])
     cam, line = [], []
     for l, k in enumerate(counts):
         cam += list(rng.choice(Cn, size=k, replace=False)); line += [l] * k
@@ -180,6 +180,13 @@ def test_pack_long_and_short_lines(host_math):
     rc, P = _pack(host_math, w)
     assert rc == 0 and P["Cf"] == 12
     _check_tiles(P, w, L)
+    # a line with more than 64 observations does not fit a wave: reported, not mangled
+    too_long = dict(w, camera_index=np.concatenate([w["camera_index"], (np.arange(65) % 64).astype(np.int32)]),
+                    line_index=np.concatenate([w["line_index"], np.full(65, 59, dtype=np.int32)]),
+                    fixed_index=np.concatenate([w["fixed_index"], np.ones(130, dtype=np.int32)]),
+                    observations=np.concatenate([w["observations"], rng.normal(size=(65, 8))]),
+                    parameters=w["parameters"])
+    assert _pack(host_math, too_long)[0] == 4
     runs = {}
     for t, (lb, nl, flags, ni) in enumerate(P["tiles"]):
         ks = [max(int(P["line_ptr"][s + 1] - P["line_ptr"][s]), 1) for s in range(lb, lb + nl)]
