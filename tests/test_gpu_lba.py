@@ -87,7 +87,10 @@ def test_long_and_short_line_runs(hip, oracle):
                  observations=mixed["observations"][keep], fixed_index=mixed["fixed_index"].reshape(-1, 2)[keep].reshape(-1))
     cm = np.bincount(mixed["line_index"], minlength=120)
     assert cm.min() == 1 and cm.max() > 16
-    for w in (long_w, short_w, mixed):
+    # the largest shape the path takes: 64 keyframes, lines observed by all of them (runs of 64 lanes = a whole tile)
+    full_w = synth.make_window(21, num_lines=40, num_kf=64, num_free=12, mean_track=300.0)
+    assert np.bincount(full_w["line_index"]).max() == 64
+    for w in (long_w, short_w, mixed, full_w):
         x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
         x1, s1, t1 = hip.lba_solve(w)
         _assert_trace_parity(t0, t1, n=3)
