@@ -266,6 +266,9 @@ int slslam_ransac_motion_batch(int num_frames, const slslam_ransac_trials* frame
 
 /* ------------------------------------------------------------------ misc */
 int         slslam_device_count(void);          /* 0 when no HIP device is usable */
+/* The one-shot entry points (slslam_lba_solve, slslam_po_solve) keep the device block of their last call per host thread
+ * and reuse it when it is large enough (allocation costs as much as a small solve).  Frees the calling thread's block. */
+void        slslam_release_cached_memory(void);
 const char* slslam_version(void);
 const char* slslam_status_string(int status);
 

@@ -82,7 +82,7 @@ EXPORTS = [
     "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
-    "slslam_po_solve", "slslam_po_structure", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_version", "slslam_status_string",
+    "slslam_po_solve", "slslam_po_structure", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_release_cached_memory", "slslam_version", "slslam_status_string",
 ]
 
 _lib = None
@@ -128,6 +128,7 @@ def lib():
     L.slslam_ransac_motion_batch.argtypes = [C.c_int, C.POINTER(RansacTrials), C.POINTER(dp), C.c_double, C.c_double, C.c_double,
                                              C.c_int, ip, ip, dp, C.POINTER(C.POINTER(C.c_ulonglong))]
     L.slslam_device_count.restype = C.c_int
+    L.slslam_release_cached_memory.restype = None
     L.slslam_version.restype = C.c_char_p
     L.slslam_status_string.argtypes = [C.c_int]
     L.slslam_status_string.restype = C.c_char_p
@@ -156,6 +157,11 @@ def default_options(**kw):
             raise TypeError("unknown solver option %r" % k)
         setattr(o, k, v)
     return o
+
+
+def release_cached_memory():
+    """Frees the device block the one-shot solves of this thread keep between calls."""
+    lib().slslam_release_cached_memory()
 
 
 def device_count():

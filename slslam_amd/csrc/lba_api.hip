@@ -12,6 +12,7 @@
 
 #include "../../include/slslam_hip.h"
 #include "lba_kernels.h"
+#include "device_cache.h"
 #include "lba_pack.h"
 
 using namespace slslam;
@@ -47,6 +48,8 @@ extern "C" void slslam_default_options(slslam_solver_options* o) {
   o->po_factor_fp32 = 0;
   o->po_dense_factor = 0;
 }
+
+extern "C" void slslam_release_cached_memory(void) { DeviceBlockCache::drop(); }
 
 extern "C" int slslam_device_count(void) {
   int n = 0;
@@ -91,6 +94,9 @@ struct DeviceArena {
   struct Item { void** pp; size_t bytes; const void* host; int group; size_t off; };   // group 0 uploaded, 1 scratch, 2 zeroed
   std::vector<Item> items;
   char* base = nullptr;
+  size_t bytes = 0;
+  int device = 0;
+  bool cached = false;              // one-shot solves: the block comes from / returns to the thread's DeviceBlockCache
   template <typename T>
   void add(DevBuf<T>& d, size_t count, const T* host, int group) {
     d.n = count; d.in_arena = true; d.p = nullptr;
@@ -111,7 +117,9 @@ struct DeviceArena {
       if (group == 0) upload_end = off;
     }
     if (off == 0) return SLSLAM_OK;
-    HIP_TRY(hipMalloc((void**)&base, off));
+    bytes = off;
+    if (cached) HIP_TRY(DeviceBlockCache::acquire(off, device, &base));
+    else HIP_TRY(hipMalloc((void**)&base, off));
     std::vector<char> stage(upload_end);
     for (const Item& it : items) {
       *it.pp = base + it.off;
@@ -122,7 +130,10 @@ struct DeviceArena {
     items.clear();
     return SLSLAM_OK;
   }
-  void release() { if (base) (void)hipFree(base); base = nullptr; items.clear(); }
+  void release() {
+    if (base) { if (cached) DeviceBlockCache::give_back(base, bytes, device); else (void)hipFree(base); }
+    base = nullptr; items.clear();
+  }
 };
 
 Policy make_policy(const slslam_solver_options& o) {
@@ -319,6 +330,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   // ---- one allocation, one upload
   int rc;
   DeviceArena& ar = b->arena;
+  ar.device = b->device;
   ar.upload(b->d_wins, b->h_wins);
   ar.upload(b->d_tiles, tiles);
   ar.upload(b->d_chunks, chunks);
@@ -676,6 +688,7 @@ extern "C" int slslam_lba_solve(const slslam_lba_window* w, const slslam_solver_
   if (rc) return rc;
   o.use_graph = 0;   // a single solve is replayed once: capture would only add latency
   b->wins.push_back(std::move(pw));
+  b->arena.cached = true;
   if ((rc = slslam_lba_batch_finalize(b, &o)) == SLSLAM_OK &&
       (rc = slslam_lba_batch_solve(b, nullptr)) == SLSLAM_OK &&
       (rc = slslam_lba_batch_download(b, nullptr)) == SLSLAM_OK) {

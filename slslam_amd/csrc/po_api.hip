@@ -11,6 +11,7 @@
 
 #include "../../include/slslam_hip.h"
 #include "po_kernels.h"
+#include "device_cache.h"
 
 using namespace slslam;
 
@@ -171,6 +172,8 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   std::memset(&p, 0, sizeof(p));
   PoChain* d_chains = nullptr;
   char* arena = nullptr;
+  size_t arena_bytes = 0;
+  int arena_device = 0;
   const int nj = structured ? n - n_chain : 0;
   const int nblk_j = (nj + kNB - 1) / kNB;
   int *d_p1 = nullptr, *d_p2 = nullptr, *d_slot = nullptr;
@@ -194,7 +197,9 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
                  o_linv = take(sizeof(double) * nb2), o_Hf = take(f32 ? sizeof(float) * (size_t)(n > 0 ? n : 1) * ld : 0),
                  o_linvf = take(f32 ? sizeof(float) * nb2 : 0), o_scal = take(sizeof(double) * 8), o_flags = take(sizeof(int) * 2),
                  o_st = take(sizeof(LMState)), o_trace = take(sizeof(IterRec) * kMaxTrace), o_chains = take(sizeof(PoChain) * (chains.size() + 1));
-    PO_TRY(hipMalloc((void**)&arena, off));
+    arena_bytes = off;
+    (void)hipGetDevice(&arena_device);
+    PO_TRY(DeviceBlockCache::acquire(off, arena_device, &arena));   // the block of the previous one-shot solve, if large enough
     d_p1 = (int*)(arena + o_p1); d_p2 = (int*)(arena + o_p2); d_slot = (int*)(arena + o_slot); d_cons = (double*)(arena + o_cons);
     p.x = (double*)(arena + o_x); p.scale = (double*)(arena + o_scale); p.H = (double*)(arena + o_H); p.g = (double*)(arena + o_g);
     p.d2 = (double*)(arena + o_d2); p.y = (double*)(arena + o_y); d_linv = (double*)(arena + o_linv);
@@ -312,7 +317,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     }
   }
 done:
-  (void)hipFree(arena);
+  DeviceBlockCache::give_back(arena, arena_bytes, arena_device);
   return rc;
 }
 

@@ -306,3 +306,21 @@ def test_randomised_shapes_against_oracle(hip, oracle):
     bad, worst = mod.run(60, seed=3, verbose=True)
     assert bad == 0
     assert worst["trace"] < 1e-6
+
+
+def test_one_shot_solves_reuse_their_device_block(hip, oracle):
+    """slslam_lba_solve / slslam_po_solve keep the device block of the previous call (device_cache.h): solves of different
+    shapes back to back, interleaved with pose-graph solves, still match the oracle - nothing depends on fresh memory."""
+    shapes = [dict(num_lines=300), dict(num_lines=40, num_kf=6, num_free=3), dict(num_lines=500), dict(num_lines=60, num_kf=24, num_free=12, mean_track=30.0)]
+    g = synth.make_pose_graph(3, num_poses=60, num_loops=4)
+    xg0, sg0, _ = oracle.po_solve(g)
+    for rep in range(2):
+        for i, kw in enumerate(shapes):
+            w = synth.make_window(40 + i, **kw)
+            x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+            x1, s1, t1 = hip.lba_solve(w)
+            _assert_trace_parity(t0, t1, n=3)
+            _assert_summary_parity(s0, s1)
+            xg, sg, _ = hip.po_solve(g)
+            assert abs(sg["final_cost"] - sg0["final_cost"]) <= 1e-6 * sg0["final_cost"] + 1e-15 and np.abs(xg - xg0).max() < 1e-5
+        hip.release_cached_memory()
