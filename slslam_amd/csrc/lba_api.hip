@@ -182,6 +182,7 @@ struct slslam_lba_batch {
   BatchPtrs ptrs;
   int nchunk = 0, nline = 0, ncam = 0;
   long long nobs = 0;
+  int num_cus = 256;
   size_t lds_lin = 0, lds_solve = 0, lds_bs = 0, lds_bs_stream = 0, lds_cost = 0;
   // graph
   hipGraphExec_t graph_exec = nullptr;
@@ -250,6 +251,10 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if (!(b->opt.initial_trust_region_radius > 0.0) || !(b->opt.baseline == b->opt.baseline)) return SLSLAM_ERR_INVALID_ARGUMENT;
   b->pol = make_policy(b->opt);
   HIP_TRY(hipSetDevice(b->device));
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) == hipSuccess && cus > 0) b->num_cus = cus;
+  }
   const int B = (int)b->wins.size();
 
   // ---- global layout
@@ -280,7 +285,15 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     // fill the chip when the batch is small.
     int per_chunk;
     if (b->opt.chunks_per_window > 0) per_chunk = std::max(1, (wd.ntiles + b->opt.chunks_per_window - 1) / b->opt.chunks_per_window);
-    else per_chunk = (int)std::min<long long>(32, std::max<long long>(4, total_tiles / 2048));
+    else {
+      // the sweeps run 8 one-wave workgroups per CU (LDS): the same number of chunks for every window, chosen so that
+      // the batch fills whole rounds of the chip's wave slots with about 36 tiles per chunk at most
+      // (1024 bench windows: 6 chunks of 33 tiles = 6144 waves = 3 rounds of 256 CUs x 8), at least 4 tiles per chunk
+      const long long slots = 8LL * b->num_cus;
+      const long long rounds = std::max<long long>(1, (total_tiles + 36 * slots - 1) / (36 * slots));
+      const long long cpw = std::max<long long>(1, (slots * rounds) / std::max(1, B));
+      per_chunk = (int)std::max<long long>(4, (wd.ntiles + cpw - 1) / cpw);
+    }
     const std::vector<int> bounds = chunk_boundaries(wd.ntiles, per_chunk);
     wd.chunk_off = (int)chunks.size(); wd.nchunks = (int)bounds.size() - 1;
     const long long slab_stride = (long long)sys_doubles(wd.n) + kSlabScalars;
