@@ -1,6 +1,7 @@
 // slslam_amd/host/window_packer.cpp — see window_packer.h.
 #include "window_packer.h"
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -119,4 +120,48 @@ extern "C" void slslam_free_packed_window(slslam_packed_window* w) {
   delete[] w->camera_index; delete[] w->line_index; delete[] w->fixed_index;
   delete[] w->observations; delete[] w->parameters; delete[] w->camera_kf_id; delete[] w->line_lm_id;
   std::memset(w, 0, sizeof(*w));
+}
+
+// ---- pose graph (SLAM::pose_optimization, reference src/slam.cpp:1236-1313)
+extern "C" int slslam_pack_pose_graph(const slslam_pose* kf_T, int num_poses, slslam_pg_edge* edges, int num_edges,
+                                      slslam_packed_pose_graph* out) {
+  if (!out || num_poses < 0 || num_edges < 0 || (num_poses > 0 && !kf_T) || (num_edges > 0 && !edges)) return 1;
+  std::memset(out, 0, sizeof(*out));
+  for (int i = 0; i < num_edges; ++i)
+    if (edges[i].n1 < 0 || edges[i].n1 >= num_poses || edges[i].n2 < 0 || edges[i].n2 >= num_poses) return 1;
+  std::stable_sort(edges, edges + num_edges, [](const slslam_pg_edge& a, const slslam_pg_edge& b) {
+    return a.n1 != b.n1 ? a.n1 < b.n1 : a.n2 < b.n2;                 // std::set<pii> iteration order (slam.cpp:1249)
+  });
+  for (int i = 1; i < num_edges; ++i)
+    if (edges[i].n1 == edges[i - 1].n1 && edges[i].n2 == edges[i - 1].n2) return 1;   // a set holds a pair once
+  out->num_poses = num_poses; out->num_edges = num_edges;
+  out->pose_index_1 = new int[num_edges > 0 ? num_edges : 1];
+  out->pose_index_2 = new int[num_edges > 0 ? num_edges : 1];
+  out->constraints = new double[6 * (size_t)(num_edges > 0 ? num_edges : 1)];
+  out->parameters = new double[6 * (size_t)(num_poses > 0 ? num_poses : 1)];
+  for (int i = 0; i < num_edges; ++i) {                                // slam.cpp:1267-1274
+    out->pose_index_1[i] = edges[i].n1;
+    out->pose_index_2[i] = edges[i].n2;
+    slslam_gc_Rt_to_wt(&edges[i].C, out->constraints + 6 * (size_t)i);
+  }
+  for (int k = 0; k < num_poses; ++k) slslam_gc_Rt_to_wt(&kf_T[k], out->parameters + 6 * (size_t)k);   // :1276-1280
+  return 0;
+}
+
+extern "C" int slslam_unpack_pose_graph(const slslam_packed_pose_graph* g, slslam_pose* kf_T, int num_poses,
+                                        slslam_pg_edge* edges, int num_edges) {
+  if (!g || g->num_poses != num_poses || (num_poses > 0 && !kf_T) || (num_edges > 0 && !edges)) return 1;
+  for (int k = 0; k < num_poses; ++k) slslam_gc_wt_to_Rt(g->parameters + 6 * (size_t)k, &kf_T[k]);    // slam.cpp:1295-1300
+  for (int i = 0; i < num_edges; ++i) {                                                               // :1302-1310
+    if (edges[i].n1 < 0 || edges[i].n1 >= num_poses || edges[i].n2 < 0 || edges[i].n2 >= num_poses) return 1;
+    slslam_gc_T_21(&kf_T[edges[i].n2], &kf_T[edges[i].n1], &edges[i].T);
+    slslam_gc_T_21(&kf_T[edges[i].n1], &kf_T[edges[i].n2], &edges[i].T_rev);
+  }
+  return 0;
+}
+
+extern "C" void slslam_free_packed_pose_graph(slslam_packed_pose_graph* g) {
+  if (!g) return;
+  delete[] g->pose_index_1; delete[] g->pose_index_2; delete[] g->constraints; delete[] g->parameters;
+  std::memset(g, 0, sizeof(*g));
 }

@@ -59,6 +59,36 @@ int slslam_unpack_window(const slslam_packed_window* w, slslam_keyframe* kfs, in
 /* Frees whatever pack allocated and the caller has not handed to an LBAProblem (pass NULL-ed pointers otherwise). */
 void slslam_free_packed_window(slslam_packed_window* w);
 
+/* ---- pose graph: what SLAM::pose_optimization does before and after ceres::Solve
+ *   pack    reference src/slam.cpp:1248-1280   edge_set (std::set<pii>: ascending (n1, n2)) -> pose_index_1 / pose_index_2,
+ *           constraints[6 i] = gc_Rt_to_wt(edges[(n1, n2)].C), parameters[6 k] = gc_Rt_to_wt(kfs[k]->T) for k = 0..N-1
+ *   unpack  reference src/slam.cpp:1295-1311   kfs[k]->T = gc_wt_to_Rt(parameters[6 k]); every edge's current relative
+ *           pose T = gc_T_21(kfs[n2]->T, kfs[n1]->T) refreshed in both directions
+ * Keyframe ids are the pose slots (kfs is indexed 0..N-1 in the reference).  Edge 0's first pose is the gauge
+ * (po_problem.cpp:62-63).  Arrays are new[]-allocated so that ceres::POProblem can take ownership. */
+typedef struct slslam_pg_edge {
+  int n1, n2;                  /* n1 < n2 is not required; the pack sorts by (n1, n2) like std::set<pii> */
+  slslam_pose C;               /* measured T_{n2 <- n1} */
+  slslam_pose T;               /* current T_{n2 <- n1} from the keyframe poses (refreshed by unpack) */
+  slslam_pose T_rev;           /* current T_{n1 <- n2} (edges[(n2, n1)].T in the reference) */
+} slslam_pg_edge;
+
+typedef struct slslam_packed_pose_graph {
+  int num_poses, num_edges;
+  int* pose_index_1;
+  int* pose_index_2;
+  double* constraints;         /* [6 E] */
+  double* parameters;          /* [6 N] */
+} slslam_packed_pose_graph;
+
+/* Sorts `edges` in place into the std::set<pii> order.  Returns 0, or 1 on an edge that names an unknown pose or a duplicate. */
+int slslam_pack_pose_graph(const slslam_pose* kf_T, int num_poses, slslam_pg_edge* edges, int num_edges,
+                           slslam_packed_pose_graph* out);
+/* Writes the solved poses back into kf_T[] and refreshes T / T_rev of every edge. */
+int slslam_unpack_pose_graph(const slslam_packed_pose_graph* g, slslam_pose* kf_T, int num_poses,
+                             slslam_pg_edge* edges, int num_edges);
+void slslam_free_packed_pose_graph(slslam_packed_pose_graph* g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -340,3 +340,71 @@ def test_frame_reader_and_metric_embedding(tmp_path):
     R2 = np.array(P[2].R).reshape(3, 3); t2 = np.array(P[2].t)
     for e, s in enumerate((-0.5, 1.5)):
         assert np.abs(ep[3 * e:3 * e + 3] - R2.T @ (p0 + v * s - t2)).max() < 1e-12
+
+
+def test_pose_graph_packer_reproduces_the_array_contract(oracle):
+    """slslam_pack_pose_graph (SLAM::pose_optimization pre, slam.cpp:1248-1280) on a keyframe / edge map built from a
+    synthetic pose graph gives the arrays of the POProblem contract - edges in std::set<pii> order whatever order they
+    were handed over in - and slslam_unpack_pose_graph (slam.cpp:1295-1311) writes the solved poses back and refreshes
+    the edges' relative poses."""
+    import ctypes as C
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    lib = C.CDLL(os.path.join(LIBDIR, "libslslam_host.so"))
+
+    class Pose(C.Structure):
+        _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3)]
+
+    class Edge(C.Structure):
+        _fields_ = [("n1", C.c_int), ("n2", C.c_int), ("C", Pose), ("T", Pose), ("T_rev", Pose)]
+
+    class Packed(C.Structure):
+        _fields_ = [("num_poses", C.c_int), ("num_edges", C.c_int), ("pose_index_1", C.POINTER(C.c_int)),
+                    ("pose_index_2", C.POINTER(C.c_int)), ("constraints", C.POINTER(C.c_double)), ("parameters", C.POINTER(C.c_double))]
+
+    def pose_of(wt):
+        T = Pose()
+        lib.slslam_gc_wt_to_Rt((C.c_double * 6)(*wt), C.byref(T))
+        return T
+
+    g = synth.make_pose_graph(4, num_poses=30, num_loops=3)
+    N, E = g["num_poses"], len(g["pose_index_1"])
+    kfT = (Pose * N)(*[pose_of(g["parameters"][6 * k:6 * k + 6]) for k in range(N)])
+    perm = np.random.default_rng(0).permutation(E)                      # the packer restores the set order
+    edges = (Edge * E)()
+    for slot, e in enumerate(perm):
+        edges[slot].n1, edges[slot].n2 = int(g["pose_index_1"][e]), int(g["pose_index_2"][e])
+        edges[slot].C = pose_of(g["constraints"][e])
+    pk = Packed()
+    assert lib.slslam_pack_pose_graph(kfT, N, edges, E, C.byref(pk)) == 0
+    assert (pk.num_poses, pk.num_edges) == (N, E)
+    assert [pk.pose_index_1[i] for i in range(E)] == list(g["pose_index_1"]) and [pk.pose_index_2[i] for i in range(E)] == list(g["pose_index_2"])
+    cons = np.array([pk.constraints[i] for i in range(6 * E)]).reshape(E, 6)
+    prm = np.array([pk.parameters[i] for i in range(6 * N)])
+    assert np.abs(cons - g["constraints"]).max() < 1e-12 and np.abs(prm - g["parameters"]).max() < 1e-12
+    # solve (oracle on the CPU) and write back
+    x, s, _ = oracle.po_solve(dict(g, pose_index_1=np.array([pk.pose_index_1[i] for i in range(E)], dtype=np.int32),
+                                   pose_index_2=np.array([pk.pose_index_2[i] for i in range(E)], dtype=np.int32),
+                                   constraints=cons, parameters=prm))
+    for i in range(6 * N):
+        pk.parameters[i] = x[i]
+    assert lib.slslam_unpack_pose_graph(C.byref(pk), kfT, N, edges, E) == 0
+    back = np.zeros(6)
+    lib.slslam_gc_Rt_to_wt(C.byref(kfT[N - 1]), back.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.abs(back - x[6 * (N - 1):]).max() < 1e-9
+    # after the optimisation every edge's current relative pose is close to its measurement, in both directions
+    for e in range(E):
+        rel, rev = np.zeros(6), np.zeros(6)
+        lib.slslam_gc_Rt_to_wt(C.byref(edges[e].T), rel.ctypes.data_as(C.POINTER(C.c_double)))
+        lib.slslam_gc_Rt_to_wt(C.byref(edges[e].T_rev), rev.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.abs(rel - cons[e]).max() < 5e-2
+        inv = Pose()
+        lib.slslam_gc_T_inv(C.byref(edges[e].T), C.byref(inv))
+        chk = np.zeros(6)
+        lib.slslam_gc_Rt_to_wt(C.byref(inv), chk.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.abs(chk - rev).max() < 1e-9
+    # an edge naming an unknown pose and a duplicate edge are rejected
+    bad = (Edge * 1)(); bad[0].n1, bad[0].n2 = 0, N
+    assert lib.slslam_pack_pose_graph(kfT, N, bad, 1, C.byref(Packed())) == 1
+    dup = (Edge * 2)(); dup[0].n1, dup[0].n2, dup[1].n1, dup[1].n2 = 0, 1, 0, 1
+    assert lib.slslam_pack_pose_graph(kfT, N, dup, 2, C.byref(Packed())) == 1
+    lib.slslam_free_packed_pose_graph(C.byref(pk))
