@@ -165,3 +165,36 @@ extern "C" void slslam_free_packed_pose_graph(slslam_packed_pose_graph* g) {
   delete[] g->pose_index_1; delete[] g->pose_index_2; delete[] g->constraints; delete[] g->parameters;
   std::memset(g, 0, sizeof(*g));
 }
+
+// ---- motion-only bundle adjustment (SLAM::motion_only_ba, reference src/slam.cpp:578-675)
+extern "C" int slslam_pack_motion_only(const slslam_pose* T, const double* obs_cur, const double* obs_prev, const double* lines,
+                                       int num_inliers, slslam_packed_window* out) {
+  if (!T || !out || num_inliers < 0 || (num_inliers > 0 && (!obs_cur || !obs_prev || !lines))) return 1;
+  std::memset(out, 0, sizeof(*out));
+  const int K = num_inliers, M = 2 * K;
+  out->num_cameras = 2; out->num_lines = K; out->num_observations = M; out->num_parameters = 12 + 4 * K;
+  out->camera_index = new int[M > 0 ? M : 1];
+  out->line_index = new int[M > 0 ? M : 1];
+  out->fixed_index = new int[2 * (size_t)(M > 0 ? M : 1)];
+  out->observations = new double[8 * (size_t)(M > 0 ? M : 1)];
+  out->parameters = new double[out->num_parameters];
+  slslam_gc_Rt_to_wt(T, out->parameters);                              // camera 0: the current estimate (slam.cpp:590)
+  slslam_pose I;
+  std::memset(&I, 0, sizeof(I));
+  I.R[0] = I.R[4] = I.R[8] = 1.0;
+  slslam_gc_Rt_to_wt(&I, out->parameters + 6);                        // camera 1: pose_t() (:591)
+  for (int i = 0; i < K; ++i) {                                        // :593-607
+    out->camera_index[2 * i] = 0; out->line_index[2 * i] = i;
+    out->fixed_index[4 * i] = 0; out->fixed_index[4 * i + 1] = 1;
+    std::memcpy(out->observations + 16 * (size_t)i, obs_cur + 8 * (size_t)i, 8 * sizeof(double));
+    out->camera_index[2 * i + 1] = 1; out->line_index[2 * i + 1] = i;
+    out->fixed_index[4 * i + 2] = 1; out->fixed_index[4 * i + 3] = 1;
+    std::memcpy(out->observations + 16 * (size_t)i + 8, obs_prev + 8 * (size_t)i, 8 * sizeof(double));
+    slslam_gc_av_to_orth(lines + 6 * (size_t)i, out->parameters + 12 + 4 * (size_t)i);
+  }
+  return 0;
+}
+
+extern "C" void slslam_unpack_motion_only(const slslam_packed_window* w, slslam_pose* T) {
+  if (w && T && w->parameters) slslam_gc_wt_to_Rt(w->parameters, T);  // slam.cpp:668-674
+}

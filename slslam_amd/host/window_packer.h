@@ -59,6 +59,18 @@ int slslam_unpack_window(const slslam_packed_window* w, slslam_keyframe* kfs, in
 /* Frees whatever pack allocated and the caller has not handed to an LBAProblem (pass NULL-ed pointers otherwise). */
 void slslam_free_packed_window(slslam_packed_window* w);
 
+/* ---- motion-only bundle adjustment: what SLAM::motion_only_ba does before and after ceres::Solve
+ *   pack    reference src/slam.cpp:590-640   camera 0 = gc_Rt_to_wt(T) (free), camera 1 = identity (constant); per inlier
+ *           two observations of one line - (camera 0, current frame's observation), then (camera 1, previous frame's) -,
+ *           every line constant (fixed_index = {0,1},{1,1}), line parameter = gc_av_to_orth(line) with the line
+ *           given in the previous frame's coordinates
+ *   unpack  reference src/slam.cpp:668-674   T = gc_wt_to_Rt(parameters[0..5])
+ * obs_cur / obs_prev: [8 K] the inliers' observations (x0 y0 x1 y1 x2 y2 x3 y3, normalised), lines: [6 K] (closest point,
+ * direction).  out->camera_kf_id / line_lm_id stay NULL. */
+int slslam_pack_motion_only(const slslam_pose* T, const double* obs_cur, const double* obs_prev, const double* lines,
+                            int num_inliers, slslam_packed_window* out);
+void slslam_unpack_motion_only(const slslam_packed_window* w, slslam_pose* T);
+
 /* ---- pose graph: what SLAM::pose_optimization does before and after ceres::Solve
  *   pack    reference src/slam.cpp:1248-1280   edge_set (std::set<pii>: ascending (n1, n2)) -> pose_index_1 / pose_index_2,
  *           constraints[6 i] = gc_Rt_to_wt(edges[(n1, n2)].C), parameters[6 k] = gc_Rt_to_wt(kfs[k]->T) for k = 0..N-1

@@ -408,3 +408,63 @@ def test_pose_graph_packer_reproduces_the_array_contract(oracle):
     dup = (Edge * 2)(); dup[0].n1, dup[0].n2, dup[1].n1, dup[1].n2 = 0, 1, 0, 1
     assert lib.slslam_pack_pose_graph(kfT, N, dup, 2, C.byref(Packed())) == 1
     lib.slslam_free_packed_pose_graph(C.byref(pk))
+
+
+def test_motion_only_packer_reproduces_the_array_contract(oracle):
+    """slslam_pack_motion_only (SLAM::motion_only_ba pre, slam.cpp:590-640): the arrays it emits are those of the
+    synthetic motion-only window they were taken apart from; slslam_unpack_motion_only returns camera 0."""
+    import ctypes as C
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    lib = C.CDLL(os.path.join(LIBDIR, "libslslam_host.so"))
+
+    class Pose(C.Structure):
+        _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3)]
+
+    class Packed(C.Structure):
+        _fields_ = [("num_cameras", C.c_int), ("num_lines", C.c_int), ("num_observations", C.c_int), ("num_parameters", C.c_int),
+                    ("camera_index", C.POINTER(C.c_int)), ("line_index", C.POINTER(C.c_int)), ("fixed_index", C.POINTER(C.c_int)),
+                    ("observations", C.POINTER(C.c_double)), ("parameters", C.POINTER(C.c_double)),
+                    ("camera_kf_id", C.POINTER(C.c_int)), ("line_lm_id", C.POINTER(C.c_int))]
+
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    w = synth.make_motion_only(3, num_lines=40)
+    K = w["num_lines"]
+    prm = w["parameters"]
+    assert np.abs(prm[6:12]).max() == 0.0                                  # camera 1 is the identity keyframe
+    obs = w["observations"]
+    cur = np.zeros((K, 8)); prev = np.zeros((K, 8)); have = np.zeros((K, 2), dtype=bool)
+    for i in range(len(w["camera_index"])):
+        (cur if w["camera_index"][i] == 0 else prev)[w["line_index"][i]] = obs[i]
+        have[w["line_index"][i], w["camera_index"][i]] = True
+    sel = np.nonzero(have.all(axis=1))[0]                                  # lines seen in both frames = the inliers
+    lines_av = np.array([synth.orth_to_av(prm[12 + 4 * l:16 + 4 * l]) for l in sel])
+    T = Pose()
+    lib.slslam_gc_wt_to_Rt((C.c_double * 6)(*prm[:6]), C.byref(T))
+    pk = Packed()
+    cur_s, prev_s = np.ascontiguousarray(cur[sel]), np.ascontiguousarray(prev[sel])
+    assert lib.slslam_pack_motion_only(C.byref(T), dp(cur_s), dp(prev_s), dp(np.ascontiguousarray(lines_av)), len(sel), C.byref(pk)) == 0
+    n = len(sel)
+    assert (pk.num_cameras, pk.num_lines, pk.num_observations, pk.num_parameters) == (2, n, 2 * n, 12 + 4 * n)
+    assert [pk.camera_index[i] for i in range(2 * n)] == [0, 1] * n and [pk.line_index[i] for i in range(2 * n)] == [i // 2 for i in range(2 * n)]
+    assert [pk.fixed_index[i] for i in range(4 * n)] == [0, 1, 1, 1] * n
+    o = np.array([pk.observations[i] for i in range(16 * n)]).reshape(n, 2, 8)
+    assert np.array_equal(o[:, 0], cur_s) and np.array_equal(o[:, 1], prev_s)
+    p = np.array([pk.parameters[i] for i in range(12 + 4 * n)])
+    assert np.abs(p[:6] - prm[:6]).max() < 1e-12 and np.abs(p[6:12]).max() == 0.0
+    # the orthonormal line parameters come back the same up to the representation's sign / 2 pi freedom: same lines
+    for q, l in enumerate(sel):
+        assert np.abs(synth.orth_to_av(p[12 + 4 * q:16 + 4 * q]) - lines_av[q]).max() < 1e-9
+    # the packed problem is the generator's (restricted to the inliers): same optimum for camera 0
+    w2 = dict(num_cameras=2, num_lines=n, camera_index=np.array([0, 1] * n, dtype=np.int32), line_index=np.repeat(np.arange(n, dtype=np.int32), 2),
+              fixed_index=np.array([0, 1, 1, 1] * n, dtype=np.int32), observations=o.reshape(2 * n, 8), parameters=p)
+    x2, s2, _ = oracle.lba_solve(w2, linear_solver=1)
+    x1, s1, _ = oracle.lba_solve(w, linear_solver=1)
+    if n == K:
+        assert abs(s1["final_cost"] - s2["final_cost"]) < 1e-7 * s1["final_cost"] and np.abs(x1[:6] - x2[:6]).max() < 1e-7
+    for i in range(6):
+        pk.parameters[i] = x2[i]
+    lib.slslam_unpack_motion_only(C.byref(pk), C.byref(T))
+    back = np.zeros(6)
+    lib.slslam_gc_Rt_to_wt(C.byref(T), dp(back))
+    assert np.abs(back - x2[:6]).max() < 1e-9
+    lib.slslam_free_packed_window(C.byref(pk))
