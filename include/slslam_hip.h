@@ -75,6 +75,9 @@ typedef struct slslam_solver_options {
   int    po_dense_factor;               /* pose graph only: 0 (default) = structured factorisation: chains of poses
                                            eliminated concurrently (block tridiagonal), dense MFMA Cholesky of the
                                            junction poses only; 1 = dense MFMA Cholesky of the whole normal matrix   */
+  int    lba_fused_motion_only;         /* 1 (default): a batch whose windows all have one free camera and only constant lines
+                                           (SLAM::motion_only_ba) is solved by one launch, one wave per window, the 6 x 6
+                                           system in registers; 0: the general elimination / back-substitution path     */
 } slslam_solver_options;
 
 /* Fills every field with the configuration the reference runs (robust loss on, 10 iterations). */

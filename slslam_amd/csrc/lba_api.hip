@@ -13,6 +13,7 @@
 #include "../../include/slslam_hip.h"
 #include "lba_kernels.h"
 #include "device_cache.h"
+#include "lba_motion_only.h"
 #include "lba_pack.h"
 
 using namespace slslam;
@@ -47,6 +48,7 @@ extern "C" void slslam_default_options(slslam_solver_options* o) {
   o->reuse_elimination = 0;
   o->po_factor_fp32 = 0;
   o->po_dense_factor = 0;
+  o->lba_fused_motion_only = 1;
 }
 
 extern "C" void slslam_release_cached_memory(void) { DeviceBlockCache::drop(); }
@@ -183,6 +185,8 @@ struct slslam_lba_batch {
   int nchunk = 0, nline = 0, ncam = 0;
   long long nobs = 0;
   int num_cus = 256;
+  bool fused_motion_only = false;
+  size_t lds_motion_only = 0;
   size_t lds_lin = 0, lds_solve = 0, lds_bs = 0, lds_bs_stream = 0, lds_cost = 0;
   // graph
   hipGraphExec_t graph_exec = nullptr;
@@ -402,6 +406,10 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
 
   b->lds_lin = sizeof(double) * (size_t)lds_doubles_linearise(maxC, maxn);
   b->lds_solve = sizeof(double) * (size_t)lds_doubles_solve(maxn);
+  // motion-only batches (one free camera, every line constant: SLAM::motion_only_ba): the whole solve in one launch
+  b->fused_motion_only = b->opt.lba_fused_motion_only && !b->opt.reuse_elimination && B > 0;
+  for (const PackedWindow& P : b->wins) if (P.Cf != 1 || P.nfree_params != 6) b->fused_motion_only = false;
+  b->lds_motion_only = sizeof(double) * (size_t)lds_doubles_motion_only(maxC);
   b->lds_bs = sizeof(double) * (size_t)lds_doubles_backsub(maxC, maxn);
   b->lds_bs_stream = sizeof(double) * (size_t)lds_doubles_backsub_stream(maxC, maxn);
   b->lds_cost = sizeof(double) * (size_t)lds_doubles_cost(maxC, maxn);
@@ -460,6 +468,11 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     if ((rc = L.end())) return rc;                         \
   } while (0)
   if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 0));
+  if (b->fused_motion_only) {
+    LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_motion_only, g_win, blk64, b->lds_motion_only, s, p, pol));
+    HIP_TRY(hipGetLastError());
+    return SLSLAM_OK;
+  }
   // Ceres' initial evaluation (cost, gradient, column norms at x0 -> Jacobi scale, trace record 0) rides on the first
   // LM iteration's sweeps (LMState.fresh); only a solve that may not iterate at all needs it as a pass of its own
   if (pol.max_num_iterations <= 0 || pol.store_f) {     // (the streaming variant keeps F blocks in the first sweep's coordinates)

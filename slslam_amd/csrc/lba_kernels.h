@@ -1412,22 +1412,12 @@ __global__ __launch_bounds__(64) void k_lm_init(BatchPtrs p, Policy pol) {
   if (st->iter >= pol.max_num_iterations) st->status = 0;
 }
 
-__global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= p.nwin) return;
-  const WinDesc wd = p.wins[w];
-  LMState* st = p.state + w;
-  if (st->status != kRunning) return;
-  const int n = wd.n, nsys = sys_doubles(n);
+// One trust-region step's bookkeeping (Ceres 1.7 TrustRegionMinimizer; policy table in DESIGN.md section 5): given the cost at the
+// candidate point and the step statistics, accept or reject, move the radius, record the iteration, test the stopping rules.
+__device__ __forceinline__ void lm_step(BatchPtrs& p, const Policy& pol, int w, LMState* st, double new_cost, double model,
+                                        double dn2, double xn2) {
   IterRec rec;
   rec.pad = 0;
-  // ---- one LM iteration
-  double new_cost = 0.0, model = st->cam_model, dn2 = st->cam_dn2, xn2 = st->cam_xn2;
-  for (int c = 0; c < wd.nchunks; ++c) {
-    new_cost += p.cost_part[wd.chunk_off + c];
-    const double* bp = p.bs_part + (long long)(wd.chunk_off + c) * kBsStride;
-    model += bp[kBsModel]; dn2 += bp[kBsDn2]; xn2 += bp[kBsXn2];
-  }
   const double cost = st->cost;
   rec.iteration = st->iter + 1;
   rec.step_is_valid = 0; rec.step_is_successful = 0;
@@ -1477,6 +1467,22 @@ __global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol) {
   if (st->radius < pol.min_radius) { st->status = 5; return; }
   if (st->iter >= pol.max_num_iterations) { st->status = 0; return; }
   atomicAdd(p.active_counter, 1u);    // still running: lets the host stop enqueueing long solves early
+}
+
+__global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= p.nwin) return;
+  const WinDesc wd = p.wins[w];
+  LMState* st = p.state + w;
+  if (st->status != kRunning) return;
+  // ---- one LM iteration: totals over the window's chunks, then the bookkeeping
+  double new_cost = 0.0, model = st->cam_model, dn2 = st->cam_dn2, xn2 = st->cam_xn2;
+  for (int c = 0; c < wd.nchunks; ++c) {
+    new_cost += p.cost_part[wd.chunk_off + c];
+    const double* bp = p.bs_part + (long long)(wd.chunk_off + c) * kBsStride;
+    model += bp[kBsModel]; dn2 += bp[kBsDn2]; xn2 += bp[kBsXn2];
+  }
+  lm_step(p, pol, w, st, new_cost, model, dn2, xn2);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -324,3 +324,41 @@ def test_one_shot_solves_reuse_their_device_block(hip, oracle):
             xg, sg, _ = hip.po_solve(g)
             assert abs(sg["final_cost"] - sg0["final_cost"]) <= 1e-6 * sg0["final_cost"] + 1e-15 and np.abs(xg - xg0).max() < 1e-5
         hip.release_cached_memory()
+
+
+def test_fused_motion_only_matches_general_path_and_oracle(hip, oracle):
+    """Motion-only windows (one free camera, constant lines) are solved by one launch with the 6 x 6 system in registers
+    (lba_motion_only.h); same trust-region policy as the general four-launch path: identical step counts and termination,
+    poses and traces to round-off - near and far from the optimum, with rejected steps (forced through
+    min_relative_decrease), with and without the robust loss, for 0, 1 and many iterations."""
+    cases = [(0, {}), (1, {"max_num_iterations": 0}), (2, {"max_num_iterations": 1}), (3, {"max_num_iterations": 40}),
+             (4, {"huber_delta": 0.0}), (5, {"huber_delta": 0.0, "min_relative_decrease": 1.5}),
+             (6, {"huber_delta": 0.0, "min_relative_decrease": 1.0000005}), (7, {"jacobi_scaling": 0}), (8, {})]
+    rejected = 0
+    for seed, kw in cases:
+        w = synth.make_motion_only(800 + seed, num_lines=30 + 25 * seed, noise_px=[0.0, 0.5, 2.0][seed % 3])
+        if seed % 2:
+            rng = np.random.default_rng(seed)
+            w["parameters"] = w["parameters"].copy()
+            w["parameters"][:6] += rng.normal(0, 1.0, 6) * [0.05, 0.05, 0.05, 0.5, 0.5, 0.5]
+        x0, s0, t0 = hip.lba_solve(w, lba_fused_motion_only=0, **kw)
+        x1, s1, t1 = hip.lba_solve(w, lba_fused_motion_only=1, **kw)
+        okw = {k: v for k, v in kw.items() if k != "huber_delta"}
+        xo, so, to = oracle.lba_solve(w, huber_delta=kw.get("huber_delta", 1.0 / 406.05), **okw)
+        for s in (s0, so):
+            _assert_summary_parity(s, s1)
+        _assert_trace_parity(t0, t1)
+        _assert_trace_parity(to, t1)
+        assert np.abs(x0 - x1).max() < 1e-9 and np.abs(xo - x1).max() < 1e-7
+        rejected += s1["num_unsuccessful_steps"]
+    assert rejected > 0
+    # batches that mix a motion-only window with an ordinary one take the general path and still solve both
+    b = hip.LBABatch()
+    wm, wg = synth.make_motion_only(900, num_lines=40), synth.make_window(901, num_lines=60)
+    b.add(wm); b.add(wg)
+    b.finalize()
+    b.solve(); b.download()
+    for i, w in enumerate((wm, wg)):
+        xo, so, _ = oracle.lba_solve(w, linear_solver=1)
+        assert np.abs(b.parameters(i) - xo).max() < 1e-5
+    b.close()
