@@ -25,7 +25,12 @@ def run(cases, seed=2026, verbose=True):
       if rng.random() < 0.15:
           kw["line_init"] = "triangulate"
       try:
-          w = synth.make_window(1000 * (seed % 1000) + case, **kw)
+          if rng.random() < 0.12:        # the motion_only_ba shape (one-launch kernel): one free camera, constant lines
+              w = synth.make_motion_only(1000 * (seed % 1000) + case, num_lines=nl, noise_px=kw["noise_px"])
+              w["parameters"] = w["parameters"].copy()
+              w["parameters"][:6] += rng.normal(0, 1.0, 6) * float(rng.choice([0.0, 0.01, 0.2]))
+          else:
+              w = synth.make_window(1000 * (seed % 1000) + case, **kw)
       except Exception as e:            # generator cannot build this shape (e.g. too few visible lines)
           continue
       m = len(w["camera_index"])
