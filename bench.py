@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--no-overlap-run", action="store_true", help="skip the informational two-stream measurement")
     ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph (no per-kernel events)")
     ap.add_argument("--chunks", type=int, default=0, help="waves cooperating on one window (0 = library default)")
+    ap.add_argument("--elim", type=int, default=0,
+                    help="lba_elimination: 0 auto, 1 LDS-atomic sweep, 2 / 3 matrix-core sweep with 1 / 2 waves per chunk")
     ap.add_argument("--streams", type=int, default=1,
                     help="the rank's windows are split into this many batches on separate HIP streams, so that the "
                          "latency-bound kernels of one batch (reduced solve, LM update) overlap the sweeps of the other")
@@ -147,7 +149,7 @@ def main():
         for wi in range(si, B, ns):
             bt.add(windows[wi])
             owner.append((wi, si, len(bt.sizes) - 1))
-        bt.finalize(use_graph=1 if args.graph else 0, chunks_per_window=args.chunks)
+        bt.finalize(use_graph=1 if args.graph else 0, chunks_per_window=args.chunks, lba_elimination=args.elim)
         bt.set_profiling(not args.graph)
         batches.append(bt)
     where = {wi: (si, li) for wi, si, li in owner}
@@ -195,7 +197,7 @@ def main():
             bt = capi.LBABatch(device=local_rank)
             for wi in range(si, B, 2):
                 bt.add(windows[wi])
-            bt.finalize(use_graph=1, chunks_per_window=args.chunks)
+            bt.finalize(use_graph=1, chunks_per_window=args.chunks, lba_elimination=args.elim)
             obatches.append(bt)
 
         def orun():

@@ -12,6 +12,7 @@
 
 #include "../../include/slslam_hip.h"
 #include "lba_kernels.h"
+#include "lba_eliminate_mfma.h"
 #include "device_cache.h"
 #include "lba_motion_only.h"
 #include "lba_pack.h"
@@ -49,6 +50,7 @@ extern "C" void slslam_default_options(slslam_solver_options* o) {
   o->po_factor_fp32 = 0;
   o->po_dense_factor = 0;
   o->lba_fused_motion_only = 1;
+  o->lba_elimination = 0;
 }
 
 extern "C" void slslam_release_cached_memory(void) { DeviceBlockCache::drop(); }
@@ -148,7 +150,9 @@ Policy make_policy(const slslam_solver_options& o) {
   p.parameter_tolerance = o.parameter_tolerance;
   p.max_num_iterations = o.max_num_iterations; p.max_invalid = o.max_num_consecutive_invalid_steps;
   p.jacobi_scaling = o.jacobi_scaling; p.pad = 0;
-  p.store_f = o.reuse_elimination ? 1 : 0; p.pad2 = 0;
+  p.store_f = o.reuse_elimination ? 1 : 0;
+  const char* dbg = std::getenv("SLSLAM_DEBUG_ABLATE");    // timing experiments of the elimination sweep; never set in production
+  p.debug_flags = dbg ? std::atoi(dbg) : 0;
   return p;
 }
 
@@ -174,6 +178,10 @@ struct slslam_lba_batch {
   // device
   DeviceArena arena;
   DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<uint8_t> d_items; DevBuf<uint16_t> d_lane_map;
+  DevBuf<uint32_t> d_line_desc;
+  DevBuf<unsigned long long> d_dbg_cycles;
+  int elim_mode = 0, elim_waves = 1;     // see BatchPtrs
+  size_t lds_elim = 0;
   DevBuf<unsigned long long> d_iter_counter;
   DevBuf<unsigned int> d_active;
   DevBuf<double> d_cam_x, d_cam_x0, d_cam_scale; DevBuf<int> d_cam_cf, d_cam_win;
@@ -195,11 +203,22 @@ struct slslam_lba_batch {
   bool profiling = false;
   double fam_ms[FAM_N] = { 0 };
   int fam_launches[FAM_N] = { 0 };
-  std::vector<hipEvent_t> ev_pool;
+  std::vector<hipEvent_t> ev_pool;            // created once, reused by every profiled solve
   std::vector<std::pair<int, int>> ev_used;   // (family, index of start event); stop = start + 1
+  size_t ev_next = 0;                         // first unused event of the pool
+  // folds the recorded event pairs into fam_ms / fam_launches and frees them for reuse (waits for the last one)
+  void harvest_events() {
+    if (ev_used.empty()) { ev_next = 0; return; }
+    (void)hipEventSynchronize(ev_pool[ev_used.back().second + 1]);
+    for (const auto& u : ev_used) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev_pool[u.second], ev_pool[u.second + 1]) == hipSuccess) { fam_ms[u.first] += ms; fam_launches[u.first]++; }
+    }
+    ev_used.clear(); ev_next = 0;
+  }
 
   void release() {
-    d_wins.release(); d_tiles.release(); d_chunks.release(); d_items.release(); d_lane_map.release();
+    d_wins.release(); d_tiles.release(); d_chunks.release(); d_items.release(); d_lane_map.release(); d_line_desc.release(); d_dbg_cycles.release();
     d_cam_x.release(); d_cam_x0.release(); d_cam_scale.release(); d_cam_cf.release(); d_cam_win.release();
     d_line_x.release(); d_line_x0.release(); d_line_scale.release(); d_line_ptr.release(); d_line_flags.release();
     d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release();
@@ -261,8 +280,21 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   }
   const int B = (int)b->wins.size();
 
+  // ---- which elimination sweep: the matrix-core one (lba_eliminate_mfma.h) needs the reduced system in the registers of
+  // one workgroup (<= 10 free cameras) and one observation per (line, free camera); everything else takes the LDS-atomic sweep
+  {
+    bool mfma_ok = !b->opt.reuse_elimination && b->opt.max_num_iterations > 0 && B > 0;
+    for (const PackedWindow& P : b->wins) if (P.Cf > kMfmaMaxFree || P.dup_free_obs) mfma_ok = false;
+    const int want = b->opt.lba_elimination;
+    if (want < 0 || want > 3) return SLSLAM_ERR_INVALID_ARGUMENT;
+    // automatic = the LDS-atomic sweep: on MI355X one wave issues a v_mfma_f64_16x16x4_f64 every ~141 cycles (tools/micro/
+    // mfma_f64_bench.hip: the same flop rate as its fp64 VALU), so the matrix-core sweep measures slower
+    b->elim_mode = (want >= 2 && mfma_ok) ? 1 : 0;
+    b->elim_waves = b->elim_mode == 0 ? 1 : (want == 2 ? 1 : 2);
+  }
+
   // ---- global layout
-  std::vector<Tile> tiles; std::vector<Chunk> chunks; std::vector<uint8_t> items; std::vector<uint16_t> lane_map;
+  std::vector<Tile> tiles; std::vector<Chunk> chunks; std::vector<uint8_t> items; std::vector<uint16_t> lane_map; std::vector<uint32_t> line_desc;
   std::vector<double> cam_x, line_x, ob, cam_x0, line_u0; std::vector<int> cam_cf, cam_win, line_ptr, line_flags, line_win, line_orig, ob_cam, ob_orig;
   long long ncam = 0, nline = 0, nobs = 0, sys = 0, slab = 0, param_off = 0;
   long long total_tiles = 0;
@@ -293,14 +325,15 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
       // the sweeps run 8 one-wave workgroups per CU (LDS): the same number of chunks for every window, chosen so that
       // the batch fills whole rounds of the chip's wave slots with about 36 tiles per chunk at most
       // (1024 bench windows: 6 chunks of 33 tiles = 6144 waves = 3 rounds of 256 CUs x 8), at least 4 tiles per chunk
-      const long long slots = 8LL * b->num_cus;
-      const long long rounds = std::max<long long>(1, (total_tiles + 36 * slots - 1) / (36 * slots));
+      const long long slots = (8LL / b->elim_waves) * b->num_cus;      // chunk workgroups resident per round
+      const long long per_round = 36LL * b->elim_waves * slots;
+      const long long rounds = std::max<long long>(1, (total_tiles + per_round - 1) / per_round);
       const long long cpw = std::max<long long>(1, (slots * rounds) / std::max(1, B));
-      per_chunk = (int)std::max<long long>(4, (wd.ntiles + cpw - 1) / cpw);
+      per_chunk = (int)std::max<long long>(4 * b->elim_waves, (wd.ntiles + cpw - 1) / cpw);
     }
     const std::vector<int> bounds = chunk_boundaries(wd.ntiles, per_chunk);
     wd.chunk_off = (int)chunks.size(); wd.nchunks = (int)bounds.size() - 1;
-    const long long slab_stride = (long long)sys_doubles(wd.n) + kSlabScalars;
+    const long long slab_stride = (long long)(b->elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n)) + kSlabScalars;
     for (int c = 0; c < wd.nchunks; ++c) {
       Chunk ck; ck.win = wi; ck.tile_begin = wd.tile_off + bounds[c]; ck.tile_end = wd.tile_off + bounds[c + 1];
       ck.slab_off = (int)slab; slab += slab_stride;
@@ -311,6 +344,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     for (Tile t : P.tiles) { t.line_begin += (int)nline; t.item_off += item_base; tiles.push_back(t); }
     items.insert(items.end(), P.items.begin(), P.items.end());
     lane_map.insert(lane_map.end(), P.lane_map.begin(), P.lane_map.end());
+    line_desc.insert(line_desc.end(), P.line_desc.begin(), P.line_desc.end());
     for (int c = 0; c < P.C; ++c) {
       for (int buf = 0; buf < 2; ++buf) for (int a = 0; a < 6; ++a) cam_x.push_back(P.cam_x[6 * (size_t)c + a]);
       for (int a = 0; a < 6; ++a) cam_x0.push_back(P.cam_x[6 * (size_t)c + a]);
@@ -355,6 +389,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.upload(b->d_items, items);
   if (lane_map.empty()) lane_map.assign(64, (uint16_t)0x00FF);
   ar.upload(b->d_lane_map, lane_map);
+  if (line_desc.empty()) line_desc.push_back(0u);
+  ar.upload(b->d_line_desc, line_desc);
   if (cam_x.empty()) cam_x.assign(12, 0.0);
   ar.upload(b->d_cam_x, cam_x);
   if (cam_x0.empty()) cam_x0.assign(6, 0.0);
@@ -389,6 +425,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.zeroed(b->d_trace, std::max<size_t>(1, (size_t)B * kMaxTrace));
   ar.upload(b->d_param_off, b->h_param_off);
   ar.zeroed(b->d_iter_counter, 1);
+  ar.zeroed(b->d_dbg_cycles, b->pol.debug_flags ? (size_t)32 * std::max(1, b->nchunk) : 1);
   ar.zeroed(b->d_active, 1);
   if ((rc = ar.commit())) return rc;
 
@@ -403,6 +440,9 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.state = b->d_state.p; p.trace = b->d_trace.p;
   p.iter_counter = b->d_iter_counter.p; p.active_counter = b->d_active.p; p.cam_x0 = b->d_cam_x0.p; p.line_u0 = b->d_line_x0.p;
   p.nwin = B; p.nchunk = b->nchunk; p.nline = b->nline; p.ncam = b->ncam;
+  p.dbg_cycles = b->d_dbg_cycles.p;
+  p.line_desc = b->d_line_desc.p; p.elim_mode = b->elim_mode; p.elim_waves = b->elim_waves;
+  b->lds_elim = (size_t)lds_bytes_eliminate_mfma(maxC, maxn, b->elim_waves);
 
   b->lds_lin = sizeof(double) * (size_t)lds_doubles_linearise(maxC, maxn);
   b->lds_solve = sizeof(double) * (size_t)lds_doubles_solve(maxn);
@@ -418,6 +458,13 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if (b->lds_lin > 48 * 1024) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
     HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
+  }
+  if (b->elim_mode == 1 && b->lds_elim > 48 * 1024) {
+    if (b->lds_elim > 160 * 1024) return SLSLAM_ERR_UNSUPPORTED;
+    HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
   }
   if (b->lds_solve > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
@@ -437,16 +484,20 @@ struct Launcher {
   bool prof;
   int begin(int fam) {
     if (!prof) return SLSLAM_OK;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SLSLAM_ERR_HIP;
-    b->ev_pool.push_back(e0); b->ev_pool.push_back(e1);
-    b->ev_used.push_back({ fam, (int)b->ev_pool.size() - 2 });
-    if (hipEventRecord(e0, s) != hipSuccess) return SLSLAM_ERR_HIP;
+    if (b->ev_next + 2 > b->ev_pool.size()) {          // the pool only grows until it covers one harvest interval
+      hipEvent_t e0, e1;
+      if (hipEventCreate(&e0) != hipSuccess) return SLSLAM_ERR_HIP;
+      if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return SLSLAM_ERR_HIP; }
+      b->ev_pool.push_back(e0); b->ev_pool.push_back(e1);
+    }
+    b->ev_used.push_back({ fam, (int)b->ev_next });
+    b->ev_next += 2;
+    if (hipEventRecord(b->ev_pool[b->ev_used.back().second], s) != hipSuccess) return SLSLAM_ERR_HIP;
     return SLSLAM_OK;
   }
   int end() {
     if (!prof) return SLSLAM_OK;
-    if (hipEventRecord(b->ev_pool.back(), s) != hipSuccess) return SLSLAM_ERR_HIP;
+    if (hipEventRecord(b->ev_pool[b->ev_used.back().second + 1], s) != hipSuccess) return SLSLAM_ERR_HIP;
     return SLSLAM_OK;
   }
 };
@@ -489,11 +540,18 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       if (active == 0) break;
     }
     if (!capturing && ((it + 1) % 16) == 0) HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
-    if (b->nchunk > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_linearise_schur<false>, g_chunk, blk64, b->lds_lin, s, p, pol));
+    if (b->nchunk > 0) {
+      if (b->elim_mode == 1 && pol.debug_flags) {          // timing experiments (SLSLAM_DEBUG_ABLATE)
+        if (b->elim_waves == 2) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<2, true>), g_chunk, dim3(128), b->lds_elim, s, p, pol));
+        else LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<1, true>), g_chunk, blk64, b->lds_elim, s, p, pol));
+      } else if (b->elim_mode == 1 && b->elim_waves == 2) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<2, false>), g_chunk, dim3(128), b->lds_elim, s, p, pol));
+      else if (b->elim_mode == 1) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<1, false>), g_chunk, blk64, b->lds_elim, s, p, pol));
+      else LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_linearise_schur<false>, g_chunk, blk64, b->lds_lin, s, p, pol));
+    }
     LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve, g_win, blk256, b->lds_solve, s, p, pol));
     if (b->nchunk > 0) {
       if (pol.store_f) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub_stream, g_chunk, blk64, b->lds_bs_stream, s, p, pol));
-      else LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub, g_chunk, blk64, b->lds_bs, s, p, pol));
+      else LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub, g_chunk, dim3(64 * b->elim_waves), b->lds_bs, s, p, pol));
     }
     if (pol.store_f) {   // the streaming variant has no observation in registers: separate sin/cos and cost sweeps
       if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 1));
@@ -514,7 +572,10 @@ extern "C" int slslam_lba_batch_solve(slslam_lba_batch* b, void* stream) {
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
   b->downloaded = false;
-  if (b->profiling) return enqueue_solve(b, s, true);   // events accumulate until set_profiling()
+  if (b->profiling) {                                   // times accumulate until set_profiling()
+    if (b->ev_next > 16384) b->harvest_events();        // long profiled runs: bounded pool (costs one synchronisation)
+    return enqueue_solve(b, s, true);
+  }
   if (!b->opt.use_graph || b->opt.max_num_iterations > 16) return enqueue_solve(b, s, false);
   if (!b->graph_exec) {
     // capture the whole solve (1 + 4 * max_iter launches) once; replay costs one host call
@@ -523,10 +584,15 @@ extern "C" int slslam_lba_batch_solve(slslam_lba_batch* b, void* stream) {
     const int rc = enqueue_solve(b, b->capture_stream, false, true);
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(b->capture_stream, &g);
-    if (rc != SLSLAM_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-    HIP_TRY(e);
+    if (rc != SLSLAM_OK || e != hipSuccess) {           // no half-built capture state survives a failed attempt
+      if (g) (void)hipGraphDestroy(g);
+      (void)hipStreamDestroy(b->capture_stream); b->capture_stream = nullptr;
+      if (rc != SLSLAM_OK) return rc;
+      HIP_TRY(e);
+    }
     const hipError_t ei = hipGraphInstantiate(&b->graph_exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) { (void)hipStreamDestroy(b->capture_stream); b->capture_stream = nullptr; }
     HIP_TRY(ei);
   }
   HIP_TRY(hipGraphLaunch(b->graph_exec, s));
@@ -586,15 +652,7 @@ extern "C" int slslam_lba_batch_download(slslam_lba_batch* b, void* stream) {
     HIP_TRY(hipMemcpyAsync(b->h_trace.data(), b->d_trace.p, b->h_trace.size() * sizeof(IterRec), hipMemcpyDeviceToHost, s));
   }
   HIP_TRY(hipStreamSynchronize(s));
-  if (b->profiling) {
-    for (int f = 0; f < FAM_N; ++f) { b->fam_ms[f] = 0.0; b->fam_launches[f] = 0; }
-    for (const auto& u : b->ev_used) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, b->ev_pool[u.second], b->ev_pool[u.second + 1]) == hipSuccess) {
-        b->fam_ms[u.first] += ms; b->fam_launches[u.first]++;
-      }
-    }
-  }
+  if (b->profiling) b->harvest_events();
   b->downloaded = true;
   return SLSLAM_OK;
 }
@@ -650,12 +708,25 @@ extern "C" int slslam_lba_batch_counts(const slslam_lba_batch* b, long long* nw,
   return SLSLAM_OK;
 }
 
+// Timing experiments only (SLSLAM_DEBUG_ABLATE bit 8; not part of include/slslam_hip.h): per-phase wave cycles of the last
+// matrix-core sweep, summed over all waves; out[16].
+extern "C" int slslam_debug_phase_cycles(slslam_lba_batch* b, double* out) {
+  if (!b || !out || !b->finalized) return SLSLAM_ERR_INVALID_ARGUMENT;
+  const size_t n = (size_t)32 * std::max(1, b->nchunk);
+  if (!b->pol.debug_flags) return SLSLAM_ERR_STATE;
+  std::vector<unsigned long long> h(n);
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h.data(), b->d_dbg_cycles.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; ++i) out[i] = 0.0;
+  for (size_t q = 0; q < n; ++q) out[q % 16] += (double)h[q];
+  return SLSLAM_OK;
+}
+
 extern "C" int slslam_lba_batch_set_profiling(slslam_lba_batch* b, int enable) {
   if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
   b->profiling = enable != 0;
-  (void)hipSetDevice(b->device);
-  for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
-  b->ev_pool.clear(); b->ev_used.clear();
+  b->ev_used.clear(); b->ev_next = 0;                   // the events themselves are kept for reuse
   for (int f = 0; f < FAM_N; ++f) { b->fam_ms[f] = 0.0; b->fam_launches[f] = 0; }
   return SLSLAM_OK;
 }

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include "lba_math.h"
 #include "lba_types.h"
+#include "lba_eliminate_mfma_maps.h"
 
 namespace slslam {
 
@@ -38,6 +39,7 @@ enum { kCamTab = 21 };   // doubles per camera in LDS: R[9] JL[9] t[3]; odd stri
 //   pair block (cj > ci) (kPairAcc = 37): 6x6, row a of cj, column b of ci [36] | pad
 // 20 cameras / 10 free: 3360 + 480 + 16440 + 24 = 20 304 B -> 8 workgroups per CU.
 enum { kCamAcc = 39, kPairAcc = 37, kRecB = 21, kRecG = 27, kRecH = 33 };
+enum { kMfmaTiles = kPTiles, kMfmaRec = kDiagRec };   // slab of the matrix-core elimination: 10 accumulator tiles | camera records
 __host__ __device__ inline int sys_doubles(int n) { const int cf = n / 6; return cf * kCamAcc + ((cf * (cf - 1)) / 2) * kPairAcc; }
 __device__ __forceinline__ int pair_base(int ncf, int cj, int ci) { return ncf * kCamAcc + ((cj * (cj - 1)) / 2 + ci) * kPairAcc; }
 
@@ -152,15 +154,17 @@ struct LaneLin {
 // the dependent chain  tile descriptor -> line_ptr -> observation  is off the critical path.
 struct TileCtx {
   int flags, ls, j, o0, k, lflags, nitems, item_off;
+  int slot, nlines;         // the lane's line slot in the tile (matrix-core sweep), lines of the tile (wave-uniform)
   bool line_ok;
 };
 __device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_end, int lane) {
   TileCtx c;
   c.flags = 0; c.ls = 0; c.j = 0; c.o0 = 0; c.k = 0; c.lflags = 1; c.nitems = 0; c.item_off = 0; c.line_ok = false;
+  c.slot = 0; c.nlines = 0;
   if (t < t_end) {
     const Tile tl = p.tiles[t];
     const int m = p.lane_map[(long long)t * 64 + lane];
-    c.flags = tl.flags; c.nitems = tl.nitems; c.item_off = tl.item_off;
+    c.flags = tl.flags; c.nitems = tl.nitems; c.item_off = tl.item_off; c.nlines = tl.nlines; c.slot = m & 0xff;
     c.line_ok = (m & 0xff) != 0xff;
     if (c.line_ok) {
       c.j = m >> 8;
@@ -689,7 +693,7 @@ __host__ __device__ inline int solve_stride(int n) { return ((solve_pad(n) + 30)
 // i.e. 4 workgroups per CU and the whole 1024-window batch resident in one round.
 __host__ __device__ inline int lds_doubles_solve(int n) {
   const int N = solve_pad(n);
-  return N * solve_stride(n) + 6 * N + 16;
+  return N * solve_stride(n) + 6 * N + 16 + 9 * (n / 6);     // + JL of every free camera (matrix-core sweep: T_c is applied here)
 }
 typedef double solve_acc_t __attribute__((ext_vector_type(4)));
 
@@ -719,8 +723,136 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
   for (int q = tid; q < 6 * N; q += 256) bvec[q] = 0.0;
   __syncthreads();
   // ---- 1. ordered reduction over the window's chunk partials (uniform stride between consecutive slabs)
-  const long long slab0 = p.chunks[wd.chunk_off].slab_off;
-  const long long sstride = (long long)nsys + kSlabScalars;
+  const bool mfma_slab = p.elim_mode == 1;          // slab layout of lba_eliminate_mfma.h
+  const int nsys_slab = mfma_slab ? kMfmaTiles * 256 + ncf * kMfmaRec : nsys;
+  const long long slab0 = wd.nchunks > 0 ? p.chunks[wd.chunk_off].slab_off : 0;
+  const long long sstride = (long long)nsys_slab + kSlabScalars;
+  if (mfma_slab) {
+    // The matrix-core sweep leaves everything in RAW camera coordinates (J_c' = [tau | gP]: no SO(3) left Jacobian, no
+    // Jacobi scale).  (1) camera records: D' = J_c'^T J_c' (diagonal blocks), b', g'
+    for (int q = tid; q < ncf * kMfmaRec; q += 256) {
+      const double* src = p.slab + slab0 + kMfmaTiles * 256 + q;
+      double s = 0.0;
+      for (int k0 = 0; k0 < wd.nchunks; k0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < wd.nchunks) ? src[(k0 + u) * sstride] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      const int cf = q / kMfmaRec, e = q - cf * kMfmaRec;
+      if (e < 21) {
+        const int a = e >= 15 ? 5 : e >= 10 ? 4 : e >= 6 ? 3 : e >= 3 ? 2 : e >= 1 ? 1 : 0, b = e - tri_index(a, 0);
+        A[(6 * cf + a) * ld + 6 * cf + b] = s;
+      } else if (e < 27) {
+        bvec[6 * cf + (e - 21)] = s;
+      } else {
+        gvec[6 * cf + (e - 27)] = s;
+      }
+    }
+    // the cameras' left Jacobians JL(w) at the accepted point: T_c = diag(JL diag(s_w), diag(s_t)), J_c = J_c' T_c
+    double* jlm = red + 16;                                // [ncf][9]
+    for (int c = tid; c < wd.C; c += 256) {
+      const int cf = p.cam_cf[wd.cam_off + c];
+      if (cf < 0) continue;
+      const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + cur) * kCamRec;
+      double wv[3] = { x[0], x[1], x[2] }, R[9], JL[9];
+      cam_prepare<double>(wv, R, JL);
+      for (int q = 0; q < 9; ++q) jlm[9 * cf + q] = JL[q];
+    }
+    __syncthreads();
+    // (2) diag(J_c^T J_c) with unit scale (LM diagonal, Jacobi scale), b and g through T0 = diag(JL, I)
+    for (int q = tid; q < n; q += 256) {
+      const int cf = q / 6, a = q - 6 * cf;
+      const double* JL = jlm + 9 * cf;
+      double h;
+      if (a >= 3) h = A[q * ld + q];
+      else {
+        h = 0.0;
+        for (int i = 0; i < 3; ++i)
+          for (int j2 = 0; j2 < 3; ++j2) {
+            const int r = 6 * cf + (i >= j2 ? i : j2), c = 6 * cf + (i >= j2 ? j2 : i);
+            h += JL[3 * i + a] * A[r * ld + c] * JL[3 * j2 + a];
+          }
+      }
+      hvec[q] = h;
+      if (a < 3) {
+        double sb = 0.0, sg = 0.0;
+        for (int i = 0; i < 3; ++i) { sb += JL[3 * i + a] * bvec[6 * cf + i]; sg += JL[3 * i + a] * gvec[6 * cf + i]; }
+        tvec[q] = sb; yvec[q] = sg;                         // staged: the loop reads all three raw entries of a camera
+      }
+    }
+    __syncthreads();
+    for (int q = tid; q < n; q += 256) if (q % 6 < 3) { bvec[q] = tvec[q]; gvec[q] = yvec[q]; }
+    // (3) S' = blockdiag(D') - P: accumulator tiles of P = sum_lines X X^T (tile t = (I, J), J <= I; entry q * 64 + lane is
+    // row (lane >> 4) + 4 q, column lane & 15)
+#pragma unroll 2
+    for (int q = tid; q < kMfmaTiles * 256; q += 256) {
+      int row, col;
+      acc_row_col(q >> 8, (q & 255) >> 6, q & 63, &row, &col);
+      if (row >= n || col > row) continue;
+      const double* src = p.slab + slab0 + q;
+      double s = 0.0;
+      for (int k0 = 0; k0 < wd.nchunks; k0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < wd.nchunks) ? src[(k0 + u) * sstride] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      A[row * ld + col] -= s;
+    }
+    __syncthreads();
+    // (4) S = T0^T S' T0, block by block: diagonal blocks mirrored to full 6x6 first (the upper triangle of A is free
+    // until the factorisation), then every block's rows times JL_ci (w columns), then its columns times JL_cj^T (w rows)
+    for (int q = tid; q < ncf * 15; q += 256) {
+      const int cf = q / 15, e = q - 15 * cf;
+      const int a = e >= 10 ? 5 : e >= 6 ? 4 : e >= 3 ? 3 : e >= 1 ? 2 : 1, b = e - ((a - 1) * a) / 2;   // a > b
+      A[(6 * cf + b) * ld + 6 * cf + a] = A[(6 * cf + a) * ld + 6 * cf + b];
+    }
+    __syncthreads();
+    const int nblk = (ncf * (ncf + 1)) / 2;
+    for (int q = tid; q < nblk * 6; q += 256) {
+      const int blk = q / 6, a = q - 6 * blk;
+      int cj = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
+      while ((cj * (cj + 1)) / 2 > blk) --cj;
+      while (((cj + 1) * (cj + 2)) / 2 <= blk) ++cj;
+      const int ci = blk - (cj * (cj + 1)) / 2;
+      double* row = A + (6 * cj + a) * ld + 6 * ci;
+      const double* JL = jlm + 9 * ci;
+      const double x0 = row[0], x1 = row[1], x2 = row[2];
+      for (int c = 0; c < 3; ++c) row[c] = x0 * JL[c] + x1 * JL[3 + c] + x2 * JL[6 + c];
+    }
+    __syncthreads();
+    for (int q = tid; q < nblk * 6; q += 256) {
+      const int blk = q / 6, b = q - 6 * blk;
+      int cj = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
+      while ((cj * (cj + 1)) / 2 > blk) --cj;
+      while (((cj + 1) * (cj + 2)) / 2 <= blk) ++cj;
+      const int ci = blk - (cj * (cj + 1)) / 2;
+      double* col = A + (6 * cj) * ld + 6 * ci + b;
+      const double* JL = jlm + 9 * cj;
+      const double x0 = col[0], x1 = col[ld], x2 = col[2 * ld];
+      for (int r = 0; r < 3; ++r) col[r * ld] = JL[r] * x0 + JL[3 + r] * x1 + JL[6 + r] * x2;
+    }
+    __syncthreads();
+    // (5) Jacobi scale of the camera columns, kept since the first iteration (the first one derives it below)
+    if (!fresh) {
+      for (int q = tid; q < 6 * wd.C; q += 256) {
+        const int c = q / 6, cf = p.cam_cf[wd.cam_off + c];
+        if (cf >= 0) tvec[6 * cf + (q - 6 * c)] = p.cam_scale[(long long)(wd.cam_off + c) * 6 + (q - 6 * c)];
+      }
+      __syncthreads();
+      for (int q = tid; q < n * ld; q += 256) {
+        const int r = q / ld, c = q - r * ld;
+        if (c <= r) A[q] *= tvec[r] * tvec[c];
+      }
+      for (int q = tid; q < n; q += 256) {
+        const double sc = tvec[q];
+        bvec[q] *= sc; gvec[q] *= sc; hvec[q] *= sc * sc;
+      }
+    }
+  } else {
 #pragma unroll 2
   for (int q = tid; q < nsys; q += 256) {
     const double* src = p.slab + slab0 + q;
@@ -752,10 +884,11 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
       }
     }
   }
+  }
   double gmax_line = 0.0;
   int fail = 0;
   for (int k = 0; k < wd.nchunks; ++k) {
-    const double* sc = p.slab + p.chunks[wd.chunk_off + k].slab_off + nsys;
+    const double* sc = p.slab + p.chunks[wd.chunk_off + k].slab_off + nsys_slab;
     gmax_line = fmax(gmax_line, sc[kScGradMaxLine]);
     if (sc[kScFail] != 0.0) fail = 1;
   }
@@ -770,7 +903,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
       double cost = 0.0, fixed = 0.0, xn2 = 0.0, gmax = 0.0;
       if (lane == 0) {
         for (int k = 0; k < wd.nchunks; ++k) {
-          const double* sc = p.slab + p.chunks[wd.chunk_off + k].slab_off + nsys;
+          const double* sc = p.slab + p.chunks[wd.chunk_off + k].slab_off + nsys_slab;
           cost += sc[kScCost]; fixed += sc[kScFixedCost]; xn2 += sc[kScXn2Line];
         }
         gmax = gmax_line;
@@ -1027,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
 // registers when the line's candidate parameters become known, the candidate residual is
 // evaluated right here: no third sweep over the observations and no separate sin/cos pass.
 enum { kCandTab = 13 };   // doubles per camera of the candidate table: R[9] t[3]; odd stride in 8-byte units
-__host__ __device__ inline int lds_doubles_backsub(int C, int n) { (void)n; return C * (kBsTab + kCandTab) + (C + 7) / 8; }
+__host__ __device__ inline int lds_doubles_backsub(int C, int n) { (void)n; return C * (kBsTab + kCandTab) + 8 + (C + 7) / 8; }
 
 // sin/cos table of a candidate line, computed cooperatively: every lane of a line's run holds the same u[4];
 // lane j < 4 of the run evaluates the sin/cos of angle j and the run shares the results (ds_bpermute from the
@@ -1062,9 +1195,10 @@ __device__ __forceinline__ void seg_line_trig(const double u[4], const SegCtx& s
   trig[6] = sc[7] / sc[6];
 }
 
-__global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
+// One or two waves per chunk workgroup (blockDim.x = 64 or 128): wave w takes the tiles tile_begin + w, + nw, ...
+__global__ __launch_bounds__(128) void k_backsub(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const Chunk ck = p.chunks[blockIdx.x];
   const WinDesc wd = p.wins[ck.win];
   const LMState* st = p.state + ck.win;
@@ -1073,8 +1207,9 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
   const int n = wd.n;
   double* bstab = smem;
   double* candtab = bstab + wd.C * kBsTab;
-  signed char* camcf = (signed char*)(candtab + wd.C * kCandTab);
-  for (int c = lane; c < wd.C; c += 64) {
+  double* red = candtab + wd.C * kCandTab;             // [2][4] per-wave sums
+  signed char* camcf = (signed char*)(red + 8);
+  for (int c = tid; c < wd.C; c += 64 * nw) {
     // accepted pose: R, t and the camera step folded through JL and the Jacobi scale;
     // candidate pose (written by k_reduced_solve): R, t for the cost at the candidate point
     const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + cur) * kCamRec;
@@ -1105,13 +1240,13 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
   __syncthreads();
 
   double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0, acc_cost = 0.0;
-  TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
+  TileCtx nxt = fetch_tile(p, ck.tile_begin + wave, ck.tile_end, lane);
   ObsPref pfn;
   prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
-  for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
+  for (int t = ck.tile_begin + wave; t < ck.tile_end; t += nw) {
     const TileCtx tc = nxt;
     const ObsPref pf = pfn;
-    nxt = fetch_tile(p, t + 1, ck.tile_end, lane);
+    nxt = fetch_tile(p, t + nw, ck.tile_end, lane);
     const SegCtx sg = make_seg(tc, lane);
     const int j = tc.j, ls = tc.ls, k = tc.k;
     const bool line_ok = tc.line_ok;
@@ -1188,7 +1323,15 @@ __global__ __launch_bounds__(64) void k_backsub(BatchPtrs p, Policy pol) {
     }
   }
   const double m = wave_sum(acc_model), d = wave_sum(acc_dn2), x = wave_sum(acc_xn2), cs = wave_sum(acc_cost);
-  if (lane == 0) {
+  if (nw > 1) {
+    if (lane == 0) { red[4 * wave] = m; red[4 * wave + 1] = d; red[4 * wave + 2] = x; red[4 * wave + 3] = cs; }
+    __syncthreads();
+    if (tid == 0) {
+      double* bp = p.bs_part + (long long)blockIdx.x * kBsStride;
+      bp[kBsModel] = red[0] + red[4]; bp[kBsDn2] = red[1] + red[5]; bp[kBsXn2] = red[2] + red[6];
+      p.cost_part[blockIdx.x] = red[3] + red[7];
+    }
+  } else if (lane == 0) {
     double* bp = p.bs_part + (long long)blockIdx.x * kBsStride;
     bp[kBsModel] = m; bp[kBsDn2] = d; bp[kBsXn2] = x;
     p.cost_part[blockIdx.x] = cs;
@@ -1357,7 +1500,7 @@ __global__ __launch_bounds__(64) void k_lm_init(BatchPtrs p, Policy pol) {
   LMState* st = p.state + w;
   if (st->status != kRunning) return;
   const int n = wd.n, nsys = sys_doubles(n);
-  const long long slab0 = p.chunks[wd.chunk_off].slab_off;
+  const long long slab0 = wd.nchunks > 0 ? p.chunks[wd.chunk_off].slab_off : 0;     // a window without lines has no chunk
   const long long sstride = (long long)nsys + kSlabScalars;
   double cost = 0.0, fixed = 0.0, gmax = 0.0, xn2 = 0.0;
   for (int c = lane; c < wd.nchunks; c += 64) {

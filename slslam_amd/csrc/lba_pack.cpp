@@ -47,7 +47,11 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   std::vector<int> kfree(L, 0);
   std::vector<unsigned> fmask(L, 0u);            // free cameras that see the line
   for (int i = 0; i < M; ++i)
-    if (P.cam_cf[w->camera_index[i]] >= 0) { kfree[w->line_index[i]]++; fmask[w->line_index[i]] |= 1u << P.cam_cf[w->camera_index[i]]; }
+    if (P.cam_cf[w->camera_index[i]] >= 0) {
+      const unsigned bit = 1u << P.cam_cf[w->camera_index[i]];
+      if (fmask[w->line_index[i]] & bit) P.dup_free_obs = true;
+      kfree[w->line_index[i]]++; fmask[w->line_index[i]] |= bit;
+    }
   auto lanes_of = [&](int l) { return std::max(line_cnt[l], 1); };
   auto items_of = [&](int l) { return line_const[l] ? 0 : (kfree[l] * (kfree[l] - 1)) / 2; };
   struct Row { int used, items, head, tail; unsigned mask; };   // the lines of a row are chained through `next`; mask: free cameras
@@ -180,6 +184,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
     P.tiles.reserve(tile_ptr.size());
     { size_t ni = 0; for (int l = 0; l < L; ++l) ni += (size_t)items_of(l); P.items.reserve(2 * ni); }
     P.lane_map.reserve(64 * tile_ptr.size());
+    P.line_desc.assign(L, 0u);
     uint16_t map[64];
     for (size_t ti = 0; ti + 1 < tile_ptr.size(); ++ti) {
       Tile t;
@@ -199,6 +204,20 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
             while (kf < k && P.cam_cf[P.ob_cam[P.line_ptr[s] + kf]] >= 0) ++kf;
             for (int i = 0; i < kf; ++i)
               for (int j = i + 1; j < kf; ++j) { P.items.push_back((uint8_t)(lane + i)); P.items.push_back((uint8_t)(lane + j)); }
+          }
+          {
+            // what the matrix-core elimination needs to find the line's F blocks and to know which accumulator tiles the line
+            // updates: free-camera mask (bits 0-9; the observations of these cameras are the first lanes of the run, ascending
+            // free index) | first lane of the run << 10 | tile t = (I, J), J <= I, touched (both 16-row blocks hold a row of
+            // one of the line's cameras; camera cf owns rows 6 cf .. 6 cf + 5) << (16 + t)
+            const uint32_t m = (P.line_flags[s] & 1) ? 0u : (fmask[P.line_order[s]] & 0x3ffu);
+            bool blk[4] = { false, false, false, false };
+            for (int cf = 0; cf < 10; ++cf)
+              if ((m >> cf) & 1u) { blk[(6 * cf) / 16] = true; blk[(6 * cf + 5) / 16] = true; }
+            uint32_t tiles_touched = 0;
+            for (int I = 0, t = 0; I < 4; ++I)
+              for (int J = 0; J <= I; ++J, ++t) if (blk[I] && blk[J]) tiles_touched |= 1u << t;
+            P.line_desc[s] = m | ((uint32_t)lane << 10) | (tiles_touched << 16);
           }
           lane += run;
         }

@@ -97,7 +97,9 @@ struct Policy {             // numeric policy, by value into every kernel that n
   double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
   double function_tolerance, gradient_tolerance, parameter_tolerance;
   int max_num_iterations, max_invalid, jacobi_scaling, pad;
-  int store_f, pad2;           // 1: spill F blocks for the streaming back-substitution (variant B)
+  int store_f;                 // 1: spill F blocks for the streaming back-substitution (variant B)
+  int debug_flags;             // timing experiments only (environment SLSLAM_DEBUG_ABLATE; results are wrong when set): bit 0 skip the
+                               // matrix-core phase, bit 1 fetch operands without MFMA, bit 2 skip the camera-record atomics
 };
 
 // Everything the kernels need, passed by value.
@@ -107,6 +109,8 @@ struct BatchPtrs {
   const Chunk* chunks;
   const uint16_t* lane_map;   // [ntile][64] lane -> (line slot, position in the line's run), see Tile
   const uint8_t* items;       // 2 bytes per item: (lane_i, lane_j), camera(lane_i) <= camera(lane_j)
+  const uint32_t* line_desc;  // [nline] matrix-core elimination: free-camera mask (bits 0-9, 0 for a constant line) | first lane of the
+                              // line's run in its tile << 10 | accumulator tiles the line updates << 16
   // cameras
   double* cam_x;              // [ncam][2][6]
   double* cam_scale;          // [ncam][6]
@@ -135,6 +139,10 @@ struct BatchPtrs {
   const double* cam_x0;       // [ncam][6] initial camera poses (reset)
   const double* line_u0;      // [nline][4] initial line parameters (reset)
   int nwin, nchunk, nline, ncam;
+  unsigned long long* dbg_cycles;   // [nchunk * 2][16] phase timing of the matrix-core sweep (debug_flags bit 8), else unused
+  int elim_mode;              // 0: per-wave LDS partial fed by ds_add_f64 (lba_kernels.h); 1: matrix-core elimination
+                              // (lba_eliminate_mfma.h), slab layout sys_doubles_mfma()
+  int elim_waves;             // waves per chunk workgroup of the sweeps (1 or 2)
 };
 
 }  // namespace slslam

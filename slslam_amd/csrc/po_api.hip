@@ -70,7 +70,10 @@ void order_chains_first(int N, int E, const int* p1, const int* p2, const std::v
         if (isfree[k] && !junction[k] && !done[k]) {
           bool alone = true;                          // still untouched after this loop's earlier promotions?
           for (int v : adj[k]) if (junction[v]) alone = false;
-          if (alone) { junction[k] = 1; }
+          if (alone) {                                // one pose per cycle: walk the rest of the cycle right away, so that no
+            junction[k] = 1;                          // other pose of it is promoted (its poses are chain poses from here on)
+            for (int v : adj[k]) if (isfree[v] && !junction[v] && !done[v]) { walk(v); break; }
+          }
         }
   }
   // a chain whose two ends meet the same junction: move its last pose to the junctions

@@ -311,8 +311,9 @@ extern "C" int slslam_ransac_motion(const slslam_ransac_trials* tr, const double
     return SLSLAM_ERR_INVALID_ARGUMENT;
   const int H = tr->num_trials, K = tr->num_lines, s = tr->sample_size;
   if (H > 0 && K > 0 && (!tr->samples || !tr->observations0 || !tr->observations1 || !lines)) return SLSLAM_ERR_INVALID_ARGUMENT;
-  for (long long i = 0; i < (long long)H * s; ++i)
-    if (K == 0 || tr->samples[i] < 0 || tr->samples[i] >= K) return SLSLAM_ERR_INVALID_ARGUMENT;
+  // comm_size == 0: the reference's trial loop never runs (ransac_trial = 0), whatever the sample array holds
+  for (long long i = 0; K > 0 && i < (long long)H * s; ++i)
+    if (tr->samples[i] < 0 || tr->samples[i] >= K) return SLSLAM_ERR_INVALID_ARGUMENT;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SLSLAM_ERR_NO_DEVICE;
   *trial_cnt = 0;
@@ -376,8 +377,8 @@ extern "C" int slslam_ransac_motion_batch(int num_frames, const slslam_ransac_tr
     if (tr.num_trials < 0 || tr.num_lines < 0 || tr.sample_size < 1 || tr.sample_size > 16) return SLSLAM_ERR_INVALID_ARGUMENT;
     const int H = tr.num_trials, K = tr.num_lines, s = tr.sample_size;
     if (H > 0 && K > 0 && (!tr.samples || !tr.observations0 || !tr.observations1 || !lines[f])) return SLSLAM_ERR_INVALID_ARGUMENT;
-    for (long long i = 0; i < (long long)H * s; ++i)
-      if (K == 0 || tr.samples[i] < 0 || tr.samples[i] >= K) return SLSLAM_ERR_INVALID_ARGUMENT;
+    for (long long i = 0; K > 0 && i < (long long)H * s; ++i)      // a frame without common lines runs no trials
+      if (tr.samples[i] < 0 || tr.samples[i] >= K) return SLSLAM_ERR_INVALID_ARGUMENT;
     Off& o = off[f];
     o.H = H; o.K = K; o.s = s; o.words = (K + 63) / 64;
     o.o0 = nd; nd += 8 * (size_t)K; o.o1 = nd; nd += 8 * (size_t)K; o.ln = nd; nd += 6 * (size_t)K; o.poses = nd; nd += 12 * (size_t)H;

@@ -12,6 +12,11 @@
 // src/lba_problem.cpp:46-52).  build() binds the arrays instead of allocating M cost functions;
 // the residual functor itself (src/lba_problem.h:46-118) lives in slslam_amd/csrc/lba_math.h and
 // runs on the GPU.
+//
+// Attribution: the class surface declared here (names, signatures, accessor layout) mirrors the interface of
+// SLSLAM's src/lba_problem.h — Copyright (C) 2015 Guoxuan Zhang, Jin Han Lee, Jongwoo Lim, Il Hong Suh, distributed under the
+// GNU General Public License, version 2 or later — because the drop-in contract is that interface.  Only the
+// declarations are mirrored; the implementation behind them is this repository's own.
 #ifndef LBA_PROBLEM_H_
 #define LBA_PROBLEM_H_
 

@@ -3,6 +3,11 @@
 // Same names, argument meaning and ownership (destructor delete[]s the four arrays,
 // src/po_problem.cpp:33-38).  The SE(3) functor (src/po_problem.h:27-108) runs on the GPU
 // (slslam_amd/csrc/po_kernels.h).
+//
+// Attribution: the class surface declared here (names, signatures, accessor layout) mirrors the interface of
+// SLSLAM's src/po_problem.h — Copyright (C) 2015 Guoxuan Zhang, Jin Han Lee, Jongwoo Lim, Il Hong Suh, distributed under the
+// GNU General Public License, version 2 or later — because the drop-in contract is that interface.  Only the
+// declarations are mirrored; the implementation behind them is this repository's own.
 #ifndef PO_PROBLEM_H_
 #define PO_PROBLEM_H_
 

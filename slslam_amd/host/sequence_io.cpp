@@ -74,7 +74,7 @@ int slslam_parse_frame_text(const char* text, size_t len, const slslam_intrinsic
   while (p < len) {
     size_t e = p;
     while (e < len && text[e] != '\n') ++e;
-    if (e - p >= 255) break;                 // getline(line, 256) sets failbit on a longer line: the read ends
+    if (e - p > 255) break;                  // getline(line, 256) stores up to 255 characters; a longer line sets failbit: the read ends
     std::memcpy(line, text + p, e - p);
     line[e - p] = 0;
     int id;

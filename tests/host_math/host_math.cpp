@@ -2,6 +2,7 @@
 // CPU test-suite can compare the analytic Jacobians with the oracle's dual numbers without a GPU.
 // Test infrastructure only: nothing in the product links this.
 #include "../../slslam_amd/csrc/lba_math.h"
+#include "../../slslam_amd/csrc/lba_gram.h"
 
 extern "C" {
 void hm_cam_prepare(const double* w, double* R, double* JL) { slslam::cam_prepare<double>(w, R, JL); }
@@ -29,6 +30,27 @@ void hm_obs_residual(const double* cam, const double* line, const double* obs, d
   slslam::line_trig<double>(line, trig);
   slslam::line_points<double>(trig, cp, dv);
   slslam::obs_residual<double>(R, cam + 3, cp, dv, obs, baseline, r);
+}
+// The Gram formulation of the elimination sweep (lba_gram.h): blocks of one observation in RAW camera coordinates
+// (J_c' = [tau | gP], i.e. without the SO(3) left Jacobian and without any scaling), line columns scaled by sl.
+// out: r[4], D[21] = J_c'^T J_c', gc[6] = J_c'^T r, G[24] = J_c'^T J_l (row-major 6x4), H[10] = J_l^T J_l, gl[4] = J_l^T r.
+void hm_obs_gram_blocks(const double* cam, const double* line, const double* obs, double baseline, const double* sl,
+                        double* r, double* D, double* gc, double* G, double* H, double* gl) {
+  double R[9], JL[9], trig[7], dc[3], e2[3], P[3], W[21], w[6], Ml[24], Y[24];
+  slslam::cam_prepare<double>(cam, R, JL);
+  slslam::line_trig<double>(line, trig);
+  slslam::obs_gram<double>(R, cam + 3, trig, obs, baseline, dc, e2, P, r, W, w);
+  const double Q[3] = { -trig[6] * e2[0], -trig[6] * e2[1], -trig[6] * e2[2] };
+  const double zc[3] = { R[2], R[5], R[8] };
+  slslam::gram_camera_block<double>(W, Q, dc, D);
+  slslam::apply_mc<double>(Q, dc, w, gc);
+  slslam::line_rows<double>(dc, e2, zc, trig[6], trig[1], trig[0], sl, Ml);
+  slslam::gram_line<double>(W, w, Ml, Y, H, gl);
+  for (int j = 0; j < 4; ++j) {
+    double col[6];
+    slslam::apply_mc<double>(Q, dc, Y + 6 * j, col);
+    for (int a = 0; a < 6; ++a) G[4 * a + j] = col[a];
+  }
 }
 double hm_huber(double s, double a, double* cost) { return slslam::huber_scale<double>(s, a, cost); }
 }
@@ -62,4 +84,28 @@ int hm_pack(int C, int L, int M, const int* cam, const int* line, const int* fix
   std::memcpy(lane_map, P.lane_map.data(), P.lane_map.size() * sizeof(unsigned short));
   return 0;
 }
+}
+
+// ---- the matrix-core elimination's index maps (lba_eliminate_mfma.h), exported so that the CPU suite can replay one tile
+#include "../../slslam_amd/csrc/lba_eliminate_mfma_maps.h"
+extern "C" {
+// line descriptors of the packed window (free-camera mask | first lane << 16) and the duplicate-observation flag
+int hm_line_desc(int C, int L, int M, const int* cam, const int* line, const int* fixed, const double* obs, double* params,
+                 unsigned* line_desc, int* dup) {
+  slslam_lba_window w{C, L, M, cam, line, fixed, obs, params};
+  slslam::PackedWindow P;
+  const int rc = slslam::pack_window(&w, &P);
+  if (rc) return rc;
+  std::memcpy(line_desc, P.line_desc.data(), sizeof(unsigned) * L);
+  *dup = P.dup_free_obs ? 1 : 0;
+  return 0;
+}
+// where lane `lane` stores entry (a, k) of its F block / where it fetches its operand of block I for a line (mask, first lane);
+// returns -1 when the lane's camera does not see the line
+int hm_panel_store(int lane, int a, int k) { return slslam::panel_store_index(lane, a, k); }
+int hm_panel_fetch(int lane, int I, unsigned mask, int first_lane) { return slslam::panel_fetch_index(lane, I, mask, first_lane); }
+unsigned hm_block_cam_mask(int I) { return slslam::block_cam_mask(I); }
+int hm_ptile_of(int nw, int w, int e) { return slslam::ptile_of(nw, w, e); }
+// accumulator entry (tile t, register q, lane) -> row / column of the stacked system
+void hm_acc_rc(int t, int q, int lane, int* row, int* col) { slslam::acc_row_col(t, q, lane, row, col); }
 }

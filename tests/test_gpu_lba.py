@@ -217,6 +217,44 @@ def test_batch_equals_single_and_is_reproducible(hip, oracle):
     b.close()
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+def test_matrix_core_elimination_sweep(hip, oracle, mode):
+    """lba_elimination = 2 / 3: Schur outer products on v_mfma_f64_16x16x4_f64 with the accumulator tiles in registers
+    (lba_eliminate_mfma.h), normal-equation blocks from the Gram formulation (lba_gram.h), camera constants applied by the
+    reduced solve.  Different operation order than the default sweep and the oracle, the same algebra: the first three
+    iterations agree with the oracle to the trace tolerances above, step counts and terminations are equal, final cost
+    to 1e-6 relative and parameters to 1e-5 (the late iterations inherit the conditioning of the problem, see the header
+    of this file); two runs are bitwise identical.  Shapes: the bench window family, few cameras, tiles with more than
+    32 lines (sources derived from the line masks), lines that span several lane rows, motion-only (no free line)."""
+    shapes = [dict(num_lines=150), dict(num_lines=500), dict(num_lines=60, num_kf=6, num_free=3),
+              dict(num_lines=90, num_kf=8, num_free=6, mean_track=2.0),
+              dict(num_lines=60, num_kf=24, num_free=10, mean_track=40.0)]
+    ws = [synth.make_window(70 + i, **kw) for i, kw in enumerate(shapes)]
+    ws.append(synth.make_motion_only(5, num_lines=40))
+    for w in ws:
+        x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+        x1, s1, t1 = hip.lba_solve(w, lba_elimination=mode, lba_fused_motion_only=0)
+        xd, sd, td = hip.lba_solve(w, lba_elimination=1, lba_fused_motion_only=0)
+        _assert_trace_parity(t0, t1, n=3)
+        for k in ("num_successful_steps", "num_unsuccessful_steps", "termination_type", "num_free_parameters", "num_residual_blocks"):
+            assert s0[k] == s1[k] == sd[k], k
+        assert abs(s0["initial_cost"] - s1["initial_cost"]) <= 1e-12 * s0["initial_cost"]
+        assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-6 * s0["final_cost"]
+        assert np.abs(x0 - x1).max() < 1e-5 and np.abs(xd - x1).max() < 1e-5
+    b = hip.LBABatch()
+    for w in ws[:4]:
+        b.add(w)
+    b.finalize(lba_elimination=mode)
+    b.solve(); b.download()
+    first = [b.parameters(i).copy() for i in range(4)]
+    b.reset(); b.solve(); b.download()
+    for i in range(4):
+        assert np.array_equal(first[i], b.parameters(i)), "window %d not reproducible" % i
+        xs, _, _ = hip.lba_solve(ws[i], lba_elimination=mode)
+        assert np.abs(xs - first[i]).max() < 1e-8          # batch vs single: different chunking, same algebra
+    b.close()
+
+
 def test_spilled_elimination_variant(hip, oracle):
     """reuse_elimination = 1: the back-substitution streams the F blocks the elimination kernel
     spilled instead of re-linearising; same algebra, so the same solve to round-off."""

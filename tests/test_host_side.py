@@ -41,6 +41,130 @@ def test_analytic_jacobian_matches_oracle_dual_numbers(host_math, oracle):
     assert worst[0] < 1e-14 and worst[1] < 1e-13 and worst[2] < 1e-13
 
 
+def test_gram_formulation_matches_explicit_jacobians(host_math):
+    """lba_gram.h (what the matrix-core elimination sweep evaluates: W = sum g g^T per observation, every block a product
+    with it) against the explicit analytic Jacobians of lba_math.h.  Raw camera coordinates: J_c = J_c' T_c with
+    T_c = diag(JL, I) — the reduced solve applies T_c — so J_c' is recovered from J_c with JL^-1."""
+    rng = np.random.default_rng(11)
+    w = synth.make_window(6, num_lines=60)
+    Cn, prm = w["num_cameras"], w["parameters"]
+    worst = 0.0
+    for i in range(0, len(w["camera_index"]), 2):
+        cam = prm[6 * w["camera_index"][i]:][:6].copy()
+        if i % 6 == 0:
+            cam[:3] = 0.0                                    # the identity keyframe: first-order branch of the rotation
+        line = prm[6 * Cn + 4 * w["line_index"][i]:][:4].copy()
+        ob = w["observations"][i].copy()
+        sl = rng.uniform(0.2, 1.5, size=4)
+        r, jc, jl = np.zeros(4), np.zeros((4, 6)), np.zeros((4, 4))
+        host_math.hm_obs_linearise(_dp(cam), _dp(line), _dp(ob), C.c_double(0.12), _dp(r), _dp(jc), _dp(jl))
+        R, JL = np.zeros(9), np.zeros(9)
+        host_math.hm_cam_prepare(_dp(cam), _dp(R), _dp(JL))
+        jcp = jc.copy()
+        jcp[:, :3] = jc[:, :3] @ np.linalg.inv(JL.reshape(3, 3))       # rows tau^T
+        jls = jl * sl
+        r2, D, gc, G, H, gl = np.zeros(4), np.zeros(21), np.zeros(6), np.zeros((6, 4)), np.zeros(10), np.zeros(4)
+        host_math.hm_obs_gram_blocks(_dp(cam), _dp(line), _dp(ob), C.c_double(0.12), _dp(sl), _dp(r2), _dp(D), _dp(gc), _dp(G),
+                                     _dp(H), _dp(gl))
+        Dw, Hw = jcp.T @ jcp, jls.T @ jls
+        tri6 = np.array([Dw[a, b] for a in range(6) for b in range(a + 1)])
+        tri4 = np.array([Hw[a, b] for a in range(4) for b in range(a + 1)])
+        for got, want in ((r2, r), (D, tri6), (gc, jcp.T @ r), (G, jcp.T @ jls), (H, tri4), (gl, jls.T @ r)):
+            worst = max(worst, abs(got - want).max() / (1e-300 + abs(want).max()))
+    assert worst < 5e-12, worst
+
+
+def test_mfma_elimination_index_maps_replay_a_window(host_math):
+    """The matrix-core elimination sweep (lba_eliminate_mfma.h) replayed on the CPU through the index maps the kernels use
+    (lba_eliminate_mfma_maps.h compiled for the host): every observation of a free camera stores a random 6x4 F block in
+    the panel slab of its lane; per line, lane l fetches X[16 I + (l & 15)][l >> 4] for the blocks the line touches and the
+    touched accumulator tiles take the rank-4 update X_I X_J^T with the v_mfma_f64_16x16x4_f64 register layout; decoded
+    with acc_row_col (what k_reduced_solve does) the tiles must hold sum_lines sum_{i,j} F_i F_j^T."""
+    rng = np.random.default_rng(5)
+    w = synth.make_window(9, num_lines=150)
+    rc, P = _pack(host_math, w)
+    assert rc == 0
+    Cn, L, M = w["num_cameras"], w["num_lines"], len(w["camera_index"])
+    cam = np.ascontiguousarray(w["camera_index"], dtype=np.int32)
+    line = np.ascontiguousarray(w["line_index"], dtype=np.int32)
+    fixed = np.ascontiguousarray(w["fixed_index"], dtype=np.int32).reshape(-1)
+    obs = np.ascontiguousarray(w["observations"], dtype=np.float64).reshape(-1)
+    prm = np.array(w["parameters"], dtype=np.float64)
+    desc, dup = np.zeros(L, dtype=np.uint32), C.c_int(-1)
+    assert host_math.hm_line_desc(Cn, L, M, _ip(cam), _ip(line), _ip(fixed), _dp(obs), _dp(prm),
+                                  desc.ctypes.data_as(C.POINTER(C.c_uint)), C.byref(dup)) == 0
+    assert dup.value == 0
+    ncf = P["Cf"]
+    n = 6 * ncf
+    want = np.zeros((64, 64))
+    tiles = np.zeros((10, 4, 64))                        # accumulator registers [tile][q][lane]
+    bm = [host_math.hm_block_cam_mask(I) for I in range(4)]
+    nmfma = 0
+    for t, (lb, nl, flags, ni) in enumerate(P["tiles"]):
+        panel = np.full(4 * 400 + 64, np.nan)
+        lane_slot, lane_pos = P["lane_map"][t] & 0xFF, P["lane_map"][t] >> 8
+        F = {}
+        for lane in range(64):
+            if lane_slot[lane] == 0xFF:
+                continue
+            s_ = lb + int(lane_slot[lane])
+            k = int(P["line_ptr"][s_ + 1] - P["line_ptr"][s_])
+            if lane_pos[lane] >= k:
+                continue
+            cf = P["cam_cf"][P["ob_cam"][P["line_ptr"][s_] + int(lane_pos[lane])]]
+            if cf < 0:
+                continue
+            Fb = rng.normal(size=(6, 4))
+            F[(s_, int(cf))] = Fb
+            for a in range(6):
+                for k4 in range(4):
+                    panel[host_math.hm_panel_store(lane, a, k4)] = Fb[a, k4]
+        for q in range(nl):
+            s_ = lb + q
+            mask, first, tbits = int(desc[s_]) & 0x3FF, (int(desc[s_]) >> 10) & 63, int(desc[s_]) >> 16
+            cams = [c for c in range(ncf) if (mask >> c) & 1]
+            assert sorted(c for (ss, c) in F if ss == s_) == cams          # the mask names the line's free cameras
+            assert first == int(np.nonzero(lane_slot == q)[0][0])
+            X = np.zeros((4, 64))
+            for I in range(4):
+                if not (mask & bm[I]):
+                    continue
+                for lane in range(64):
+                    idx = host_math.hm_panel_fetch(lane, I, mask, first)
+                    if idx >= 0:
+                        X[I, lane] = panel[idx]
+            assert not np.isnan(X).any()
+            stack = np.zeros((64, 4))
+            for c in cams:
+                stack[6 * c:6 * c + 6] = F[(s_, c)]
+            want += stack @ stack.T
+            for tt in range(10):
+                I, J = (3 if tt >= 6 else 2 if tt >= 3 else 1 if tt >= 1 else 0), 0
+                J = tt - I * (I + 1) // 2
+                assert bool((mask & bm[I]) and (mask & bm[J])) == bool((tbits >> tt) & 1)     # the packer's tile bits
+                if (tbits >> tt) & 1:
+                    nmfma += 1
+                    Am = np.array([[X[I, m + 16 * kk] for kk in range(4)] for m in range(16)])     # A[m][k] = a(lane = m + 16 k)
+                    Bm = np.array([[X[J, nn + 16 * kk] for nn in range(16)] for kk in range(4)])   # B[k][n] = b(lane = n + 16 k)
+                    Dm = Am @ Bm
+                    for lane in range(64):
+                        for qq in range(4):
+                            tiles[tt, qq, lane] += Dm[(lane >> 4) + 4 * qq, lane & 15]
+    got = np.zeros((64, 64))
+    row, col = C.c_int(0), C.c_int(0)
+    for tt in range(10):
+        for qq in range(4):
+            for lane in range(64):
+                host_math.hm_acc_rc(tt, qq, lane, C.byref(row), C.byref(col))
+                got[row.value, col.value] = tiles[tt, qq, lane]
+    lower = np.tril(np.ones((64, 64), dtype=bool))
+    assert abs(got - want)[lower].max() < 1e-11 and abs(want[n:, :]).max() == 0.0
+    assert 3.0 < nmfma / L < 6.0                          # ~4.4 MFMA per line on sliding-window visibility
+    # both waves of a two-wave workgroup together own every tile exactly once
+    owned = sorted(host_math.hm_ptile_of(2, wv, e) for wv in range(2) for e in range(5))
+    assert owned == list(range(10)) and [host_math.hm_ptile_of(1, 0, e) for e in range(10)] == list(range(10))
+
+
 def test_backsub_contraction_matches_jacobians(host_math):
     """The back-substitution's w = J_l^T (J_c y_c), contracted on the fly (obs_backsub_w), equals the product of the
     explicit analytic Jacobians."""
