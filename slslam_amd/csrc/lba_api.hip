@@ -187,6 +187,8 @@ struct slslam_lba_batch {
   DevBuf<double> d_cam_x, d_cam_x0, d_cam_scale; DevBuf<int> d_cam_cf, d_cam_win;
   DevBuf<double> d_line_x, d_line_x0, d_line_scale; DevBuf<int> d_line_ptr, d_line_flags, d_line_win, d_line_orig;
   DevBuf<double> d_ob; DevBuf<int> d_ob_cam, d_ob_orig;
+  DevBuf<double> d_slab_sum;
+  long long slab_sum_stride = 0;           // > 0: k_slab_reduce runs ahead of the reduced solve
   DevBuf<double> d_slab, d_bs_part, d_cost_part, d_ysys, d_params_out, d_fstore, d_line_elim;
   DevBuf<LMState> d_state; DevBuf<IterRec> d_trace; DevBuf<long long> d_param_off;
   BatchPtrs ptrs;
@@ -224,7 +226,7 @@ struct slslam_lba_batch {
     d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release();
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
     d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release(); d_active.release();
-    d_fstore.release(); d_line_elim.release();
+    d_fstore.release(); d_line_elim.release(); d_slab_sum.release();
     arena.release();
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     if (capture_stream) { (void)hipStreamDestroy(capture_stream); capture_stream = nullptr; }
@@ -324,12 +326,13 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     else {
       // the sweeps run 8 one-wave workgroups per CU (LDS): the same number of chunks for every window, chosen so that
       // the batch fills whole rounds of the chip's wave slots with about 36 tiles per chunk at most
-      // (1024 bench windows: 6 chunks of 33 tiles = 6144 waves = 3 rounds of 256 CUs x 8), at least 4 tiles per chunk
+      // (1024 bench windows: 6 chunks of 33 tiles = 6144 waves = 3 rounds of 256 CUs x 8)
       const long long slots = (8LL / b->elim_waves) * b->num_cus;      // chunk workgroups resident per round
       const long long per_round = 36LL * b->elim_waves * slots;
       const long long rounds = std::max<long long>(1, (total_tiles + per_round - 1) / per_round);
       const long long cpw = std::max<long long>(1, (slots * rounds) / std::max(1, B));
-      per_chunk = (int)std::max<long long>(4 * b->elim_waves, (wd.ntiles + cpw - 1) / cpw);
+      // (at least 2 tiles per wave: below that the camera table set-up and the partial written per chunk outweigh the tiles)
+      per_chunk = (int)std::max<long long>(2 * b->elim_waves, (wd.ntiles + cpw - 1) / cpw);
     }
     const std::vector<int> bounds = chunk_boundaries(wd.ntiles, per_chunk);
     wd.chunk_off = (int)chunks.size(); wd.nchunks = (int)bounds.size() - 1;
@@ -415,6 +418,16 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.upload(b->d_ob_cam, ob_cam);
   ar.upload(b->d_ob_orig, ob_orig);
   ar.scratch(b->d_slab, std::max<size_t>(1, (size_t)slab));
+  {
+    // windows cut into many chunks (small batches): their partials are summed by a kernel of their own, spread over the chip
+    int max_chunks = 0, max_sys = 0;
+    for (const WinDesc& wd : b->h_wins) {
+      max_chunks = std::max(max_chunks, wd.nchunks);
+      max_sys = std::max(max_sys, b->elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n));
+    }
+    b->slab_sum_stride = (max_chunks > 8 && !b->opt.reuse_elimination) ? (long long)max_sys + kSlabScalars : 0;
+    ar.scratch(b->d_slab_sum, b->slab_sum_stride ? (size_t)b->slab_sum_stride * (size_t)B : 1);
+  }
   ar.scratch(b->d_bs_part, std::max<size_t>(1, (size_t)b->nchunk * kBsStride));
   ar.scratch(b->d_cost_part, std::max<size_t>(1, (size_t)b->nchunk));
   ar.scratch(b->d_ysys, std::max<size_t>(1, (size_t)sys));
@@ -435,6 +448,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.line_x = b->d_line_x.p; p.line_scale = b->d_line_scale.p; p.line_ptr = b->d_line_ptr.p;
   p.line_flags = b->d_line_flags.p; p.line_win = b->d_line_win.p;
   p.ob = b->d_ob.p; p.ob_cam = b->d_ob_cam.p; p.ob_stride = std::max<long long>(1, nobs);
+  p.slab_sum = b->slab_sum_stride ? b->d_slab_sum.p : nullptr; p.slab_sum_stride = b->slab_sum_stride;
   p.slab = b->d_slab.p; p.bs_part = b->d_bs_part.p; p.cost_part = b->d_cost_part.p; p.ysys = b->d_ysys.p;
   p.fstore = b->d_fstore.p; p.line_elim = b->d_line_elim.p;
   p.state = b->d_state.p; p.trace = b->d_trace.p;
@@ -510,7 +524,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
   Launcher L{ b, s, prof };
   const dim3 blk64(64), blk256(256);
   const dim3 g_chunk((unsigned)std::max(1, b->nchunk)), g_win((unsigned)B), g_line((unsigned)((b->nline + 255) / 256)),
-      g_upd((unsigned)((B + 63) / 64));
+      g_upd((unsigned)B);
   int rc;
 #define LAUNCH(fam, ...)                                   \
   do {                                                     \
@@ -548,6 +562,8 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       else if (b->elim_mode == 1) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<1, false>), g_chunk, blk64, b->lds_elim, s, p, pol));
       else LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_linearise_schur<false>, g_chunk, blk64, b->lds_lin, s, p, pol));
     }
+    if (b->slab_sum_stride)
+      LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((b->slab_sum_stride + 255) / 256), (unsigned)B), blk256, 0, s, p));
     LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve, g_win, blk256, b->lds_solve, s, p, pol));
     if (b->nchunk > 0) {
       if (pol.store_f) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub_stream, g_chunk, blk64, b->lds_bs_stream, s, p, pol));

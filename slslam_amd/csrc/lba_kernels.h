@@ -697,6 +697,45 @@ __host__ __device__ inline int lds_doubles_solve(int n) {
 }
 typedef double solve_acc_t __attribute__((ext_vector_type(4)));
 
+// Phase timing of the reduced solve (debug_flags bit 9, timing experiments only): wave 0 stamps the shader clock at the phase
+// boundaries, dbg_cycles[win * 16 + phase] accumulates (slslam_debug_phase_cycles reads it).
+__device__ __forceinline__ unsigned long long solve_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+#define SLS_SOLVE_STAMP(i)                                                                   \
+  do {                                                                                       \
+    if (timing) { const unsigned long long now_ = solve_clock(); if (tid == 0) p.dbg_cycles[(long long)w * 16 + (i)] += now_ - tlast_; tlast_ = now_; } \
+  } while (0)
+
+
+// Sum of a window's chunk partials, spread over the chip: launched ahead of k_reduced_solve when a window has many chunks
+// (a single window is cut into ~50 so that its sweeps fill the CUs; one workgroup reading all of them is bound by the
+// load bandwidth of its CU, ~10 B per cycle: 0.8 MB = 30 us on the latency path of every iteration).  One thread per entry,
+// partials added in chunk order (the sum k_reduced_solve would form); per-chunk scalars: cost / fixed cost / |x|^2 summed,
+// gradient norm and failure flag maxed.  Result: one slab per window in slab_sum, same layout.
+__global__ __launch_bounds__(256) void k_slab_reduce(BatchPtrs p) {
+  const int w = blockIdx.y;
+  const WinDesc wd = p.wins[w];
+  if (p.state[w].status != kRunning || wd.nchunks <= 0) return;
+  const int nsys = p.elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n);
+  const long long sstride = (long long)nsys + kSlabScalars;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nsys + kSlabScalars) return;
+  const double* src = p.slab + p.chunks[wd.chunk_off].slab_off + q;
+  const bool is_max = q == nsys + kScGradMaxLine || q == nsys + kScFail;
+  double s = 0.0;
+  for (int k0 = 0; k0 < wd.nchunks; k0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (k0 + u < wd.nchunks) ? src[(k0 + u) * sstride] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s = is_max ? fmax(s, v[u]) : s + v[u];
+  }
+  p.slab_sum[(long long)w * p.slab_sum_stride + q] = s;
+}
+
 __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -718,6 +757,8 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
   const int need_grad_check = st->need_grad_check;
   const double abs_grad_tol = st->abs_grad_tol;
   const int fresh = st->fresh;            // read before the barriers below: wave 0 clears it in step 1b
+  const bool timing = (pol.debug_flags & 512) && p.dbg_cycles;
+  unsigned long long tlast_ = timing ? solve_clock() : 0ull;
 
   for (int q = tid; q < N * ld; q += 256) A[q] = 0.0;
   for (int q = tid; q < 6 * N; q += 256) bvec[q] = 0.0;
@@ -725,18 +766,21 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
   // ---- 1. ordered reduction over the window's chunk partials (uniform stride between consecutive slabs)
   const bool mfma_slab = p.elim_mode == 1;          // slab layout of lba_eliminate_mfma.h
   const int nsys_slab = mfma_slab ? kMfmaTiles * 256 + ncf * kMfmaRec : nsys;
-  const long long slab0 = wd.nchunks > 0 ? p.chunks[wd.chunk_off].slab_off : 0;
+  const bool presummed = p.slab_sum != nullptr && wd.nchunks > 0;       // k_slab_reduce ran: one partial per window
+  const double* slab_base = presummed ? p.slab_sum : p.slab;
+  const long long slab0 = presummed ? (long long)w * p.slab_sum_stride : (wd.nchunks > 0 ? p.chunks[wd.chunk_off].slab_off : 0);
   const long long sstride = (long long)nsys_slab + kSlabScalars;
+  const int nchunks = presummed ? 1 : wd.nchunks;
   if (mfma_slab) {
     // The matrix-core sweep leaves everything in RAW camera coordinates (J_c' = [tau | gP]: no SO(3) left Jacobian, no
     // Jacobi scale).  (1) camera records: D' = J_c'^T J_c' (diagonal blocks), b', g'
     for (int q = tid; q < ncf * kMfmaRec; q += 256) {
-      const double* src = p.slab + slab0 + kMfmaTiles * 256 + q;
+      const double* src = slab_base + slab0 + kMfmaTiles * 256 + q;
       double s = 0.0;
-      for (int k0 = 0; k0 < wd.nchunks; k0 += 8) {
+      for (int k0 = 0; k0 < nchunks; k0 += 8) {
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < wd.nchunks) ? src[(k0 + u) * sstride] : 0.0;
+        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < nchunks) ? src[(k0 + u) * sstride] : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += v[u];
       }
@@ -791,12 +835,12 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
       int row, col;
       acc_row_col(q >> 8, (q & 255) >> 6, q & 63, &row, &col);
       if (row >= n || col > row) continue;
-      const double* src = p.slab + slab0 + q;
+      const double* src = slab_base + slab0 + q;
       double s = 0.0;
-      for (int k0 = 0; k0 < wd.nchunks; k0 += 8) {
+      for (int k0 = 0; k0 < nchunks; k0 += 8) {
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < wd.nchunks) ? src[(k0 + u) * sstride] : 0.0;
+        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < nchunks) ? src[(k0 + u) * sstride] : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += v[u];
       }
@@ -853,47 +897,73 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
       }
     }
   } else {
-#pragma unroll 2
-  for (int q = tid; q < nsys; q += 256) {
-    const double* src = p.slab + slab0 + q;
-    double s = 0.0;
-    for (int k0 = 0; k0 < wd.nchunks; k0 += 8) {           // 8 independent loads in flight, summed in chunk order
-      double v[8];
+  // eight entries of this thread at a time, four chunk partials each: 32 independent loads in flight (a single window is
+  // spread over ~50 chunks and this sum is on the latency path of every iteration); per entry the partials are still
+  // added in chunk order, so the result does not depend on the grouping
+  for (int q0 = tid; q0 < nsys; q0 += 8 * 256) {
+    double acc8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int k0 = 0; k0 < nchunks; k0 += 4) {
+      double v[8][4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (k0 + u < wd.nchunks) ? src[(k0 + u) * sstride] : 0.0;
+      for (int e = 0; e < 8; ++e)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + 256 * e;
+          v[e][u] = (q < nsys && k0 + u < nchunks) ? slab_base[slab0 + (long long)(k0 + u) * sstride + q] : 0.0;
+        }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc8[e] += v[e][u];
     }
-    if (q < ncf * kCamAcc) {
-      const int cf = q / kCamAcc, e = q - cf * kCamAcc;
-      if (e < kRecB) {
-        const int a = e >= 15 ? 5 : e >= 10 ? 4 : e >= 6 ? 3 : e >= 3 ? 2 : e >= 1 ? 1 : 0;
-        A[(6 * cf + a) * ld + 6 * cf + (e - tri_index(a, 0))] = s;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int q = q0 + 256 * e;
+      if (q >= nsys) continue;
+      const double s = acc8[e];
+      if (q < ncf * kCamAcc) {
+        const int cf = q / kCamAcc, ee = q - cf * kCamAcc;
+        if (ee < kRecB) {
+          const int a = ee >= 15 ? 5 : ee >= 10 ? 4 : ee >= 6 ? 3 : ee >= 3 ? 2 : ee >= 1 ? 1 : 0;
+          A[(6 * cf + a) * ld + 6 * cf + (ee - tri_index(a, 0))] = s;
+        } else {
+          const int v2 = (ee - kRecB) / 6, a = (ee - kRecB) - 6 * v2;      // 0 = b, 1 = g, 2 = hdiag
+          bvec[v2 * N + 6 * cf + a] = s;
+        }
       } else {
-        const int v = (e - kRecB) / 6, a = (e - kRecB) - 6 * v;      // 0 = b, 1 = g, 2 = hdiag
-        bvec[v * N + 6 * cf + a] = s;
-      }
-    } else {
-      const int pq = q - ncf * kCamAcc, pr = pq / kPairAcc, e = pq - pr * kPairAcc;
-      if (e < 36) {
-        int cj = (int)((sqrt(8.0 * pr + 1.0) + 1.0) * 0.5);
-        while ((cj * (cj - 1)) / 2 > pr) --cj;
-        while (((cj + 1) * cj) / 2 <= pr) ++cj;
-        const int ci = pr - (cj * (cj - 1)) / 2;
-        A[(6 * cj + e / 6) * ld + 6 * ci + (e % 6)] = s;
+        const int pq = q - ncf * kCamAcc, pr = pq / kPairAcc, ee = pq - pr * kPairAcc;
+        if (ee < 36) {
+          int cj = (int)((sqrt(8.0 * pr + 1.0) + 1.0) * 0.5);
+          while ((cj * (cj - 1)) / 2 > pr) --cj;
+          while (((cj + 1) * cj) / 2 <= pr) ++cj;
+          const int ci = pr - (cj * (cj - 1)) / 2;
+          A[(6 * cj + ee / 6) * ld + 6 * ci + (ee % 6)] = s;
+        }
       }
     }
   }
   }
   double gmax_line = 0.0;
   int fail = 0;
-  for (int k = 0; k < wd.nchunks; ++k) {
-    const double* sc = p.slab + p.chunks[wd.chunk_off + k].slab_off + nsys_slab;
-    gmax_line = fmax(gmax_line, sc[kScGradMaxLine]);
-    if (sc[kScFail] != 0.0) fail = 1;
+  {
+    // per-chunk scalars: the threads share the chunks (a single window has ~50 of them), then a block-wide max / any
+    double gm = 0.0;
+    int fl = 0;
+    for (int k = tid; k < nchunks; k += 256) {
+      const double* sc = slab_base + slab0 + (long long)k * sstride + nsys_slab;
+      gm = fmax(gm, sc[kScGradMaxLine]);
+      if (sc[kScFail] != 0.0) fl = 1;
+    }
+    gm = wave_max(gm);
+    fl = __any(fl) ? 1 : 0;
+    if (lane == 0) { red[4 + wave] = gm; red[8 + wave] = (double)fl; }
+    __syncthreads();
+    gmax_line = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    fail = (red[8] + red[9] + red[10] + red[11]) != 0.0 ? 1 : 0;
   }
   __syncthreads();
 
+  SLS_SOLVE_STAMP(0);
   // ---- 1b. first iteration of a solve: the elimination sweep ran with unit camera scale, so the system just read is in
   // UNSCALED camera coordinates.  Do what Ceres' initial evaluation does (cost, gradient max-norm, |x|, Jacobi scale of the
   // camera columns from diag(J^T J) at x0, trace record 0, the tests that can end a solve before its first step), then
@@ -901,13 +971,11 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
   if (fresh) {
     if (wave == 0) {
       double cost = 0.0, fixed = 0.0, xn2 = 0.0, gmax = 0.0;
-      if (lane == 0) {
-        for (int k = 0; k < wd.nchunks; ++k) {
-          const double* sc = p.slab + p.chunks[wd.chunk_off + k].slab_off + nsys_slab;
-          cost += sc[kScCost]; fixed += sc[kScFixedCost]; xn2 += sc[kScXn2Line];
-        }
-        gmax = gmax_line;
+      for (int k = lane; k < nchunks; k += 64) {
+        const double* sc = slab_base + slab0 + (long long)k * sstride + nsys_slab;
+        cost += sc[kScCost]; fixed += sc[kScFixedCost]; xn2 += sc[kScXn2Line];
       }
+      if (lane == 0) gmax = gmax_line;
       for (int q = lane; q < N; q += 64) tvec[q] = 1.0;
       for (int q = lane; q < 6 * wd.C; q += 64) {
         const int c = q / 6, a = q - 6 * c;
@@ -984,6 +1052,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
     if (red[0] <= abs_grad_tol) return;
   }
 
+  SLS_SOLVE_STAMP(1);
   // ---- 3. LM damping of the camera columns: D^2 = clamp(diag(J'^T J')) / radius; identity on the padding
   for (int q = tid; q < N; q += 256) {
     if (q < n) {
@@ -996,6 +1065,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
   }
   __syncthreads();
 
+  SLS_SOLVE_STAMP(2);
   const int er = tid >> 4, ec = tid & 15;       // this thread's element of a 16x16 tile
   for (int kb = 0; kb < nt; ++kb) {
     double* D = A + (16 * kb) * ld + 16 * kb;   // diagonal tile
@@ -1044,6 +1114,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
       }
     }
     __syncthreads();
+    SLS_SOLVE_STAMP(3);
     // (c) panel: L(i,kb) = A(i,kb) Linv^T, one tile per wave at a time
     for (int i = kb + 1 + wave; i < nt; i += 4) {
       double* T = A + (16 * i) * ld + 16 * kb;
@@ -1059,6 +1130,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
       for (int q = 0; q < 4; ++q) T[((lane >> 4) + 4 * q) * ld + (lane & 15)] = acc[q];
     }
     __syncthreads();
+    SLS_SOLVE_STAMP(4);
     // (d) trailing update: A(i,j) -= L(i,kb) L(j,kb)^T for kb < j <= i, tiles dealt round-robin to the waves
     int tile = 0;
     for (int i = kb + 1; i < nt; ++i)
@@ -1080,8 +1152,10 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
         for (int q = 0; q < 4; ++q) C[((lane >> 4) + 4 * q) * ld + (lane & 15)] = acc[q];
       }
     __syncthreads();
+    SLS_SOLVE_STAMP(9);
   }
 
+  SLS_SOLVE_STAMP(5);
   // ---- 4. block substitution.  forward: y_k = Linv_k (b_k - sum_{c < 16k} L[k,c] y_c)
   for (int kb = 0; kb < nt; ++kb) {
     {
@@ -1099,6 +1173,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
     }
     __syncthreads();
   }
+  SLS_SOLVE_STAMP(6);
   // backward: x_k = Linv_k^T (y_k - sum_{r >= 16(k+1)} L[r,k]^T x_r), in place in yvec
   for (int kb = nt - 1; kb >= 0; --kb) {
     {
@@ -1117,6 +1192,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
     __syncthreads();
   }
 
+  SLS_SOLVE_STAMP(7);
   // ---- 5. step statistics of the camera block and candidate camera poses (wave 0)
   if (wave != 0) return;
   double model = 0.0, dn2 = 0.0, xn2 = 0.0;
@@ -1150,6 +1226,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
     st->cam_model = model; st->cam_dn2 = dn2; st->cam_xn2 = xn2;
     st->solve_failed = any_bad ? 1 : 0;
   }
+  SLS_SOLVE_STAMP(8);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1612,20 +1689,23 @@ __device__ __forceinline__ void lm_step(BatchPtrs& p, const Policy& pol, int w, 
   atomicAdd(p.active_counter, 1u);    // still running: lets the host stop enqueueing long solves early
 }
 
+// One wave per window: the lanes fetch the window's chunk partials together (a single window is spread over ~50 chunks
+// and this kernel is on the latency path of every iteration), fixed-shape tree sum, lane 0 does the bookkeeping.
 __global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = blockIdx.x, lane = threadIdx.x;
   if (w >= p.nwin) return;
   const WinDesc wd = p.wins[w];
   LMState* st = p.state + w;
   if (st->status != kRunning) return;
   // ---- one LM iteration: totals over the window's chunks, then the bookkeeping
-  double new_cost = 0.0, model = st->cam_model, dn2 = st->cam_dn2, xn2 = st->cam_xn2;
-  for (int c = 0; c < wd.nchunks; ++c) {
+  double new_cost = 0.0, model = 0.0, dn2 = 0.0, xn2 = 0.0;
+  for (int c = lane; c < wd.nchunks; c += 64) {
     new_cost += p.cost_part[wd.chunk_off + c];
     const double* bp = p.bs_part + (long long)(wd.chunk_off + c) * kBsStride;
     model += bp[kBsModel]; dn2 += bp[kBsDn2]; xn2 += bp[kBsXn2];
   }
-  lm_step(p, pol, w, st, new_cost, model, dn2, xn2);
+  new_cost = wave_sum(new_cost); model = wave_sum(model); dn2 = wave_sum(dn2); xn2 = wave_sum(xn2);
+  if (lane == 0) lm_step(p, pol, w, st, new_cost, model + st->cam_model, dn2 + st->cam_dn2, xn2 + st->cam_xn2);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -127,6 +127,8 @@ struct BatchPtrs {
   long long ob_stride;
   // per-chunk / per-window work areas
   double* slab;               // linearise/Schur partials
+  double* slab_sum;           // [nwin][slab_sum_stride] per-window sum of the chunk partials (k_slab_reduce), nullptr when unused
+  long long slab_sum_stride;
   double* bs_part;            // [nchunk][kBsStride]
   double* cost_part;          // [nchunk]
   double* ysys;               // y_c per window (sys_off)
