@@ -97,6 +97,109 @@ def cpu_baseline_all_cores(windows, budget_s=15.0):
         len(sample), dt, its, min(cores, len(sample)))
 
 
+FP64_MEASURED_CEILING_TFLOPS = {1: 33.5, 2: 48.5, 3: 53.6, 4: 56.3, 8: 62.1}   # tools/micro/mfma_f64_bench.hip on MI355X: v_fma_f64
+                                                                              # stream, by waves per SIMD (spec: 78.6)
+
+
+def algorithmic_bytes_backsub(counts):
+    """Algorithmic HBM bytes of ONE launch of the second observation sweep (back-substitution + cost at the candidate point,
+    SURVEY.md 8d's second and third sweeps folded into one pass): observations 72 B each, every line's parameters read
+    and its candidate written (32 + 32 B), accepted and candidate camera poses (2 x 48 B), the camera step (6 Cf x 8 B)."""
+    return sum(72 * m + 64 * l + 96 * c + 48 * cf for (c, cf, l, m) in counts)
+
+
+def reduced_solve_mfma_count(n):
+    """v_mfma_f64_16x16x4_f64 instructions of one blocked (6 Cf)^2 Cholesky in k_reduced_solve: per block step 4 per panel
+    tile and 4 per trailing tile (n = 60: 64)."""
+    nt = (n + 15) // 16
+    return sum(4 * (nt - kb - 1) + 4 * ((nt - kb - 1) * (nt - kb)) // 2 for kb in range(nt))
+
+
+def ceres_probe():
+    """Is a Ceres Solver installation visible on this host (headers or shared library)?  The reference links Ceres 1.7.0
+    (README:8, src/CMakeLists.txt:14); without it the CPU baseline is the in-repo oracle (kind "port")."""
+    import glob
+    import subprocess
+    hits = []
+    for pat in ("/usr/include/ceres/ceres.h", "/usr/local/include/ceres/ceres.h", "/opt/*/include/ceres/ceres.h",
+                "/usr/lib/x86_64-linux-gnu/libceres*", "/usr/local/lib/libceres*", "/usr/lib/cmake/Ceres/*", "/usr/local/share/Ceres/*",
+                "/usr/local/lib/cmake/Ceres/*"):
+        hits += glob.glob(pat)
+    try:
+        ld = subprocess.run(["ldconfig", "-p"], capture_output=True, text=True, timeout=10).stdout
+        hits += [l.strip() for l in ld.splitlines() if "libceres" in l]
+    except Exception:
+        pass
+    return {"ceres_available": bool(hits), "found": hits[:4]}
+
+
+def time_batch(windows, device, steps, warmup, **opt):
+    """Resident batch of `windows`, `steps` timed solves (hipGraph replay): (LM iterations / s, ms per solve)."""
+    bt = capi.LBABatch(device=device)
+    for w in windows:
+        bt.add(w)
+    bt.finalize(use_graph=1, **opt)
+    for _ in range(max(warmup, 1)):
+        bt.reset(); bt.solve()
+    bt.iterations(clear=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bt.reset(); bt.solve()
+    its = bt.iterations()
+    dt = time.perf_counter() - t0
+    bt.close()
+    return its / dt, 1e3 * dt / steps
+
+
+def single_window_latency(lines, device):
+    """The reference's call protocol (slam.cpp:924-944: one window per keyframe, each built from the result of the one
+    before): ms per 10-iteration solve of ONE window resident in HBM (hipGraph replay) and through slslam_lba_solve
+    (host buffers: pack + upload + solve + download)."""
+    w = synth.make_window(5, num_lines=lines)
+    _, resident = time_batch([w], device, 30, 3)
+    capi.lba_solve(w)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        _, s, _ = capi.lba_solve(w)
+    host = 1e3 * (time.perf_counter() - t0) / 10
+    return {"lines": lines, "observations": len(w["camera_index"]), "resident_ms_per_solve": resident, "host_buffer_ms_per_solve": host,
+            "lm_iterations": s["num_successful_steps"] + s["num_unsuccessful_steps"]}
+
+
+def pose_graph_block():
+    """BASELINE configs[4]: 260-pose graph with 8 loop closures (the myung-dong scale), 10 iterations, on one GPU."""
+    from oracle import pyoracle          # cpu_baseline leg only
+    g = synth.make_pose_graph(7, num_poses=260, num_loops=8)
+    out = {"poses": 260, "edges": len(g["pose_index_1"]), "loop_closures": 8}
+    res = {}
+    for name, kw in (("structured", {}), ("dense_fp64", dict(po_dense_factor=1)), ("dense_fp32", dict(po_factor_fp32=1))):
+        capi.po_solve(g, **kw)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            x, s, tm = capi.po_solve_timed(g, **kw)
+        res[name] = x
+        d = {"ms_per_solve_host_clock": 1e3 * (time.perf_counter() - t0) / 3, "device_ms": tm["total_ms"],
+             "factorisation_ms_per_iteration": tm["factor_ms"],
+             "unknowns": tm["unknowns"], "steps": [s["num_successful_steps"], s["num_unsuccessful_steps"]], "final_cost": s["final_cost"]}
+        if name != "structured":
+            flops = tm["unknowns"] ** 3 / 3.0
+            peak = FP64_VECTOR_PEAK_TFLOPS if name == "dense_fp64" else 157.3
+            tf = flops / (d["factorisation_ms_per_iteration"] * 1e-3) / 1e12
+            d["mfma"] = {"algorithmic_flops": flops, "achieved_tflops": tf, "peak_tflops": peak, "utilisation": tf / peak}
+        else:
+            d["junction_unknowns"] = tm["junction_unknowns"]
+        out[name] = d
+    dx = (res["dense_fp32"] - res["dense_fp64"]).reshape(-1, 6)
+    out["fp32_vs_fp64"] = {"max_rotation_diff_rad": float(np.abs(dx[:, :3]).max()), "max_translation_diff_m": float(np.abs(dx[:, 3:]).max())}
+    out["structured_vs_dense_max_diff"] = float(np.abs(res["structured"] - res["dense_fp64"]).max())
+    t0 = time.perf_counter()
+    xo, so, _ = pyoracle.po_solve(g)
+    out["cpu_oracle_ms"] = 1e3 * (time.perf_counter() - t0)
+    out["max_diff_vs_oracle"] = float(np.abs(res["structured"] - xo).max())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +213,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="waves cooperating on one window (0 = library default)")
     ap.add_argument("--elim", type=int, default=0,
                     help="lba_elimination: 0 auto, 1 LDS-atomic sweep, 2 / 3 matrix-core sweep with 1 / 2 waves per chunk")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the 500-line, latency and pose-graph blocks")
     ap.add_argument("--streams", type=int, default=1,
                     help="the rank's windows are split into this many batches on separate HIP streams, so that the "
                          "latency-bound kernels of one batch (reduced solve, LM update) overlap the sweeps of the other")
@@ -270,17 +374,42 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "k_linearise_schur", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": ms / n, "launches": n,
+                               # what actually bounds the kernel: fp64 issue at two waves per SIMD
+                               # (256 VGPRs) - a v_fma_f64 stream reaches 48.5 TFLOP/s there, not the 78.6 of the spec -
+                               # together with the LDS fp64 atomics of the per-wave partial system
+                               "binding": "fp64 VALU issue at 2 waves/SIMD (measured ceiling %.1f TFLOP/s) + LDS ds_add_f64" % FP64_MEASURED_CEILING_TFLOPS[2],
                                # secondary view: the kernel's arithmetic intensity (~28 flop / algorithmic byte) is above the
                                # fp64 ridge (78.6 TF / 8 TB/s ~ 10 flop / B), so the vector-fp64 roofline is the nearer one
                                "fp64_vector": {"algorithmic_flops_per_launch": flops_launch, "achieved": tflops,
                                                "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS}}
+            out["roofline"]["fp64_vector"]["frac_of_measured_ceiling_2_waves_per_simd"] = tflops / FP64_MEASURED_CEILING_TFLOPS[2]
             out["kernel_ms_per_step"] = {k: v[0] / max(args.steps, 1) for k, v in kt.items() if v[1] > 0}
+            bms, bn = kt["backsub"]
+            if bn > 0:
+                bb = algorithmic_bytes_backsub(counts) / ns
+                ach = bb / (bms / bn * 1e-3) / 1e9
+                out["roofline_backsub"] = {"bound": "hbm", "kernel": "k_backsub", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bb,
+                                           "avg_launch_ms": bms / bn, "launches": bn,
+                                           "binding": "fp64 VALU issue at 2 waves/SIMD"}
+            sms, sn = kt["reduced_solve"]
+            if sn > 0:
+                nm = sum(reduced_solve_mfma_count(6 * c[1]) for c in counts) / ns
+                tf = nm * 2048.0 / (sms / sn * 1e-3) / 1e12
+                out["reduced_solve_mfma"] = {"instruction": "v_mfma_f64_16x16x4_f64", "mfma_per_launch": nm, "avg_launch_ms": sms / sn,
+                                             "achieved_tflops": tf, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "utilisation": tf / FP64_VECTOR_PEAK_TFLOPS,
+                                             "note": "60x60 systems: latency-bound (one workgroup per window), 3 % of the step"}
         if world == 1 and not args.no_cpu_baseline:
             v, sample, outs = cpu_baseline(windows)
             out["cpu_baseline"] = {"value": v, "unit": "LM iterations/s", "cores": 1, "kind": "port", "sample": sample,
                                    "host_cores_available": os.cpu_count()}
             va, ca, sa = cpu_baseline_all_cores(windows)
-            out["cpu_baseline_all_cores"] = {"value": va, "unit": "LM iterations/s", "cores": ca, "kind": "port", "sample": sa}
+            out["cpu_baseline_all_cores"] = {"value": va, "unit": "LM iterations/s", "cores": ca, "kind": "port", "sample": sa,
+                                             # threads the process may run on (sched_getaffinity) vs how well they scale:
+                                             # a shared host delivers far fewer than it advertises
+                                             "parallel_efficiency": va / (ca * v) if v > 0 and ca > 0 else None,
+                                             "equivalent_full_cores": va / v if v > 0 else None}
+            out["cpu_baseline"].update(ceres_probe())
             # trajectory error of the GPU solve against the oracle solve of the same windows
             err = []
             for i, xo in enumerate(outs):
@@ -290,6 +419,28 @@ def main():
             err = np.concatenate(err)
             out["traj_error_vs_oracle"] = {"rms_m": float(np.sqrt((err ** 2).mean())), "mean_m": float(err.mean()),
                                            "keyframes": int(err.size)}
+        if world == 1 and not args.no_extra_configs:
+            for bt in batches:           # release HBM before the extra measurements
+                bt.close()
+            batches = []
+            # BASELINE configs[1]: 10-keyframe / 500-line window
+            nb = min(B, 512)
+            w500 = [synth.make_window(2_000_000 + i, num_lines=500) for i in range(nb)]
+            v500, ms500 = time_batch(w500, local_rank, 5, 2)
+            c2 = {"workload": "synthetic 10 free + 10 fixed keyframe window, 500 lines, ~%d observations" % int(np.mean([len(w["camera_index"]) for w in w500])),
+                  "batched": {"windows": nb, "value": v500, "unit": "LM iterations/s", "ms_per_step": ms500},
+                  "single_window": single_window_latency(500, local_rank)}
+            if not args.no_cpu_baseline:
+                from oracle import pyoracle          # cpu_baseline leg only
+                t0 = time.perf_counter()
+                _, so, _ = pyoracle.lba_solve(w500[0], linear_solver=1)
+                dt = time.perf_counter() - t0
+                c2["cpu_oracle_single_solve_ms"] = 1e3 * dt
+                c2["cpu_oracle_lm_iterations_per_s"] = (so["num_successful_steps"] + so["num_unsuccessful_steps"]) / dt
+            out["config2_window_500_lines"] = c2
+            out["latency_single_window"] = single_window_latency(args.lines, local_rank)
+            if not args.no_cpu_baseline:
+                out["config5_pose_graph"] = pose_graph_block()
         print(json.dumps(out))
     for bt in batches:
         bt.close()

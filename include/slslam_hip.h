@@ -273,6 +273,18 @@ int slslam_ransac_motion_batch(int num_frames, const slslam_ransac_trials* frame
                                int* best_score_io, int* trial_cnt, double* best_pose,
                                unsigned long long* const* best_inlier_bits);
 
+/* ------------------------------------------------------------------ diagnostics (benches, timing experiments)
+ * Not part of the reference's surface: the reference times its back-end with StopWatch accumulators around whole calls
+ * (src/stopwatch.h:42-157, proc_2 / proc_3 at src/slam.cpp:1384-1386, :1237,1312); these give the device-side split. */
+/* Per-thread switch: slslam_po_solve brackets its device work and every factorisation (+ triangular solve) with HIP events. */
+int slslam_po_set_profiling(int enable);
+/* Timing of the calling thread's last profiled slslam_po_solve: device time of the whole solve, of its slowest factorisation
+ * (iterations enqueued after the solve has converged are no-ops), how many factorisations were enqueued, unknowns of the reduced program and of the junction block (0 with the dense factorisations). */
+int slslam_po_last_timing(double* total_ms, double* factor_ms, int* factor_calls, int* unknowns, int* junction_unknowns);
+/* Timing experiments of the matrix-core elimination sweep / the reduced solve (environment SLSLAM_DEBUG_ABLATE, bits 8 / 9):
+ * wave-clock cycles per phase summed over the batch since finalize; out[16].  SLSLAM_ERR_STATE unless the variable was set. */
+int slslam_debug_phase_cycles(slslam_lba_batch* batch, double* out);
+
 /* ------------------------------------------------------------------ misc */
 int         slslam_device_count(void);          /* 0 when no HIP device is usable */
 /* The one-shot entry points (slslam_lba_solve, slslam_po_solve) keep the device block of their last call per host thread

@@ -83,7 +83,7 @@ EXPORTS = [
     "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
-    "slslam_po_solve", "slslam_po_structure", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_release_cached_memory", "slslam_version", "slslam_status_string",
+    "slslam_po_solve", "slslam_po_structure", "slslam_po_set_profiling", "slslam_po_last_timing", "slslam_debug_phase_cycles", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_release_cached_memory", "slslam_version", "slslam_status_string",
 ]
 
 _lib = None
@@ -128,6 +128,9 @@ def lib():
                                        C.POINTER(C.c_ulonglong)]
     L.slslam_ransac_motion_batch.argtypes = [C.c_int, C.POINTER(RansacTrials), C.POINTER(dp), C.c_double, C.c_double, C.c_double,
                                              C.c_int, ip, ip, dp, C.POINTER(C.POINTER(C.c_ulonglong))]
+    L.slslam_po_set_profiling.argtypes = [C.c_int]
+    L.slslam_po_last_timing.argtypes = [dp, dp, ip, ip, ip]
+    L.slslam_debug_phase_cycles.argtypes = [vp, dp]
     L.slslam_device_count.restype = C.c_int
     L.slslam_release_cached_memory.restype = None
     L.slslam_version.restype = C.c_char_p
@@ -317,6 +320,20 @@ def po_solve(g, params=None, trace_cap=64, **opt):
     n = C.c_int(0)
     _check(lib().slslam_po_solve(C.byref(cg), C.byref(o), C.byref(s), tr, trace_cap, C.byref(n)), "slslam_po_solve")
     return x, _summary_dict(s), _trace_list(tr, min(n.value, trace_cap))
+
+
+def po_solve_timed(g, **opt):
+    """po_solve with the device-side split: returns (x, summary, dict(total_ms, factor_ms = the slowest factorisation,
+    factor_calls, unknowns, junction_unknowns))."""
+    lib().slslam_po_set_profiling(1)
+    try:
+        x, s, _ = po_solve(g, **opt)
+        tot, fac = C.c_double(0), C.c_double(0)
+        nc, nu, nj = C.c_int(0), C.c_int(0), C.c_int(0)
+        lib().slslam_po_last_timing(C.byref(tot), C.byref(fac), C.byref(nc), C.byref(nu), C.byref(nj))
+    finally:
+        lib().slslam_po_set_profiling(0)
+    return x, s, dict(total_ms=tot.value, factor_ms=fac.value, factor_calls=nc.value, unknowns=nu.value, junction_unknowns=nj.value)
 
 
 def ransac_score(poses, observations, lines, baseline=0.12, error_thr=5.0 / 406.05):

@@ -122,6 +122,23 @@ void order_chains_first(int N, int E, const int* p1, const int* p2, const std::v
 
 }  // namespace
 
+namespace {
+// Optional timing of slslam_po_solve (slslam_po_set_profiling): hipEvents on the solve's stream around the whole device
+// part and around every factorisation + triangular solve; read back with slslam_po_last_timing.
+struct PoTiming { bool enabled = false; double total_ms = 0, factor_ms = 0, factor_max_ms = 0; int factor_calls = 0, unknowns = 0, junction_unknowns = 0; };
+thread_local PoTiming g_po_timing;
+}  // namespace
+
+extern "C" int slslam_po_set_profiling(int enable) { g_po_timing.enabled = enable != 0; return SLSLAM_OK; }
+extern "C" int slslam_po_last_timing(double* total_ms, double* factor_ms, int* factor_calls, int* unknowns, int* junction_unknowns) {
+  if (total_ms) *total_ms = g_po_timing.total_ms;
+  if (factor_ms) *factor_ms = g_po_timing.factor_max_ms;
+  if (factor_calls) *factor_calls = g_po_timing.factor_calls;
+  if (unknowns) *unknowns = g_po_timing.unknowns;
+  if (junction_unknowns) *junction_unknowns = g_po_timing.junction_unknowns;
+  return SLSLAM_OK;
+}
+
 extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_options* opt_in,
                                slslam_summary* summary, slslam_iteration* trace, int trace_cap, int* trace_len) {
   if (!g) return SLSLAM_ERR_INVALID_ARGUMENT;
@@ -171,6 +188,9 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   pol.max_invalid = opt.max_num_consecutive_invalid_steps; pol.jacobi_scaling = opt.jacobi_scaling; pol.pad = 0;
 
   int rc = SLSLAM_OK;
+  const bool timing = g_po_timing.enabled;
+  std::vector<hipEvent_t> tev;            // [0] start, [1] end, then (start, stop) per factorisation
+  auto stamp = [&]() { if (timing) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, 0); tev.push_back(e); } } };
   PoPtrs p, pj;
   std::memset(&p, 0, sizeof(p));
   PoChain* d_chains = nullptr;
@@ -232,6 +252,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     PO_TRY(hipMemcpy(d_chains, chains.data(), sizeof(PoChain) * chains.size(), hipMemcpyHostToDevice));
   }
 
+  stamp(); stamp();                       // [1] is re-recorded at the end
   // ---- initial evaluation: cost, gradient, column norms -> Jacobi scale
   PO_TRY(hipMemsetAsync(p.H, 0, hbytes, 0));
   PO_TRY(hipMemsetAsync(p.g, 0, sizeof(double) * ones.size(), 0));
@@ -250,6 +271,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 0);
     hipLaunchKernelGGL(k_po_prepare, dim3(1), dim3(256), 0, 0, p, pol, 0);
     if (f32) hipLaunchKernelGGL(k_po_to_f32, dim3(256), dim3(256), 0, 0, p, d_Hf);
+    stamp();
     if (structured) {
       // chains eliminated concurrently, then the dense MFMA Cholesky of the junction block only
       if (!chains.empty()) hipLaunchKernelGGL(k_po_chain_eliminate, dim3((unsigned)chains.size()), dim3(64), 0, 0, p, (const PoChain*)d_chains);
@@ -287,12 +309,24 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     if (structured) { /* solved above */ }
     else if (f32) hipLaunchKernelGGL(k_po_trisolve<float>, dim3(1), dim3(256), 0, 0, p, (const float*)d_Hf, (const float*)d_linvf);
     else hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(256), 0, 0, p, (const double*)p.H, (const double*)d_linv);
+    stamp();
     hipLaunchKernelGGL(k_po_candidate, dim3(1), dim3(256), 0, 0, p);
     hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 1);
     hipLaunchKernelGGL(k_po_update, dim3(1), dim3(64), 0, 0, p, pol);
   }
   PO_TRY(hipGetLastError());
+  if (timing && tev.size() >= 2) (void)hipEventRecord(tev[1], 0);
   PO_TRY(hipDeviceSynchronize());
+  if (timing) {
+    PoTiming& T = g_po_timing;
+    T.total_ms = 0; T.factor_ms = 0; T.factor_max_ms = 0; T.factor_calls = 0; T.unknowns = n; T.junction_unknowns = nj;
+    float ms = 0.f;
+    if (tev.size() >= 2 && hipEventElapsedTime(&ms, tev[0], tev[1]) == hipSuccess) T.total_ms = ms;
+    for (size_t i = 2; i + 1 < tev.size(); i += 2)
+      if (hipEventElapsedTime(&ms, tev[i], tev[i + 1]) == hipSuccess) { T.factor_ms += ms; T.factor_calls++; if (ms > T.factor_max_ms) T.factor_max_ms = ms; }
+    for (hipEvent_t e : tev) (void)hipEventDestroy(e);
+    tev.clear();
+  }
   PO_TRY(hipMemcpy(&hst, p.st, sizeof(hst), hipMemcpyDeviceToHost));
   PO_TRY(hipMemcpy(htrace.data(), p.trace, sizeof(IterRec) * kMaxTrace, hipMemcpyDeviceToHost));
   PO_TRY(hipMemcpy(x2.data(), p.x, sizeof(double) * 12 * N, hipMemcpyDeviceToHost));
