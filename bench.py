@@ -28,7 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from slslam_amd import capi, synth  # noqa: E402
-from slslam_amd.dist import allreduce_summary  # noqa: E402
+from slslam_amd.dist import allgather_parameters, allreduce_summary, export_parameters_device, shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector (and matrix) peak
@@ -213,6 +213,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="waves cooperating on one window (0 = library default)")
     ap.add_argument("--elim", type=int, default=0,
                     help="lba_elimination: 0 auto, 1 LDS-atomic sweep, 2 / 3 matrix-core sweep with 1 / 2 waves per chunk")
+    ap.add_argument("--gather-results", action="store_true",
+                    help="also all-gather the solved parameters of every rank inside the timed region (one RCCL all-gather per step)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the 500-line, latency and pose-graph blocks")
     ap.add_argument("--streams", type=int, default=1,
                     help="the rank's windows are split into this many batches on separate HIP streams, so that the "
@@ -243,8 +245,11 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- synthetic inputs of the named shape, distinct per rank, resident in HBM before timing
+    # BASELINE configs[3]: a stream of world x B independent windows, window i = synth.make_window(i), split contiguously
+    # over the ranks (dist.shard_range): every rank holds B windows (weak scaling), no data-path collective
     B = args.windows
-    windows = [synth.make_window(1_000_000 * rank + i, num_lines=args.lines) for i in range(B)]
+    lo, hi = shard_range(B * world, rank, world)
+    windows = [synth.make_window(i, num_lines=args.lines) for i in range(lo, hi)]
     ns = max(1, min(args.streams, B))
     bstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
     batches, owner = [], []
@@ -278,8 +283,16 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
+    gathered_bytes = 0
     for _ in range(args.steps):
         run_step()
+        if args.gather_results:          # results needed on every rank: device export + ONE all-gather per step
+            for bt, st in zip(batches, bstreams):
+                with torch.cuda.stream(st):
+                    local = export_parameters_device(bt, dev)
+                st.synchronize()
+                parts = allgather_parameters(local)
+                gathered_bytes = sum(int(x.numel()) * 8 for x in parts)
     iters_local = sum(bt.iterations(st.cuda_stream) for bt, st in zip(batches, bstreams))   # synchronises the streams
     iters_total, _, _ = allreduce_summary(iters_local, 0.0, 0.0, device=dev)
     barrier()
@@ -346,7 +359,9 @@ def main():
             "config": {"workload": "synthetic 10 free + 10 fixed keyframe window, %d lines, ~%d observations; "
                                    "full LM solve (Huber, <=10 iterations, Schur + back-substitution)" % (
                                        args.lines, int(np.mean([c[3] for c in counts]))),
-                       "windows_per_gpu": B, "lines": args.lines, "parallelism": "windows sharded over %d GPU(s)" % world,
+                       "windows_per_gpu": B, "total_windows": B * world, "lines": args.lines,
+                       "parallelism": "windows [0, %d) split contiguously over %d GPU(s) (shard_range), no data-path collective%s" % (
+                           B * world, world, "; one all-gather of the results per step (%d MB)" % (gathered_bytes >> 20) if args.gather_results else ""),
                        "launch": "hipGraph replay" if args.graph else "eager + hipEvents", "hip_streams": ns},
             "lm_iterations": iters_total,
             "sum_initial_cost_rank0": init_cost, "sum_final_cost_rank0": final_cost,

@@ -51,3 +51,42 @@ def allgather_parameters(local, local_len=None):
     out = torch.empty(world * width, dtype=torch.float64, device=local.device)
     dist.all_gather_into_tensor(out, buf)
     return [out[r * width:r * width + lens[r]] for r in range(world)]
+
+
+def export_parameters_device(batch, device):
+    """The solved parameter vectors of a finalized LBABatch as ONE flat float64 tensor on `device`, written by the library
+    straight into the tensor's memory (slslam_lba_batch_export_device): no host round trip before a collective."""
+    n = batch.total_parameters()
+    out = torch.empty(max(n, 1), dtype=torch.float64, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream if out.is_cuda else None
+    batch.export_device(out.data_ptr(), stream)
+    return out[:n]
+
+
+def solve_shard(make_window, total, rank, world, device_index, steps=1, gather=True, **opt):
+    """Config 4 of BASELINE.json in one call: the windows [0, total) are split contiguously over the ranks
+    (`shard_range`), rank `rank` builds and solves its shard on GPU `device_index` (`make_window(i)` returns window i),
+    then ONE all-reduce of the run summary and - if `gather` - ONE all-gather of the solved parameters.
+    Returns dict(range, iterations (all ranks), initial_cost, final_cost, gathered (list of per-rank tensors or None),
+    batch (the caller closes it))."""
+    from . import capi
+    lo, hi = shard_range(total, rank, world)
+    dev = torch.device("cuda", device_index)
+    bt = capi.LBABatch(device=device_index)
+    for i in range(lo, hi):
+        bt.add(make_window(i))
+    bt.finalize(**opt)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(steps):
+        bt.reset(stream)
+        bt.solve(stream)
+    its = bt.iterations(stream)
+    bt.download(stream)
+    sums = [bt.summary(i) for i in range(hi - lo)]
+    tot = allreduce_summary(its, sum(s["initial_cost"] for s in sums), sum(s["final_cost"] for s in sums), device=dev)
+    gathered = None
+    if gather:
+        local = export_parameters_device(bt, dev)
+        torch.cuda.current_stream(dev).synchronize()
+        gathered = allgather_parameters(local)
+    return {"range": (lo, hi), "iterations": tot[0], "initial_cost": tot[1], "final_cost": tot[2], "gathered": gathered, "batch": bt}

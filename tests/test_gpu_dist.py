@@ -1,0 +1,96 @@
+"""GPU tests of the multi-GPU fan-out (BASELINE configs[3]: independent windows sharded over the GPUs of a node, RCCL).
+Only one GPU is visible to the test box, so: (1) the whole per-rank path - batch -> device export -> all-gather /
+all-reduce through torch.distributed's "nccl" backend (RCCL) - runs at world size 1 on the real device; (2) two ranks
+sharing the one GPU run the same script in subprocesses (RCCL refuses two ranks on one device, so that leg uses gloo for the
+rendezvous and the collectives, with the solves on the GPU)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIZES = [120, 40, 200, 75, 150, 60]
+
+WORKER = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from slslam_amd import synth
+from slslam_amd.dist import solve_shard
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+backend = os.environ["TEST_BACKEND"]
+if backend == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+sizes = %(sizes)r
+mk = lambda i: synth.make_window(500 + i, num_lines=sizes[i], num_kf=12, num_free=6)
+r = solve_shard(mk, len(sizes), rank, world, 0, gather=(backend == "nccl" or world == 1))
+lo, hi = r["range"]
+local = np.concatenate([r["batch"].parameters(i - lo) for i in range(lo, hi)]) if hi > lo else np.zeros(0)
+out = {"rank": rank, "range": [lo, hi], "iterations": r["iterations"], "initial_cost": r["initial_cost"], "final_cost": r["final_cost"],
+       "local": local.tolist()}
+if r["gathered"] is not None:
+    out["gathered"] = [g.cpu().numpy().tolist() for g in r["gathered"]]
+r["batch"].close()
+print("RESULT " + json.dumps(out), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _run(world, backend):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT, "sizes": SIZES}], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+        import json
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][0][7:]))
+    return sorted(outs, key=lambda o: o["rank"])
+
+
+def test_world_size_one_through_rccl(hip):
+    """batch -> slslam_lba_batch_export_device -> all_gather_into_tensor / all_reduce on the "nccl" backend (= RCCL),
+    one rank on the real device: what every rank of the 8-GPU job executes."""
+    (o,) = _run(1, "nccl")
+    assert o["range"] == [0, len(SIZES)]
+    assert len(o["gathered"]) == 1
+    assert np.array_equal(np.array(o["gathered"][0]), np.array(o["local"]))      # device export == host download
+    # same numbers as a plain one-process batch
+    from slslam_amd import synth
+    b = hip.LBABatch()
+    for i, l in enumerate(SIZES):
+        b.add(synth.make_window(500 + i, num_lines=l, num_kf=12, num_free=6))
+    b.finalize(); b.solve(); b.download()
+    ref = np.concatenate([b.parameters(i) for i in range(len(SIZES))])
+    its = sum(b.summary(i)["num_successful_steps"] + b.summary(i)["num_unsuccessful_steps"] for i in range(len(SIZES)))
+    assert np.array_equal(ref, np.array(o["local"])) and o["iterations"] == its
+    b.close()
+
+
+def test_two_ranks_on_one_gpu_match_one_rank(hip):
+    """Two ranks, contiguous shards (`shard_range`), both solving on the one visible GPU: the concatenated results are
+    bitwise those of the one-rank run (windows are independent; a window's chunking does not depend on its batch here
+    because every batch is small), the all-reduced summary is the same."""
+    (one,) = _run(1, "gloo")
+    two = _run(2, "gloo")
+    assert [o["range"] for o in two] == [[0, 3], [3, 6]]
+    both = np.concatenate([np.array(o["local"]) for o in two])
+    assert np.abs(both - np.array(one["local"])).max() < 1e-9
+    for o in two:
+        assert o["iterations"] == one["iterations"]
+        assert abs(o["final_cost"] - one["final_cost"]) <= 1e-12 * one["final_cost"]
