@@ -524,7 +524,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
   Launcher L{ b, s, prof };
   const dim3 blk64(64), blk256(256);
   const dim3 g_chunk((unsigned)std::max(1, b->nchunk)), g_win((unsigned)B), g_line((unsigned)((b->nline + 255) / 256)),
-      g_upd((unsigned)B);
+      g_upd((unsigned)((B + 63) / 64));
   int rc;
 #define LAUNCH(fam, ...)                                   \
   do {                                                     \
@@ -573,7 +573,8 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 1));
       if (b->nchunk > 0) LAUNCH(FAM_COST, hipLaunchKernelGGL(k_candidate_cost, g_chunk, blk64, b->lds_cost, s, p, pol));
     }
-    LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol));
+    if (b->slab_sum_stride) LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update_wave, g_win, blk64, 0, s, p, pol));     // many chunks per window
+    else LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol));
   }
 #undef LAUNCH
   HIP_TRY(hipGetLastError());

@@ -736,7 +736,8 @@ __global__ __launch_bounds__(256) void k_slab_reduce(BatchPtrs p) {
   p.slab_sum[(long long)w * p.slab_sum_stride + q] = s;
 }
 
-__global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) {
+// (four workgroups per CU - the LDS limit - need <= 128 registers: the whole 1024-window batch is resident in one round)
+__global__ __launch_bounds__(256, 4) void k_reduced_solve(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = blockIdx.x;
@@ -897,11 +898,27 @@ __global__ __launch_bounds__(256) void k_reduced_solve(BatchPtrs p, Policy pol) 
       }
     }
   } else {
-  // eight entries of this thread at a time, four chunk partials each: 32 independent loads in flight (a single window is
-  // spread over ~50 chunks and this sum is on the latency path of every iteration); per entry the partials are still
-  // added in chunk order, so the result does not depend on the grouping
+  // eight entries of this thread at a time: the loads of an entry's partials (up to 8 chunks per round) of all eight are
+  // in flight together; per entry the partials are added in chunk order, so the result does not depend on the grouping
   for (int q0 = tid; q0 < nsys; q0 += 8 * 256) {
     double acc8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (nchunks <= 8) {
+#pragma unroll
+      for (int e0 = 0; e0 < 8; e0 += 2) {            // two entries x eight chunks in flight (the batched case: ~6 chunks)
+        double v[2][8];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int q = q0 + 256 * (e0 + e);
+            v[e][u] = (q < nsys && u < nchunks) ? slab_base[slab0 + (long long)u * sstride + q] : 0.0;
+          }
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc8[e0 + e] += v[e][u];
+      }
+    } else
     for (int k0 = 0; k0 < nchunks; k0 += 4) {
       double v[8][4];
 #pragma unroll
@@ -1689,15 +1706,14 @@ __device__ __forceinline__ void lm_step(BatchPtrs& p, const Policy& pol, int w, 
   atomicAdd(p.active_counter, 1u);    // still running: lets the host stop enqueueing long solves early
 }
 
-// One wave per window: the lanes fetch the window's chunk partials together (a single window is spread over ~50 chunks
-// and this kernel is on the latency path of every iteration), fixed-shape tree sum, lane 0 does the bookkeeping.
-__global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol) {
+// Small batches (a window cut into ~50 chunks, this kernel on the latency path of every iteration): one wave per window,
+// the lanes fetch the window's chunk partials together, fixed-shape tree sum, lane 0 does the bookkeeping.
+__global__ __launch_bounds__(64) void k_lm_update_wave(BatchPtrs p, Policy pol) {
   const int w = blockIdx.x, lane = threadIdx.x;
   if (w >= p.nwin) return;
   const WinDesc wd = p.wins[w];
   LMState* st = p.state + w;
   if (st->status != kRunning) return;
-  // ---- one LM iteration: totals over the window's chunks, then the bookkeeping
   double new_cost = 0.0, model = 0.0, dn2 = 0.0, xn2 = 0.0;
   for (int c = lane; c < wd.nchunks; c += 64) {
     new_cost += p.cost_part[wd.chunk_off + c];
@@ -1706,6 +1722,21 @@ __global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol) {
   }
   new_cost = wave_sum(new_cost); model = wave_sum(model); dn2 = wave_sum(dn2); xn2 = wave_sum(xn2);
   if (lane == 0) lm_step(p, pol, w, st, new_cost, model + st->cam_model, dn2 + st->cam_dn2, xn2 + st->cam_xn2);
+}
+// Large batches (a handful of chunks per window): one lane per window.
+__global__ __launch_bounds__(64) void k_lm_update(BatchPtrs p, Policy pol) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= p.nwin) return;
+  const WinDesc wd = p.wins[w];
+  LMState* st = p.state + w;
+  if (st->status != kRunning) return;
+  double new_cost = 0.0, model = st->cam_model, dn2 = st->cam_dn2, xn2 = st->cam_xn2;
+  for (int c = 0; c < wd.nchunks; ++c) {
+    new_cost += p.cost_part[wd.chunk_off + c];
+    const double* bp = p.bs_part + (long long)(wd.chunk_off + c) * kBsStride;
+    model += bp[kBsModel]; dn2 += bp[kBsDn2]; xn2 += bp[kBsXn2];
+  }
+  lm_step(p, pol, w, st, new_cost, model, dn2, xn2);
 }
 
 // ------------------------------------------------------------------------------------------

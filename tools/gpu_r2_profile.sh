@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-2 evidence run: GPU tests, the default bench line, rocprofv3 kernel trace of the same command, HBM traffic counters
+# of the two sweeps (separate --pmc passes, per MI355X_MICROARCH.md), summaries copied to profiles/
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+TAG=${1:-round2_v1}
+(timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -6) > gpurun_out/${TAG}_gputests.log
+timeout 1500 python bench.py --steps 10 --warmup 2 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+BENCH="python bench.py --steps 6 --warmup 0 --no-cpu-baseline --no-overlap-run --no-extra-configs"
+timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_kt -o t -- $BENCH > gpurun_out/${TAG}_kt.log 2>&1
+python tools/rocpd_summary.py $(ls gpurun_out/${TAG}_kt/*.db | head -1) > gpurun_out/${TAG}_kernel_trace.txt 2>&1
+rm -rf gpurun_out/${TAG}_kt
+: > gpurun_out/${TAG}_pmc.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $C -d gpurun_out/${TAG}_pmc_$C -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap-run --no-extra-configs > gpurun_out/${TAG}_pmc_$C.log 2>&1
+  python tools/rocpd_pmc.py $(ls gpurun_out/${TAG}_pmc_$C/*.db | head -1) >> gpurun_out/${TAG}_pmc.txt 2>&1
+  rm -rf gpurun_out/${TAG}_pmc_$C
+done
+tail -3 gpurun_out/${TAG}_gputests.log; head -12 gpurun_out/${TAG}_kernel_trace.txt; grep -A1 "k_linearise_schur\|k_backsub" gpurun_out/${TAG}_pmc.txt; cut -c1-400 gpurun_out/${TAG}_bench.json

@@ -1,0 +1,232 @@
+"""Plausibility study against the only numbers the reference publishes for this path:
+matlab_script/result_comp_ancdir_orthonorm/ba_result_orthonorm_err{E}_basize{B}_maxnumiter10.txt - average LM iterations per
+frame and average initial / final LBA cost of a simulated ~400-keyframe run around the 74-segment "house" model
+(matlab_script/house.m:33-133), for noise E in {0.2 .. 1.0} px and window sizes B in {5, 10, 20, 40}.
+
+The reference's simulator (observation generator, ground-truth file) is NOT shipped, so this is a re-creation, not a replay:
+  * scene: the 74 segments of the house model, restated below from its dimensions (4.5 x 4.5 x 3.5 m, roof from 65 % of
+    the height, door / window rectangles, wall and roof subdivisions, wall diagonals);
+  * trajectory: 400 keyframes on the circle of radius 5.1 m around the house with the +-0.5 m, two-period height wave of the
+    shipped estimated trajectories (trajectory_orthonorm_err0.2_basize40_maxnumiter10.txt: x in [0, 10.2], z in [-5.05, 5.13],
+    y in [-0.5, 0.5], yaw 0 .. 2 pi), the stereo rig (f = 406.05, 640 x 480, baseline 0.12: src/parameter.h:43-52) looking at
+    the house;
+  * pipeline per keyframe, mirroring SLAM's data flow (src/slam.cpp:223-319, 730-761, 1370-1427): pose prediction, motion-only
+    BA against the mapped lines (LBAProblem, one free camera, constant lines), new landmarks by stereo triangulation
+    (initialize_lm), sliding-window LBA over the 2 W newest keyframes (W free + W fixed) with max 10 iterations, write-back.
+What can be asserted is the SCALING the 40 files show, not their digits: cost proportional to W, to sigma^2 below the Huber
+knee, initial cost within a few % of the final one, 2-6 LM iterations per frame falling with W (tests/test_house_study.py).
+
+    python tools/house_study.py [--backend oracle|hip] [--frames 400] [--sigmas 0.2,0.6,1.0] [--windows 5,10,20,40]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from slslam_amd import synth  # noqa: E402
+
+# the reference's published aggregates, orthonormal parametrisation, max_num_iter = 10:
+# (sigma px, W) -> (avg LM iterations per frame, avg initial cost, avg final cost)
+REFERENCE = {(0.2, 5): (2.33582, 5.33873e-4, 4.97805e-4), (0.2, 10): (2.21393, 1.04857e-3, 1.02656e-3),
+             (0.2, 20): (1.4602, 2.06725e-3, 2.05101e-3), (0.2, 40): (1.13682, 3.9544e-3, 3.94087e-3),
+             (0.6, 10): (4.27114, 8.47761e-3, 8.38284e-3),
+             (1.0, 5): (7.49254, 9.09799e-3, 8.79131e-3), (1.0, 10): (5.34826, 1.8233e-2, 1.80694e-2),
+             (1.0, 20): (4.05224, 3.59655e-2, 3.5877e-2), (1.0, 40): (3.24129, 6.86576e-2, 6.86017e-2)}
+
+
+def house_segments(l=4.5, w=4.5, h=3.5):
+    """The 74 segments of the house model as (74, 2, 3) endpoints, house frame: x along the length, y along the width, z up."""
+    r, q, p = 0.65, 0.5, 0.25                    # roof starts at r h; door / window top at q h; window sill at p h
+    a, b, c, d = 0.2, 0.4, 0.6, 0.8             # window spans a w .. b w, door c w .. d w (on the wall x = 0)
+    S = []
+    seg = lambda A, B: S.append((np.array(A, float), np.array(B, float)))
+    rect_yz = lambda x, y0, y1, z0, z1: [seg((x, y0, z0), (x, y1, z0)), seg((x, y1, z0), (x, y1, z1)),
+                                         seg((x, y1, z1), (x, y0, z1)), seg((x, y0, z1), (x, y0, z0))]
+    for (x, y) in ((0, 0), (l, 0), (l, w), (0, w)):                                   # 1-4 wall corners
+        seg((x, y, 0), (x, y, r * h))
+    seg((0, 0, 0), (l, 0, 0)); seg((l, 0, 0), (l, w, 0)); seg((l, w, 0), (0, w, 0)); seg((0, w, 0), (0, 0, 0))   # 5-8 floor
+    for x in (0, l):                                                                   # 9-12 gable slopes
+        seg((x, 0, r * h), (x, w / 2, h)); seg((x, w / 2, h), (x, w, r * h))
+    seg((0, w / 2, h), (l, w / 2, h)); seg((0, 0, r * h), (l, 0, r * h)); seg((0, w, r * h), (l, w, r * h))      # 13-15 ridge, eaves
+    rect_yz(0, c * w, d * w, 0, q * h)                                                 # 16-19 door
+    rect_yz(0, a * w, b * w, p * h, q * h)                                             # 20-23 window
+    seg((0, 0, r * h), (0, w, r * h)); seg((l, 0, r * h), (l, w, r * h))               # 24-25 gable bases
+    seg((0, a * w, (p + q) * h / 2), (0, b * w, (p + q) * h / 2)); seg((0, (a + b) * w / 2, p * h), (0, (a + b) * w / 2, q * h))   # 26-27 window cross
+    for x in (l / 2, l / 4, 3 * l / 4):                                                # 28-30 rafters, front slope
+        seg((x, 0, r * h), (x, w / 2, h))
+    for x in (l / 2, l / 4, 3 * l / 4):                                                # 31-33 rafters, back slope
+        seg((x, w / 2, h), (x, w, r * h))
+    for k in (1, 2, 3):                                                                # 34-36 purlins, front slope
+        seg((0, w * k / 8, r * h + (h - r * h) * k / 4), (l, w * k / 8, r * h + (h - r * h) * k / 4))
+    for k, m in ((5, 3), (6, 2), (7, 1)):                                              # 37-39 purlins, back slope
+        seg((0, w * k / 8, r * h + (h - r * h) * m / 4), (l, w * k / 8, r * h + (h - r * h) * m / 4))
+    for y in (0, w):                                                                   # 40-45 wall posts, long walls
+        for k in (1, 2, 3):
+            seg((l * k / 4, y, 0), (l * k / 4, y, r * h))
+    for k in (1, 2, 3):                                                                # 46-48 wall posts, far wall
+        seg((l, w * k / 4, 0), (l, w * k / 4, r * h))
+    seg((0, c * w, 0), (0, d * w, q * h)); seg((0, d * w, 0), (0, c * w, q * h))       # 49-50 door diagonals
+    for k in range(4):                                                                 # 51-58 diagonals, wall y = 0
+        seg((l * k / 4, 0, 0), (l * (k + 1) / 4, 0, r * h)); seg((l * (k + 1) / 4, 0, 0), (l * k / 4, 0, r * h))
+    for k in range(4):                                                                 # 59-66 diagonals, wall x = l
+        seg((l, w * k / 4, 0), (l, w * (k + 1) / 4, r * h)); seg((l, w * (k + 1) / 4, 0), (l, w * k / 4, r * h))
+    for k in range(4):                                                                 # 67-74 diagonals, wall y = w
+        seg((l * k / 4, w, 0), (l * (k + 1) / 4, w, r * h)); seg((l * (k + 1) / 4, w, 0), (l * k / 4, w, r * h))
+    out = np.array([[A, B] for A, B in S])
+    assert out.shape == (74, 2, 3)
+    return out
+
+
+def wave_trajectory(n=400, radius=5.1, amp=0.5, house_centre=(2.25, 2.25, 1.75), cam_height=1.5):
+    """World -> camera poses (R, t) of n keyframes circling the house, camera x right / y down / z forward, looking at the
+    house; world frame = house frame (z up)."""
+    poses = []
+    for k in range(n):
+        th = 2 * np.pi * k / n
+        c = np.array([house_centre[0] - radius * np.cos(th), house_centre[1] - radius * np.sin(th), cam_height + amp * np.sin(2 * th)])
+        fwd = np.array(house_centre) - c
+        fwd /= np.linalg.norm(fwd)
+        right = np.cross(fwd, [0, 0, 1.0]); right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        R = np.stack([right, down, fwd])                 # rows: camera axes in the world
+        poses.append((R, -R @ c))
+    return poses
+
+
+def observe(R, t, segs, sigma_px, rng):
+    """Stereo observation [8] (normalised, as SLAM::insert_curr_obs) of every segment fully inside both images."""
+    ids, obs = [], []
+    for i, (A, B) in enumerate(segs):
+        o, ok = np.empty(8), True
+        for e, P in enumerate((A, B)):
+            ul, vl, ur, z = synth._project(R, t, P)
+            ok &= bool(z > 0.3 and 0 <= ul < synth.WIDTH and 0 <= ur < synth.WIDTH and 0 <= vl < synth.HEIGHT)
+            o[2 * e], o[2 * e + 1], o[4 + 2 * e], o[4 + 2 * e + 1] = ul, vl, ur, vl
+        if ok:
+            o = o + rng.normal(0, sigma_px, 8)
+            o[0::2] = (o[0::2] - synth.CX) / synth.FOCAL
+            o[1::2] = (o[1::2] - synth.CY) / synth.FOCAL
+            ids.append(i); obs.append(o)
+    return ids, np.array(obs).reshape(-1, 8)
+
+
+def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10):
+    """One simulated run; `solve(window_dict, max_num_iterations)` -> (parameters, summary).  Returns the averages the
+    reference prints (src/main.cpp:84-89: sums over LBA calls divided by the frame count) and the estimated positions."""
+    rng = np.random.default_rng([seed, int(round(100 * sigma_px)), W])
+    segs = house_segments()
+    truth = wave_trajectory(frames)
+    R0, t0 = truth[0]
+    to_first = lambda R, t: (R @ R0.T, t - R @ R0.T @ t0)          # express poses relative to keyframe 0 (the map's origin)
+    truth = [to_first(R, t) for R, t in truth]
+    segs0 = np.einsum("ij,nej->nei", R0, segs) + t0                # segments in the frame of keyframe 0
+    kf_pose, kf_obs, lines = [], [], {}                             # estimated (w,t)[6]; {line id: obs[8]}; world orth[4]
+    s_it = s_c0 = s_c1 = 0.0
+    per_frame = []
+    for k in range(frames):
+        ids, ob = observe(truth[k][0], truth[k][1], segs0, sigma_px, rng)
+        obs_k = dict(zip(ids, ob))
+        # ---- pose prediction: last estimate composed with the true relative motion, perturbed (stands in for RANSAC VO)
+        if k == 0:
+            pose = np.zeros(6)
+        else:
+            Rp, tp = synth.wt_to_rt(kf_pose[-1])
+            Rrel = truth[k][0] @ truth[k - 1][0].T
+            trel = truth[k][1] - Rrel @ truth[k - 1][1]
+            Rn = synth.rodrigues(rng.normal(0, np.deg2rad(0.2), 3)) @ Rrel @ Rp
+            pose = synth.rt_to_wt(Rn, Rrel @ tp + trel + rng.normal(0, 0.005, 3))
+            # ---- motion-only BA against the mapped lines (SLAM::motion_only_ba: camera 0 free, lines constant)
+            common = [i for i in ids if i in lines]
+            if len(common) >= 5:
+                m = len(common)
+                w = {"num_cameras": 1, "num_lines": m, "camera_index": np.zeros(m, np.int32), "line_index": np.arange(m, dtype=np.int32),
+                     "fixed_index": np.tile([0, 1], m).astype(np.int32), "observations": np.array([obs_k[i] for i in common]),
+                     "parameters": np.concatenate([pose, np.concatenate([lines[i] for i in common])])}
+                x, _ = solve(w, max_iter)
+                pose = x[:6]
+        kf_pose.append(pose); kf_obs.append(obs_k)
+        # ---- new landmarks: stereo triangulation in the keyframe, moved to the map frame (initialize_lm, gc_line_from_pose)
+        R, t = synth.wt_to_rt(pose)
+        for i in ids:
+            if i not in lines:
+                lm = synth._initialize_lm(obs_k[i][None])[0]
+                lines[i] = synth.av_to_orth(np.concatenate([R.T @ (lm[:3] - t), R.T @ lm[3:]])[None])[0]
+        # ---- sliding-window LBA: the 2 W newest keyframes, the W newest free (src/slam.cpp:1376-1382, 811-832)
+        if k == 0:
+            continue
+        win = list(range(max(0, k - 2 * W + 1), k + 1))
+        free = win[-W:]
+        fixed = win[:-W]
+        seen_free = {}
+        for f in free:
+            for i in kf_obs[f]:
+                seen_free[i] = seen_free.get(i, 0) + 1
+        lm_ids = sorted(i for i, c in seen_free.items() if c >= 2)                # slam.cpp:839-840
+        if not lm_ids:
+            continue
+        lpos = {i: n for n, i in enumerate(lm_ids)}
+        cams = free + fixed
+        ci, li, fi, oo = [], [], [], []
+        for i in lm_ids:
+            for cpos, f in enumerate(cams):
+                if i in kf_obs[f]:
+                    ci.append(cpos); li.append(lpos[i]); fi += [1 if cpos >= len(free) else 0, 0]; oo.append(kf_obs[f][i])
+        w = {"num_cameras": len(cams), "num_lines": len(lm_ids), "camera_index": np.array(ci, np.int32), "line_index": np.array(li, np.int32),
+             "fixed_index": np.array(fi, np.int32), "observations": np.array(oo),
+             "parameters": np.concatenate([np.concatenate([kf_pose[f] for f in cams]), np.concatenate([lines[i] for i in lm_ids])])}
+        x, s = solve(w, max_iter)
+        for cpos, f in enumerate(free):
+            kf_pose[f] = x[6 * cpos:6 * cpos + 6]
+        for i in lm_ids:
+            lines[i] = x[6 * len(cams) + 4 * lpos[i]:][:4]
+        s_it += s["num_successful_steps"] + s["num_unsuccessful_steps"]
+        s_c0 += s["initial_cost"]; s_c1 += s["final_cost"]
+        per_frame.append((s["num_successful_steps"] + s["num_unsuccessful_steps"], s["initial_cost"], s["final_cost"], s["num_unsuccessful_steps"]))
+    # positions relative to the (estimated) first keyframe, as SLAM::save_trajectory re-roots them (metric_embedding(0))
+    Re0, te0 = synth.wt_to_rt(kf_pose[0])
+    est = []
+    for pz in kf_pose:
+        Rk, tk = synth.wt_to_rt(pz)
+        c_map = -(Rk.T @ tk)                       # camera centre in map coordinates
+        est.append(Re0 @ c_map + te0)              # ... in the frame of keyframe 0
+    est = np.array(est)
+    gt = np.array([-(R.T @ t) for R, t in truth])  # truth is already relative to keyframe 0
+    err = np.linalg.norm(est - gt, axis=1)
+    half = len(per_frame) // 2
+    tail = per_frame[half:]
+    return {"sigma_px": sigma_px, "W": W, "frames": frames, "avg_iterations": s_it / frames, "avg_initial_cost": s_c0 / frames,
+            "avg_final_cost": s_c1 / frames, "mean_position_error_m": float(err.mean()),
+            "second_half": {"avg_iterations": float(np.mean([q[0] for q in tail])), "avg_initial_cost": float(np.mean([q[1] for q in tail])),
+                            "avg_final_cost": float(np.mean([q[2] for q in tail])), "rejected_step_fraction": float(np.sum([q[3] for q in tail]) / max(1, np.sum([q[0] for q in tail])))},
+            "positions": est}
+
+
+def make_solver(backend):
+    if backend == "oracle":
+        from oracle import pyoracle
+        return lambda w, it: pyoracle.lba_solve(w, linear_solver=1, max_num_iterations=it)[:2]
+    from slslam_amd import capi
+    return lambda w, it: capi.lba_solve(w, max_num_iterations=it)[:2]
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="oracle")
+    ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--sigmas", default="0.2,0.6,1.0")
+    ap.add_argument("--windows", default="5,10,20,40")
+    args = ap.parse_args()
+    solve = make_solver(args.backend)
+    for s in [float(x) for x in args.sigmas.split(",")]:
+        for W in [int(x) for x in args.windows.split(",")]:
+            r = run(s, W, solve, frames=args.frames)
+            r.pop("positions")
+            ref = REFERENCE.get((s, W))
+            if ref:
+                r["reference"] = {"avg_iterations": ref[0], "avg_initial_cost": ref[1], "avg_final_cost": ref[2]}
+            print(json.dumps(r), flush=True)
