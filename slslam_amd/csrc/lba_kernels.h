@@ -1289,6 +1289,42 @@ __device__ __forceinline__ void seg_line_trig(const double u[4], const SegCtx& s
   trig[6] = sc[7] / sc[6];
 }
 
+// sin / cos table of a candidate line from the table of the accepted line and the step: the LM step of a line parameter is
+// small, so  sin(a + e) = sin a cos e + cos a sin e  with sin e, cos e from their Taylor series (|e| <= 2^-4: the terms
+// beyond e^11 / e^12 are below 1e-25) costs ~20 fp64 operations per angle where the library's full-range sin + cos cost ~150;
+// cot(t + e) = (d cos e - sin e) / (cos e + d sin e).  Every lane updates all four angles of its line (no lane exchange).
+// The caller falls back to seg_line_trig (library sin / cos of the new angles) when a step of its wave is larger.
+__device__ __forceinline__ void sincos_small(double e, double* se, double* ce) {
+  const double z = e * e;
+  double sp = -2.5052108385441720e-08;                 // -1/11!
+  sp = fma(sp, z, 2.7557319223985893e-06);             //  1/9!
+  sp = fma(sp, z, -1.9841269841269841e-04);            // -1/7!
+  sp = fma(sp, z, 8.3333333333333332e-03);             //  1/5!
+  sp = fma(sp, z, -1.6666666666666666e-01);            // -1/3!
+  *se = fma(sp * z, e, e);
+  double cp = 2.0876756987868100e-09;                  //  1/12!
+  cp = fma(cp, z, -2.7557319223985888e-07);            // -1/10!
+  cp = fma(cp, z, 2.4801587301587302e-05);             //  1/8!
+  cp = fma(cp, z, -1.3888888888888889e-03);            // -1/6!
+  cp = fma(cp, z, 4.1666666666666664e-02);             //  1/4!
+  cp = fma(cp, z, -0.5);
+  *ce = fma(cp, z, 1.0);
+}
+__device__ __forceinline__ void line_trig_step(const double trig0[7], const double e[4], double trig[7]) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    double se, ce;
+    sincos_small(e[q], &se, &ce);
+    const double s0 = trig0[2 * q], c0 = trig0[2 * q + 1];
+    trig[2 * q] = fma(s0, ce, c0 * se);
+    trig[2 * q + 1] = fma(c0, ce, -(s0 * se));
+  }
+  double se, ce;
+  sincos_small(e[3], &se, &ce);
+  const double d = trig0[6];
+  trig[6] = fma(d, ce, -se) / fma(d, se, ce);
+}
+
 // One or two waves per chunk workgroup (blockDim.x = 64 or 128): wave w takes the tiles tile_begin + w, + nw, ...
 __global__ __launch_bounds__(128) void k_backsub(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1397,7 +1433,13 @@ __global__ __launch_bounds__(128) void k_backsub(BatchPtrs p, Policy pol) {
       }
     }
     double trig[7];
-    seg_line_trig(xn, sg, trig);
+    {
+      // (the step actually taken: new minus old, exact in floating point for small steps)
+      const double e[4] = { xn[0] - pf.u[0], xn[1] - pf.u[1], xn[2] - pf.u[2], xn[3] - pf.u[3] };
+      const double emax = fmax(fmax(fabs(e[0]), fabs(e[1])), fmax(fabs(e[2]), fabs(e[3])));
+      if (__any(!(emax <= 0.0625))) seg_line_trig(xn, sg, trig);
+      else line_trig_step(pf.trig, e, trig);
+    }
     if (head) {
       double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
       for (int a = 0; a < 4; ++a) xc[a] = xn[a];
