@@ -13,6 +13,9 @@
 #include "../../include/slslam_hip.h"
 #include "lba_kernels.h"
 #include "lba_eliminate_mfma.h"
+#define SLSLAM_PO_FACTOR_ONLY
+#include "po_kernels.h"
+#include "lba_big.h"
 #include "device_cache.h"
 #include "lba_motion_only.h"
 #include "lba_pack.h"
@@ -187,6 +190,13 @@ struct slslam_lba_batch {
   DevBuf<double> d_cam_x, d_cam_x0, d_cam_scale; DevBuf<int> d_cam_cf, d_cam_win;
   DevBuf<double> d_line_x, d_line_x0, d_line_scale; DevBuf<int> d_line_ptr, d_line_flags, d_line_win, d_line_orig;
   DevBuf<double> d_ob; DevBuf<int> d_ob_cam, d_ob_orig;
+  // windows beyond the tiled sweeps (lba_big.h)
+  bool big_mode = false;
+  BigPtrs big;
+  std::vector<long long> h_big_sys_off, h_big_linv_off;
+  DevBuf<int> d_big_ob_line, d_big_pair_i, d_big_pair_j, d_big_flags;
+  DevBuf<double> d_big_J, d_big_camtab, d_big_line_acc, d_big_sys, d_big_scal, d_big_linv;
+  DevBuf<long long> d_big_sys_off;
   DevBuf<double> d_slab_sum;
   long long slab_sum_stride = 0;           // > 0: k_slab_reduce runs ahead of the reduced solve
   DevBuf<double> d_slab, d_bs_part, d_cost_part, d_ysys, d_params_out, d_fstore, d_line_elim;
@@ -227,6 +237,8 @@ struct slslam_lba_batch {
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
     d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release(); d_active.release();
     d_fstore.release(); d_line_elim.release(); d_slab_sum.release();
+    d_big_ob_line.release(); d_big_pair_i.release(); d_big_pair_j.release(); d_big_flags.release(); d_big_J.release();
+    d_big_camtab.release(); d_big_line_acc.release(); d_big_sys.release(); d_big_scal.release(); d_big_linv.release(); d_big_sys_off.release();
     arena.release();
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     if (capture_stream) { (void)hipStreamDestroy(capture_stream); capture_stream = nullptr; }
@@ -291,6 +303,9 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     if (want < 0 || want > 3) return SLSLAM_ERR_INVALID_ARGUMENT;
     // automatic = the LDS-atomic sweep: on MI355X one wave issues a v_mfma_f64_16x16x4_f64 every ~141 cycles (tools/micro/
     // mfma_f64_bench.hip: the same flop rate as its fp64 VALU), so the matrix-core sweep measures slower
+    b->big_mode = false;
+    for (const PackedWindow& P : b->wins) if (P.big) b->big_mode = true;       // one oversize window sends the batch down lba_big.h
+    if (b->big_mode) { mfma_ok = false; if (b->opt.reuse_elimination) return SLSLAM_ERR_UNSUPPORTED; }
     b->elim_mode = (want >= 2 && mfma_ok) ? 1 : 0;
     b->elim_waves = b->elim_mode == 0 ? 1 : (want == 2 ? 1 : 2);
   }
@@ -334,7 +349,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
       // (at least 2 tiles per wave: below that the camera table set-up and the partial written per chunk outweigh the tiles)
       per_chunk = (int)std::max<long long>(2 * b->elim_waves, (wd.ntiles + cpw - 1) / cpw);
     }
-    const std::vector<int> bounds = chunk_boundaries(wd.ntiles, per_chunk);
+    std::vector<int> bounds = chunk_boundaries(wd.ntiles, per_chunk);
+    if (b->big_mode) { bounds.assign(2, 0); }            // no tiles: one chunk per window carries its step statistics
     wd.chunk_off = (int)chunks.size(); wd.nchunks = (int)bounds.size() - 1;
     const long long slab_stride = (long long)(b->elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n)) + kSlabScalars;
     for (int c = 0; c < wd.nchunks; ++c) {
@@ -425,7 +441,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
       max_chunks = std::max(max_chunks, wd.nchunks);
       max_sys = std::max(max_sys, b->elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n));
     }
-    b->slab_sum_stride = (max_chunks > 8 && !b->opt.reuse_elimination) ? (long long)max_sys + kSlabScalars : 0;
+    b->slab_sum_stride = (max_chunks > 8 && !b->opt.reuse_elimination && !b->big_mode) ? (long long)max_sys + kSlabScalars : 0;
     ar.scratch(b->d_slab_sum, b->slab_sum_stride ? (size_t)b->slab_sum_stride * (size_t)B : 1);
   }
   ar.scratch(b->d_bs_part, std::max<size_t>(1, (size_t)b->nchunk * kBsStride));
@@ -437,6 +453,41 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.upload(b->d_state, b->h_state0);
   ar.zeroed(b->d_trace, std::max<size_t>(1, (size_t)B * kMaxTrace));
   ar.upload(b->d_param_off, b->h_param_off);
+  std::vector<int> big_ob_line, big_pair_i, big_pair_j;
+  if (b->big_mode) {
+    long long sys_cursor = 0, linv_cursor = 0, oc = 0, lc = 0;
+    b->h_big_sys_off.resize(B); b->h_big_linv_off.resize(B);
+    big_ob_line.reserve((size_t)nobs);
+    for (int wi = 0; wi < B; ++wi) {
+      const PackedWindow& P = b->wins[wi];
+      b->h_big_sys_off[wi] = sys_cursor; sys_cursor += big_sys_doubles(6 * P.Cf);
+      b->h_big_linv_off[wi] = linv_cursor; linv_cursor += (long long)((6 * P.Cf + kNB - 1) / kNB + 1) * kNB * kNB;
+      for (int s2 = 0; s2 < P.L; ++s2) {
+        const int o0 = P.line_ptr[s2], k = P.line_ptr[s2 + 1] - o0;
+        for (int j = 0; j < k; ++j) big_ob_line.push_back((int)lc + s2);
+        if (P.line_flags[s2] & 1) continue;
+        int kf = 0;                                        // free-camera observations come first
+        while (kf < k && P.cam_cf[P.ob_cam[o0 + kf]] >= 0) ++kf;
+        for (int i = 0; i < kf; ++i)
+          for (int j = i; j < kf; ++j) { big_pair_i.push_back((int)(oc + o0 + i)); big_pair_j.push_back((int)(oc + o0 + j)); }
+      }
+      oc += P.M; lc += P.L;
+    }
+    if (big_ob_line.empty()) big_ob_line.push_back(0);
+    b->big.npairs = (long long)big_pair_i.size();
+    if (big_pair_i.empty()) { big_pair_i.push_back(0); big_pair_j.push_back(0); }
+    ar.upload(b->d_big_ob_line, big_ob_line);
+    ar.upload(b->d_big_pair_i, big_pair_i);
+    ar.upload(b->d_big_pair_j, big_pair_j);
+    ar.upload(b->d_big_sys_off, b->h_big_sys_off);
+    ar.scratch(b->d_big_J, (size_t)std::max<long long>(1, nobs) * kBigObs);
+    ar.scratch(b->d_big_camtab, (size_t)std::max<long long>(1, ncam) * 2 * kBigCam);
+    ar.zeroed(b->d_big_line_acc, (size_t)std::max<long long>(1, nline) * kBigLine);
+    ar.zeroed(b->d_big_sys, (size_t)std::max<long long>(1, sys_cursor));
+    ar.zeroed(b->d_big_scal, (size_t)std::max(1, B) * kBgScal);
+    ar.zeroed(b->d_big_flags, (size_t)std::max(1, B) * 2);
+    ar.scratch(b->d_big_linv, (size_t)std::max<long long>(1, linv_cursor));
+  }
   ar.zeroed(b->d_iter_counter, 1);
   ar.zeroed(b->d_dbg_cycles, b->pol.debug_flags ? (size_t)32 * std::max(1, b->nchunk) : 1);
   ar.zeroed(b->d_active, 1);
@@ -455,6 +506,12 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.iter_counter = b->d_iter_counter.p; p.active_counter = b->d_active.p; p.cam_x0 = b->d_cam_x0.p; p.line_u0 = b->d_line_x0.p;
   p.nwin = B; p.nchunk = b->nchunk; p.nline = b->nline; p.ncam = b->ncam;
   p.dbg_cycles = b->d_dbg_cycles.p;
+  if (b->big_mode) {
+    BigPtrs& g = b->big;
+    g.ob_line = b->d_big_ob_line.p; g.cam_win = b->d_cam_win.p; g.J = b->d_big_J.p; g.camtab = b->d_big_camtab.p;
+    g.line_acc = b->d_big_line_acc.p; g.sys = b->d_big_sys.p; g.sys_off = b->d_big_sys_off.p; g.pair_i = b->d_big_pair_i.p;
+    g.pair_j = b->d_big_pair_j.p; g.scal = b->d_big_scal.p; g.flags = b->d_big_flags.p; g.nobs = nobs;
+  }
   p.line_desc = b->d_line_desc.p; p.elim_mode = b->elim_mode; p.elim_waves = b->elim_waves;
   b->lds_elim = (size_t)lds_bytes_eliminate_mfma(maxC, maxn, b->elim_waves);
 
@@ -468,8 +525,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   b->lds_bs_stream = sizeof(double) * (size_t)lds_doubles_backsub_stream(maxC, maxn);
   b->lds_cost = sizeof(double) * (size_t)lds_doubles_cost(maxC, maxn);
   const size_t lds_max = std::max(std::max(b->lds_lin, b->lds_solve), std::max(b->lds_bs, b->lds_cost));
-  if (lds_max > 160 * 1024) return SLSLAM_ERR_UNSUPPORTED;
-  if (b->lds_lin > 48 * 1024) {
+  if (lds_max > 160 * 1024 && !b->big_mode) return SLSLAM_ERR_UNSUPPORTED;
+  if (b->lds_lin > 48 * 1024 && !b->big_mode) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
     HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
   }
@@ -480,7 +537,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
   }
-  if (b->lds_solve > 48 * 1024)
+  if (b->lds_solve > 48 * 1024 && !b->big_mode)
     HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
   b->h_state.assign(B, LMState());
   b->h_trace.assign((size_t)B * kMaxTrace, IterRec());
@@ -533,8 +590,67 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     if ((rc = L.end())) return rc;                         \
   } while (0)
   if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 0));
-  if (b->fused_motion_only) {
+  if (b->fused_motion_only && !b->big_mode) {
     LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_motion_only, g_win, blk64, b->lds_motion_only, s, p, pol));
+    HIP_TRY(hipGetLastError());
+    return SLSLAM_OK;
+  }
+  if (b->big_mode) {
+    // windows beyond the tiled sweeps: everything in HBM / L2 (lba_big.h), the reduced system on the pose-graph path's
+    // blocked MFMA Cholesky
+    const BigPtrs& g = b->big;
+    const dim3 blk128(128);
+    const dim3 g_obs128((unsigned)((g.nobs + 127) / 128)), g_obs256((unsigned)((g.nobs + 255) / 256)), g_line128((unsigned)((b->nline + 127) / 128)),
+        g_cam((unsigned)((b->ncam + 255) / 256)), g_pair((unsigned)((g.npairs + 127) / 128));
+    const int iters = std::max(1, pol.max_num_iterations);      // (max_num_iterations = 0: the first sweep's initial evaluation only)
+    for (int it = 0; it < iters; ++it) {
+      if (!capturing && it > 0 && (it % 16) == 0) {
+        unsigned int active = 0;
+        HIP_TRY(hipMemcpyAsync(&active, b->d_active.p, sizeof(active), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (active == 0) break;
+      }
+      if (!capturing && ((it + 1) % 16) == 0) HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
+      HIP_TRY(hipMemsetAsync(b->d_big_sys.p, 0, b->d_big_sys.n * sizeof(double), s));
+      HIP_TRY(hipMemsetAsync(b->d_big_line_acc.p, 0, b->d_big_line_acc.n * sizeof(double), s));
+      HIP_TRY(hipMemsetAsync(b->d_big_scal.p, 0, b->d_big_scal.n * sizeof(double), s));
+      HIP_TRY(hipMemsetAsync(b->d_big_flags.p, 0, b->d_big_flags.n * sizeof(int), s));
+      HIP_TRY(hipMemsetAsync(b->d_bs_part.p, 0, b->d_bs_part.n * sizeof(double), s));
+      HIP_TRY(hipMemsetAsync(b->d_cost_part.p, 0, b->d_cost_part.n * sizeof(double), s));
+      LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_cameras, g_cam, blk256, 0, s, p, g, 0));
+      if (g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_linearise, g_obs128, blk128, 0, s, p, g, pol));
+      if (b->nline > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_line, g_line128, blk128, 0, s, p, g, pol));
+      if (g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_rescale, g_obs256, blk256, 0, s, p, g));
+      if (g.npairs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_schur, g_pair, blk128, 0, s, p, g));
+      LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_prepare, g_win, blk256, 0, s, p, g, pol));
+      if (pol.max_num_iterations <= 0) break;
+      for (int wi = 0; wi < B; ++wi) {
+        const int n = b->h_wins[wi].n;
+        if (n <= 0) continue;
+        PoPtrs pp;
+        std::memset(&pp, 0, sizeof(pp));
+        pp.st = b->d_state.p + wi; pp.flags = b->d_big_flags.p + 2 * wi; pp.n = n; pp.ld = big_ld(n);
+        pp.H = b->d_big_sys.p + b->h_big_sys_off[wi]; pp.y = pp.H + (long long)n * pp.ld + 3LL * n;
+        double* linv = b->d_big_linv.p + b->h_big_linv_off[wi];
+        const int nblk = (n + kNB - 1) / kNB;
+        for (int bk = 0; bk < nblk; ++bk) {
+          const int k0 = bk * kNB, rem = n - (k0 + kNB), tb = rem > 0 ? (rem + kNB - 1) / kNB : 0;
+          LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_po_potrf_diag<double>, dim3(1), blk256, 0, s, pp, pp.H, linv + (size_t)bk * kNB * kNB, k0));
+          if (tb > 0) {
+            LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)tb), blk256, 0, s, pp, pp.H, (const double*)(linv + (size_t)bk * kNB * kNB), k0, 0));
+            LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)(tb * (tb + 1) / 2)), blk256, 0, s, pp, pp.H, (const double*)(linv + (size_t)bk * kNB * kNB), k0, 1));
+          }
+        }
+        LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), blk256, 0, s, pp, (const double*)pp.H, (const double*)linv));
+      }
+      LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_finish, g_win, blk64, 0, s, p, g));
+      if (it == 0 && g.nobs > 0) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_rescale_cameras, g_obs256, blk256, 0, s, p, g));
+      LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_cameras, g_cam, blk256, 0, s, p, g, 1));
+      if (g.nobs > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_backsub_obs, g_obs128, blk128, 0, s, p, g));
+      if (b->nline > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_backsub_line, g_line128, blk128, 0, s, p, g));
+      if (g.nobs > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_cost, g_obs128, blk128, 0, s, p, g, pol));
+      LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol));
+    }
     HIP_TRY(hipGetLastError());
     return SLSLAM_OK;
   }
@@ -593,7 +709,7 @@ extern "C" int slslam_lba_batch_solve(slslam_lba_batch* b, void* stream) {
     if (b->ev_next > 16384) b->harvest_events();        // long profiled runs: bounded pool (costs one synchronisation)
     return enqueue_solve(b, s, true);
   }
-  if (!b->opt.use_graph || b->opt.max_num_iterations > 16) return enqueue_solve(b, s, false);
+  if (!b->opt.use_graph || b->opt.max_num_iterations > 16 || b->big_mode) return enqueue_solve(b, s, false);
   if (!b->graph_exec) {
     // capture the whole solve (1 + 4 * max_iter launches) once; replay costs one host call
     HIP_TRY(hipStreamCreateWithFlags(&b->capture_stream, hipStreamNonBlocking));

@@ -14,7 +14,6 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   if (M > 0 && (!w->camera_index || !w->line_index || !w->fixed_index || !w->observations))
     return SLSLAM_ERR_INVALID_ARGUMENT;
   if ((C > 0 || L > 0) && !w->parameters) return SLSLAM_ERR_INVALID_ARGUMENT;
-  if (C > kMaxCams) return SLSLAM_ERR_UNSUPPORTED;
   PackedWindow& P = *out;
   P = PackedWindow();
   P.C = C; P.L = L; P.M = M;
@@ -34,7 +33,9 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   }
   P.cam_cf.assign(C, -1);
   for (int c = 0; c < C; ++c) if (cam_used[c] && !cam_const[c]) P.cam_cf[c] = P.Cf++;
-  if (P.Cf > kMaxFreeCams) return SLSLAM_ERR_UNSUPPORTED;
+  // windows beyond what the tiled sweeps hold on chip take the global-memory path (lba_big.h): no tiles are built for them
+  P.big = C > kMaxCams || P.Cf > kMaxFreeCams;
+  for (int l = 0; l < L && !P.big; ++l) if (line_cnt[l] > 64) P.big = true;
   P.cam_x.assign(w->parameters, w->parameters + (size_t)6 * C);
 
   // lane runs: a line takes max(k, 1) consecutive lanes.  Runs are bin-packed (best fit, decreasing) into
@@ -64,74 +65,76 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   };
   // best fit over lines of decreasing length (counting sort by length, original order inside a length): a line goes to
   // the fullest open row that still holds it, else it opens a row.  Returns the range of row ids created.
-  std::vector<int> by_len[17];
-  auto pack_rows = [&](int len_lo, int len_hi) {
-    const int first = (int)rows.size();
-    std::vector<int> open_by_room[17];
-    for (int len = len_hi; len >= len_lo; --len)
-      for (int l : by_len[len]) {
-        // the fullest open row that holds the line - and, among the rows of that fill, preferably one none of whose
-        // lines shares a free camera with it: the lanes of one 16-lane row that add to the same camera record
-        // serialise in the LDS (tools/micro/lds_atomic_bench.hip)
-        int r = -1;
-        for (int pass = 0; pass < 2 && r < 0; ++pass)          // pass 0: rows without a common free camera only
-          for (int room = len; room <= 16 && r < 0; ++room) {
-            std::vector<int>& cand = open_by_room[room];
-            for (size_t c = cand.size(); c-- > 0 && cand.size() - c <= 32;)
-              if (pass == 1 || !(rows[cand[c]].mask & fmask[l])) { r = cand[c]; cand.erase(cand.begin() + c); break; }
-          }
-        if (r < 0) { r = (int)rows.size(); rows.push_back(Row{0, 0, -1, -1, 0u}); }
-        append(r, l);
-        if (rows[r].used < 16) open_by_room[16 - rows[r].used].push_back(r);
-      }
-    return std::make_pair(first, (int)rows.size());
-  };
-  std::vector<int> big;
-  for (int l = 0; l < L; ++l) {
-    if (line_cnt[l] > 64) return SLSLAM_ERR_UNSUPPORTED;
-    if (line_cnt[l] > 16) big.push_back(l); else by_len[lanes_of(l)].push_back(l);
-  }
   std::vector<int> tile_rows;                      // row ids, tile after tile
   std::vector<int> tile_ptr(1, 0);
-  {
-    int used_rows = 4;
-    std::stable_sort(big.begin(), big.end(), [&](int x, int y) { return line_cnt[x] > line_cnt[y]; });
-    for (int l : big) {                            // a long line is a row entry of its own that spans (k + 15) / 16 rows
-      const int nr = (line_cnt[l] + 15) / 16;
-      if (used_rows + nr > 4) { if (!tile_rows.empty()) tile_ptr.push_back((int)tile_rows.size()); used_rows = 0; }
-      rows.push_back(Row{0, 0, -1, -1, 0u});
-      append((int)rows.size() - 1, l);
-      tile_rows.push_back((int)rows.size() - 1);
-      used_rows += nr;
+  if (!P.big) {
+    std::vector<int> by_len[17];
+    auto pack_rows = [&](int len_lo, int len_hi) {
+      const int first = (int)rows.size();
+      std::vector<int> open_by_room[17];
+      for (int len = len_hi; len >= len_lo; --len)
+        for (int l : by_len[len]) {
+          // the fullest open row that holds the line - and, among the rows of that fill, preferably one none of whose
+          // lines shares a free camera with it: the lanes of one 16-lane row that add to the same camera record
+          // serialise in the LDS (tools/micro/lds_atomic_bench.hip)
+          int r = -1;
+          for (int pass = 0; pass < 2 && r < 0; ++pass)          // pass 0: rows without a common free camera only
+            for (int room = len; room <= 16 && r < 0; ++room) {
+              std::vector<int>& cand = open_by_room[room];
+              for (size_t c = cand.size(); c-- > 0 && cand.size() - c <= 32;)
+                if (pass == 1 || !(rows[cand[c]].mask & fmask[l])) { r = cand[c]; cand.erase(cand.begin() + c); break; }
+            }
+          if (r < 0) { r = (int)rows.size(); rows.push_back(Row{0, 0, -1, -1, 0u}); }
+          append(r, l);
+          if (rows[r].used < 16) open_by_room[16 - rows[r].used].push_back(r);
+        }
+      return std::make_pair(first, (int)rows.size());
+    };
+    std::vector<int> big;
+    for (int l = 0; l < L; ++l) {
+      if (line_cnt[l] > 16) big.push_back(l); else by_len[lanes_of(l)].push_back(l);
     }
-    if (!tile_rows.empty()) tile_ptr.push_back((int)tile_rows.size());
-  }
-  {
-    const std::pair<int, int> rr = pack_rows(4, 16);
-    std::vector<int> order(rr.second - rr.first);
-    std::iota(order.begin(), order.end(), rr.first);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rows[x].items > rows[y].items; });
-    const int R = (int)order.size(), T = (R + 3) / 4;
-    std::vector<int> slot((size_t)4 * T, -1);
-    for (int r = 0; r < R; ++r) {                  // boustrophedon deal: heavy rows meet light rows
-      const int pass = r / T, pos = r % T;
-      slot[(size_t)4 * ((pass & 1) ? T - 1 - pos : pos) + pass] = order[r];
+    {
+      int used_rows = 4;
+      std::stable_sort(big.begin(), big.end(), [&](int x, int y) { return line_cnt[x] > line_cnt[y]; });
+      for (int l : big) {                            // a long line is a row entry of its own that spans (k + 15) / 16 rows
+        const int nr = (line_cnt[l] + 15) / 16;
+        if (used_rows + nr > 4) { if (!tile_rows.empty()) tile_ptr.push_back((int)tile_rows.size()); used_rows = 0; }
+        rows.push_back(Row{0, 0, -1, -1, 0u});
+        append((int)rows.size() - 1, l);
+        tile_rows.push_back((int)rows.size() - 1);
+        used_rows += nr;
+      }
+      if (!tile_rows.empty()) tile_ptr.push_back((int)tile_rows.size());
     }
-    for (int t = 0; t < T; ++t) {
-      for (int q = 0; q < 4; ++q) if (slot[(size_t)4 * t + q] >= 0) tile_rows.push_back(slot[(size_t)4 * t + q]);
-      tile_ptr.push_back((int)tile_rows.size());
+    {
+      const std::pair<int, int> rr = pack_rows(4, 16);
+      std::vector<int> order(rr.second - rr.first);
+      std::iota(order.begin(), order.end(), rr.first);
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rows[x].items > rows[y].items; });
+      const int R = (int)order.size(), T = (R + 3) / 4;
+      std::vector<int> slot((size_t)4 * T, -1);
+      for (int r = 0; r < R; ++r) {                  // boustrophedon deal: heavy rows meet light rows
+        const int pass = r / T, pos = r % T;
+        slot[(size_t)4 * ((pass & 1) ? T - 1 - pos : pos) + pass] = order[r];
+      }
+      for (int t = 0; t < T; ++t) {
+        for (int q = 0; q < 4; ++q) if (slot[(size_t)4 * t + q] >= 0) tile_rows.push_back(slot[(size_t)4 * t + q]);
+        tile_ptr.push_back((int)tile_rows.size());
+      }
     }
-  }
-  {
-    const std::pair<int, int> rr = pack_rows(1, 3);
-    for (int r = rr.first; r < rr.second; ++r) {
-      tile_rows.push_back(r);
-      if ((r - rr.first) % 4 == 3 || r + 1 == rr.second) tile_ptr.push_back((int)tile_rows.size());
+    {
+      const std::pair<int, int> rr = pack_rows(1, 3);
+      for (int r = rr.first; r < rr.second; ++r) {
+        tile_rows.push_back(r);
+        if ((r - rr.first) % 4 == 3 || r + 1 == rr.second) tile_ptr.push_back((int)tile_rows.size());
+      }
     }
   }
   P.line_order.clear();
   P.line_order.reserve(L);
-  for (int r : tile_rows) for (int l = rows[r].head; l >= 0; l = next[l]) P.line_order.push_back(l);
+  if (P.big) { for (int l = 0; l < L; ++l) P.line_order.push_back(l); }
+  else for (int r : tile_rows) for (int l = rows[r].head; l >= 0; l = next[l]) P.line_order.push_back(l);
   std::vector<int> line_pos(L);
   for (int s = 0; s < L; ++s) line_pos[P.line_order[s]] = s;
 
@@ -179,7 +182,8 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   }
 
   // tiles, their lane maps and their off-diagonal camera-pair work items
-  {
+  P.line_desc.assign(L, 0u);
+  if (!P.big) {
     int s = 0;
     P.tiles.reserve(tile_ptr.size());
     { size_t ni = 0; for (int l = 0; l < L; ++l) ni += (size_t)items_of(l); P.items.reserve(2 * ni); }

@@ -36,6 +36,7 @@ struct PackedWindow {
   std::vector<uint16_t> lane_map;   // [64 per tile] lane -> line slot | position << 8 (0x00FF: idle)
   std::vector<uint8_t> items;       // 2 bytes per item
   std::vector<uint32_t> line_desc;  // [L] sorted: free-camera mask | first lane of the run << 10 | touched accumulator tiles << 16
+  bool big = false;                 // beyond the tiled sweeps (> 20 free / 64 cameras, a line with > 64 observations): lba_big.h
   bool dup_free_obs = false;        // some free camera observes some line more than once (the reference's map never does)
   std::vector<double> params0;      // caller's original parameter vector (for lines/cams never touched)
 };

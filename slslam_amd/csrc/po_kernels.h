@@ -146,6 +146,7 @@ struct PoPtrs {
 };
 enum { kPoCost = 0, kPoCandCost = 1, kPoModel = 2, kPoDn2 = 3, kPoXn2 = 4, kPoFixed = 5 };
 
+#ifndef SLSLAM_PO_FACTOR_ONLY    // (lba_api.hip includes this header for the blocked Cholesky kernels only: lba_big.h)
 // lane <-> (edge, column of [J1|J2]); 5 edges per wave.
 // mode 0: accumulate H, g, cost at the accepted point (scaled columns)
 // mode 1: cost only at the candidate point
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256) void k_po_prepare(PoPtrs p, Policy pol, int fi
   if (tid == 0) { p.flags[0] = 0; p.scal[kPoCandCost] = 0.0; }
 }
 
+#endif
 // ---- blocked Cholesky, block size 64 --------------------------------------------------------
 // Templated on the factorisation type: double (default; v_mfma_f64_16x16x4_f64) or float
 // (v_mfma_f32_16x16x4_f32) for the fp32-vs-fp64 tolerance study of BASELINE config 5.  In the float
@@ -292,6 +294,7 @@ template <> struct Mfma<float> {
 };
 
 // fp64 normal matrix (lower triangle) -> float copy for the single-precision factorisation
+#ifndef SLSLAM_PO_FACTOR_ONLY
 __global__ __launch_bounds__(256) void k_po_to_f32(PoPtrs p, float* Hf) {
   if (p.st->status != kRunning) return;
   const long long total = (long long)p.n * p.ld;
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(256) void k_po_to_f32(PoPtrs p, float* Hf) {
 }
 
 // Factor the diagonal block A[k0:k0+nb, k0:k0+nb] in LDS, write L11 back and its inverse to linv.
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void k_po_potrf_diag(PoPtrs p, T* A, T* linv, int k0) {
   if (p.st->status != kRunning) return;
@@ -467,6 +471,7 @@ __global__ __launch_bounds__(256) void k_po_trisolve(PoPtrs p, const T* A, const
   }
 }
 
+#ifndef SLSLAM_PO_FACTOR_ONLY
 // ------------------------------------------------------------------------------------------
 // Structured factorisation (default): a pose graph is chains of odometry edges tied together by a few
 // loop closures.  The host orders the unknowns chains first (each chain's poses consecutive, in path
@@ -769,5 +774,6 @@ __global__ void k_po_update(PoPtrs p, Policy pol) {
   if (st->iter >= pol.max_num_iterations) { st->status = 0; return; }
 }
 
+#endif
 }  // namespace slslam
 #endif  // SLSLAM_PO_KERNELS_H_

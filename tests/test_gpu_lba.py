@@ -56,7 +56,8 @@ def test_linearise_matches_oracle(hip, oracle):
         b.close()
 
 
-@pytest.mark.parametrize("seed,lines,kf,free", [(1, 60, 20, 10), (2, 200, 20, 10), (3, 500, 20, 10), (4, 80, 6, 3), (5, 40, 20, 20)])
+@pytest.mark.parametrize("seed,lines,kf,free", [(1, 60, 20, 10), (2, 200, 20, 10), (3, 500, 20, 10), (4, 80, 6, 3), (5, 40, 20, 20),
+                                                 (6, 150, 40, 20), (7, 150, 80, 40)])     # W = 20 and W = 40 of the reference's study
 def test_solve_trace_matches_oracle(hip, oracle, seed, lines, kf, free):
     """LM iteration by iteration: cost, gain ratio, radius, step norm, accept/reject decisions."""
     w = synth.make_window(seed, num_lines=lines, num_kf=kf, num_free=free)
@@ -96,6 +97,37 @@ def test_long_and_short_line_runs(hip, oracle):
         _assert_trace_parity(t0, t1, n=3)
         _assert_summary_parity(s0, s1)
         assert np.abs(x0 - x1).max() < 1e-5
+
+
+def test_windows_beyond_the_tiled_sweeps(hip, oracle):
+    """The reference's window size is a flag (src/main.cpp:22) and its study runs W = 40: 80 keyframes, 40 free, lines tracked
+    through all of them.  Such windows (more than 20 free / 64 cameras, or a line with more than 64 observations) take the
+    global-memory path (lba_big.h, reduced system on the pose-graph MFMA Cholesky); same algorithm, so the same traces.
+    (Lines observed by more than 64 keyframes: tests/test_house_study.py, W = 40.)"""
+    ws = [synth.make_window(31, num_lines=100, num_kf=80, num_free=40, mean_track=30.0),
+          synth.make_window(33, num_lines=80, num_kf=70, num_free=12, mean_track=20.0),        # > 64 cameras only
+          synth.make_window(34, num_lines=50, num_kf=30, num_free=24, mean_track=10.0)]        # > 20 free cameras only
+    for w in ws:
+        x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+        x1, s1, t1 = hip.lba_solve(w)
+        _assert_trace_parity(t0, t1, n=3)
+        _assert_summary_parity(s0, s1)
+        assert np.abs(x0 - x1).max() < 1e-5
+    # a batch that mixes an oversize window with ordinary ones goes down the same path as a whole
+    b = hip.LBABatch()
+    mix = [ws[0], synth.make_window(35, num_lines=120), synth.make_motion_only(6, num_lines=30)]
+    for w in mix:
+        b.add(w)
+    b.finalize(); b.solve(); b.download()
+    for i, w in enumerate(mix):
+        xo, so, _ = oracle.lba_solve(w, linear_solver=1)
+        assert np.abs(xo - b.parameters(i)).max() < 1e-5
+        assert b.summary(i)["num_successful_steps"] == so["num_successful_steps"]
+    b.close()
+    # max_num_iterations = 0: the initial evaluation only
+    x1, s1, t1 = hip.lba_solve(ws[0], max_num_iterations=0)
+    x0, s0, t0 = oracle.lba_solve(ws[0], linear_solver=1, max_num_iterations=0)
+    assert abs(s1["initial_cost"] - s0["initial_cost"]) <= 1e-12 * s0["initial_cost"] and np.array_equal(x1, ws[0]["parameters"])
 
 
 def test_one_iteration_is_roundoff_exact(hip, oracle):

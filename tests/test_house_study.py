@@ -57,3 +57,30 @@ def test_gpu_pipeline_matches_oracle_pipeline(hip, oracle):
     assert abs(a["avg_iterations"] - b["avg_iterations"]) <= 0.05 * a["avg_iterations"]
     assert abs(a["avg_final_cost"] - b["avg_final_cost"]) <= 1e-5 * a["avg_final_cost"]
     assert np.abs(a["positions"] - b["positions"]).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_gpu_window_size_40(hip, oracle):
+    """W = 40 of the reference's study (ba_window_size is a flag, src/main.cpp:22): windows of up to 80 keyframes, 40 of them
+    free, house lines tracked through all of them (more than 64 observations per line) - the global-memory path of
+    lba_big.h.  The oracle drives the simulated run; every window it solves is also solved on the GPU from the same input
+    and compared (the first 40 windows have no fixed keyframe: their gauge is held by the LM damping alone, so only their
+    cost is compared)."""
+    seen = {"cams": 0, "obs": 0, "windows": 0, "gauged": 0}
+
+    def solve(w, it):
+        x0, s0, t0 = oracle.lba_solve(w, linear_solver=1, max_num_iterations=it)
+        if w["num_cameras"] > 1:
+            x1, s1, t1 = hip.lba_solve(w, max_num_iterations=it)
+            seen["cams"] = max(seen["cams"], int(w["num_cameras"]))
+            seen["obs"] = max(seen["obs"], int(np.bincount(w["line_index"]).max()))
+            seen["windows"] += 1
+            assert abs(s0["initial_cost"] - s1["initial_cost"]) <= 1e-11 * s0["initial_cost"]
+            assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-5 * s0["final_cost"]
+            if np.asarray(w["fixed_index"]).reshape(-1, 2)[:, 0].any():            # a fixed keyframe pins the gauge
+                seen["gauged"] += 1
+                assert s0["num_successful_steps"] == s1["num_successful_steps"] and s0["termination_type"] == s1["termination_type"]
+                assert np.abs(x0 - x1).max() < 1e-5
+        return x0, s0
+    hs.run(0.4, 40, solve, frames=100)
+    assert seen["cams"] == 80 and seen["obs"] > 64 and seen["gauged"] >= 55
