@@ -304,13 +304,18 @@ def test_pack_long_and_short_lines(host_math):
     rc, P = _pack(host_math, w)
     assert rc == 0 and P["Cf"] == 12
     _check_tiles(P, w, L)
-    # a line with more than 64 observations does not fit a wave: reported, not mangled
+    # a line with more than 64 observations does not fit a wave: the window goes to the global-memory path
+    # (lba_big.h) - no tiles, no pair items, lines in their original order, observations still grouped by line
     too_long = dict(w, camera_index=np.concatenate([w["camera_index"], (np.arange(65) % 64).astype(np.int32)]),
                     line_index=np.concatenate([w["line_index"], np.full(65, 59, dtype=np.int32)]),
-                    fixed_index=np.concatenate([w["fixed_index"], np.ones(130, dtype=np.int32)]),
+                    fixed_index=np.concatenate([w["fixed_index"], np.stack([np.arange(65) % 64 >= 12, np.zeros(65)], 1).astype(np.int32).reshape(-1)]),
                     observations=np.concatenate([w["observations"], rng.normal(size=(65, 8))]),
                     parameters=w["parameters"])
-    assert _pack(host_math, too_long)[0] == 4
+    rc2, P2 = _pack(host_math, too_long)
+    assert rc2 == 0 and P2["ntiles"] == 0 and P2["nitems"] == 0 and P2["Cf"] == 12
+    assert np.array_equal(P2["line_order"], np.arange(L))
+    assert np.array_equal(np.diff(P2["line_ptr"]), np.bincount(too_long["line_index"], minlength=L))
+    assert sorted(P2["ob_orig"].tolist()) == list(range(len(too_long["camera_index"])))
     runs = {}
     for t, (lb, nl, flags, ni) in enumerate(P["tiles"]):
         ks = [max(int(P["line_ptr"][s + 1] - P["line_ptr"][s]), 1) for s in range(lb, lb + nl)]
@@ -332,9 +337,10 @@ def test_pack_edge_cases(host_math):
     assert _pack(host_math, bad)[0] == 1
     bad = dict(w, observations=w["observations"].copy()); bad["observations"][0, 0] = np.nan
     assert _pack(host_math, bad)[0] == 1
-    # more free cameras than the reduced-system kernel supports
+    # more free cameras than the LDS-resident reduced system holds: packed for the global-memory path, no tiles
     big = synth.make_window(2, num_lines=30, num_kf=24, num_free=24)
-    assert _pack(host_math, big)[0] == 4
+    rc, P = _pack(host_math, big)
+    assert rc == 0 and P["Cf"] == 24 and P["ntiles"] == 0 and P["nitems"] == 0 and P["nfree"] == 6 * 24 + 4 * 30
 
 
 def _declared_functions():
