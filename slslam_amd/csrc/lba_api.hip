@@ -180,6 +180,7 @@ struct slslam_lba_batch {
   bool downloaded = false;
   // device
   DeviceArena arena;
+  DevBuf<uint16_t> d_sys_map;
   DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<uint8_t> d_items; DevBuf<uint16_t> d_lane_map;
   DevBuf<uint32_t> d_line_desc;
   DevBuf<unsigned long long> d_dbg_cycles;
@@ -230,7 +231,7 @@ struct slslam_lba_batch {
   }
 
   void release() {
-    d_wins.release(); d_tiles.release(); d_chunks.release(); d_items.release(); d_lane_map.release(); d_line_desc.release(); d_dbg_cycles.release();
+    d_sys_map.release(); d_wins.release(); d_tiles.release(); d_chunks.release(); d_items.release(); d_lane_map.release(); d_line_desc.release(); d_dbg_cycles.release();
     d_cam_x.release(); d_cam_x0.release(); d_cam_scale.release(); d_cam_cf.release(); d_cam_win.release();
     d_line_x.release(); d_line_x0.release(); d_line_scale.release(); d_line_ptr.release(); d_line_flags.release();
     d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release();
@@ -387,6 +388,20 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   }
   line_ptr.push_back((int)obs_cursor);
   if (nobs > 0x7fffffffLL) return SLSLAM_ERR_UNSUPPORTED;
+  // reduced solve: where each entry of a chunk partial goes in its LDS image, one table per distinct system order
+  std::vector<uint16_t> sys_map(1, (uint16_t)0xFFFF);
+  {
+    std::vector<int> off_of_n((size_t)maxn / 6 + 1, -1);
+    for (WinDesc& wd : b->h_wins) {
+      int& off = off_of_n[wd.n / 6];
+      if (off < 0 && !b->big_mode) {
+        off = (int)sys_map.size();
+        sys_map.resize(sys_map.size() + (size_t)sys_doubles(wd.n));
+        sys_map_build(wd.n, sys_map.data() + off);
+      }
+      wd.map_off = off < 0 ? 0 : off;
+    }
+  }
   b->total_params = param_off; b->nchunk = (int)chunks.size(); b->nline = (int)nline; b->ncam = (int)ncam;
 
   // ---- initial LM state (Ceres: LevenbergMarquardtStrategy ctor)
@@ -402,6 +417,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   DeviceArena& ar = b->arena;
   ar.device = b->device;
   ar.upload(b->d_wins, b->h_wins);
+  ar.upload(b->d_sys_map, sys_map);
   ar.upload(b->d_tiles, tiles);
   ar.upload(b->d_chunks, chunks);
   if (items.empty()) items.push_back(0);
@@ -505,7 +521,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.state = b->d_state.p; p.trace = b->d_trace.p;
   p.iter_counter = b->d_iter_counter.p; p.active_counter = b->d_active.p; p.cam_x0 = b->d_cam_x0.p; p.line_u0 = b->d_line_x0.p;
   p.nwin = B; p.nchunk = b->nchunk; p.nline = b->nline; p.ncam = b->ncam;
-  p.dbg_cycles = b->d_dbg_cycles.p;
+  p.dbg_cycles = b->d_dbg_cycles.p; p.sys_map = b->d_sys_map.p;
   if (b->big_mode) {
     BigPtrs& g = b->big;
     g.ob_line = b->d_big_ob_line.p; g.cam_win = b->d_cam_win.p; g.J = b->d_big_J.p; g.camtab = b->d_big_camtab.p;

@@ -688,6 +688,34 @@ __device__ __forceinline__ void push_trace(BatchPtrs& p, int w, LMState* st, con
 
 __host__ __device__ inline int solve_pad(int n) { return ((n + 15) / 16) * 16; }
 __host__ __device__ inline int solve_stride(int n) { return ((solve_pad(n) + 30) / 32) * 32 + 1; }  // == 1 (mod 32) doubles
+// Where entry q of a chunk partial (camera records | pair blocks, see kCamAcc / kPairAcc) lives in the reduced solve's LDS image
+// A (N x ld, lower triangle) | b | g | hdiag; 0xFFFF = padding.  One table per distinct n of a batch, built on the host.
+inline void sys_map_build(int n, unsigned short* out) {
+  const int ncf = n / 6, N = solve_pad(n), ld = solve_stride(n);
+  for (int q = 0; q < sys_doubles(n); ++q) {
+    int off = 0xFFFF;
+    if (q < ncf * kCamAcc) {
+      const int cf = q / kCamAcc, ee = q - cf * kCamAcc;
+      if (ee < kRecB) {
+        int a = 0;
+        while (((a + 1) * (a + 2)) / 2 <= ee) ++a;
+        off = (6 * cf + a) * ld + 6 * cf + (ee - (a * (a + 1)) / 2);
+      } else {
+        const int v2 = (ee - kRecB) / 6, a = (ee - kRecB) - 6 * v2;      // 0 = b, 1 = g, 2 = hdiag
+        off = N * ld + v2 * N + 6 * cf + a;
+      }
+    } else {
+      const int pq = q - ncf * kCamAcc, pr = pq / kPairAcc, ee = pq - pr * kPairAcc;
+      if (ee < 36) {
+        int cj = 1;
+        while (((cj + 1) * cj) / 2 <= pr) ++cj;
+        const int ci = pr - (cj * (cj - 1)) / 2;
+        off = (6 * cj + ee / 6) * ld + 6 * ci + (ee % 6);
+      }
+    }
+    out[q] = (unsigned short)off;
+  }
+}
 // The inverse of a diagonal tile's factor is kept IN the tile: strictly lower part transposed into the tile's
 // (otherwise unused) strict upper triangle, its diagonal 1 / L[r][r] in a vector: 36.5 KB of LDS for n = 60,
 // i.e. 4 workgroups per CU and the whole 1024-window batch resident in one round.
@@ -709,6 +737,26 @@ __device__ __forceinline__ unsigned long long solve_clock() {
     if (timing) { const unsigned long long now_ = solve_clock(); if (tid == 0) p.dbg_cycles[(long long)w * 16 + (i)] += now_ - tlast_; tlast_ = now_; } \
   } while (0)
 
+
+// The 16 elimination steps of a diagonal tile of the reduced solve (see k_reduced_solve, step 3 (a)+(b)); JC is the step.
+template <int JC>
+__device__ __forceinline__ void diag_tile_steps(double (&a)[16], double (&e)[4], double& ipown, int r, int& fail) {
+  if constexpr (JC < 16) {
+    const double piv = dpp_move<0x150 + JC>(a[JC]);                      // row_newbcast: lane JC of the row to all 16 lanes
+    const bool okp = piv > 0.0 && isfinite(piv);
+    if (!okp) fail = 1;
+    const double ip = okp ? inv_sqrt<double>(piv) : 1.0;                 // v_rsq_f64 + refinement: no sqrt, no divide on the chain
+    double m = a[JC] * (ip * ip);
+    a[JC] *= ip;                                                         // L[r][JC] for r >= JC
+    m = (r > JC) ? m : 0.0;
+    ipown = (r == JC) ? ip : ipown;
+#pragma unroll
+    for (int c = JC + 1; c < 16; ++c) a[c] = fma(-m, dpp_move<0x150 + JC>(a[c]), a[c]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = fma(-m, dpp_move<0x150 + JC>(e[k]), e[k]);
+    diag_tile_steps<JC + 1>(a, e, ipown, r, fail);
+  }
+}
 
 // Sum of a window's chunk partials, spread over the chip: launched ahead of k_reduced_solve when a window has many chunks
 // (a single window is cut into ~50 so that its sweeps fill the CUs; one workgroup reading all of them is bound by the
@@ -772,6 +820,7 @@ __global__ __launch_bounds__(256, 4) void k_reduced_solve(BatchPtrs p, Policy po
   const long long slab0 = presummed ? (long long)w * p.slab_sum_stride : (wd.nchunks > 0 ? p.chunks[wd.chunk_off].slab_off : 0);
   const long long sstride = (long long)nsys_slab + kSlabScalars;
   const int nchunks = presummed ? 1 : wd.nchunks;
+  const unsigned short* smap = p.sys_map + wd.map_off;
   if (mfma_slab) {
     // The matrix-core sweep leaves everything in RAW camera coordinates (J_c' = [tau | gP]: no SO(3) left Jacobian, no
     // Jacobi scale).  (1) camera records: D' = J_c'^T J_c' (diagonal blocks), b', g'
@@ -937,26 +986,8 @@ __global__ __launch_bounds__(256, 4) void k_reduced_solve(BatchPtrs p, Policy po
     for (int e = 0; e < 8; ++e) {
       const int q = q0 + 256 * e;
       if (q >= nsys) continue;
-      const double s = acc8[e];
-      if (q < ncf * kCamAcc) {
-        const int cf = q / kCamAcc, ee = q - cf * kCamAcc;
-        if (ee < kRecB) {
-          const int a = ee >= 15 ? 5 : ee >= 10 ? 4 : ee >= 6 ? 3 : ee >= 3 ? 2 : ee >= 1 ? 1 : 0;
-          A[(6 * cf + a) * ld + 6 * cf + (ee - tri_index(a, 0))] = s;
-        } else {
-          const int v2 = (ee - kRecB) / 6, a = (ee - kRecB) - 6 * v2;      // 0 = b, 1 = g, 2 = hdiag
-          bvec[v2 * N + 6 * cf + a] = s;
-        }
-      } else {
-        const int pq = q - ncf * kCamAcc, pr = pq / kPairAcc, ee = pq - pr * kPairAcc;
-        if (ee < 36) {
-          int cj = (int)((sqrt(8.0 * pr + 1.0) + 1.0) * 0.5);
-          while ((cj * (cj - 1)) / 2 > pr) --cj;
-          while (((cj + 1) * cj) / 2 <= pr) ++cj;
-          const int ci = pr - (cj * (cj - 1)) / 2;
-          A[(6 * cj + ee / 6) * ld + 6 * ci + (ee % 6)] = s;
-        }
-      }
+      const unsigned off = smap[q];                   // where the entry lives in A | b | g | hdiag (host-built, sys_map_build)
+      if (off != 0xFFFFu) smem[off] = acc8[e];
     }
   }
   }
@@ -1086,48 +1117,31 @@ __global__ __launch_bounds__(256, 4) void k_reduced_solve(BatchPtrs p, Policy po
   const int er = tid >> 4, ec = tid & 15;       // this thread's element of a 16x16 tile
   for (int kb = 0; kb < nt; ++kb) {
     double* D = A + (16 * kb) * ld + 16 * kb;   // diagonal tile
-    // (a)+(b) diagonal tile in the registers of wave 0: lane (q, c) holds rows 4q..4q+3 of column c of the
-    // SYMMETRIC tile (both triangles are maintained, so the multiplier of a lane's own column is an element of
-    // the pivot row) and of the identity the same row operations turn into L^-1.  Right-looking Cholesky,
-    // 16 steps; per step seven wave shuffles, all reading the state before the step: one round trip.
+    // (a)+(b) diagonal tile in the registers of wave 0.  Lane r of every 16-lane row holds ROW r of the symmetric tile
+    // (a[16], the four rows of the wave carry the same values) and four columns of row r of the identity that the same
+    // row operations turn into L^-1 (row group g = lane >> 4 owns columns 4g .. 4g+3).  Elimination form of the
+    // right-looking Cholesky, 16 steps: the pivot row reaches the lanes through DPP row_newbcast (VALU moves, no LDS round
+    // trip on the chain), row r > jc takes  a_r -= (a_r[jc] / piv) a_jc,  e_r -= (a_r[jc] / piv) e_jc  (one fma per
+    // element), column jc becomes L[., jc] = a[jc] / sqrt(piv); the rows of L^-1 get their 1 / L[r][r] at the end.
     if (wave == 0) {
-      const int c = lane & 15, q = lane >> 4;
-      double a[4], e[4];
+      const int r = lane & 15, g = lane >> 4;
+      double a[16], e[4], ipown = 1.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = (r >= c) ? D[r * ld + c] : D[c * ld + r];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = (r == 4 * g + k) ? 1.0 : 0.0;
+      diag_tile_steps<0>(a, e, ipown, r, fail);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int r = 4 * q + k;
-        a[k] = (r >= c) ? D[r * ld + c] : D[c * ld + r];
-        e[k] = (r == c) ? 1.0 : 0.0;
-      }
-#pragma unroll
-      for (int jc = 0; jc < 16; ++jc) {
-        const int qj = jc >> 2, kj = jc & 3;                   // compile-time after unrolling
-        const double piv = __shfl(a[kj], 16 * qj + jc);
-        const double arow_c = __shfl(a[kj], 16 * qj + c);       // A[jc][c] = A[c][jc]
-        const double erow_c = __shfl(e[kj], 16 * qj + c);       // E[jc][c]
-        double lrow[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lrow[k] = __shfl(a[k], (lane & 48) | jc);   // A[4q+k][jc]
-        const bool okp = piv > 0.0 && isfinite(piv);
-        if (!okp) fail = 1;
-        const double ip = okp ? inv_sqrt<double>(piv) : 1.0;    // v_rsq_f64 + refinement: no sqrt, no divide on the chain
-        const double lcown = arow_c * ip, ej = erow_c * ip;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int r = 4 * q + k;
-          const double lr = lrow[k] * ip;                       // L[r][jc]
-          if (c == jc) a[k] = (r > jc) ? lr : (r == jc ? (okp ? piv * ip : 1.0) : a[k]);
-          else if (r > jc && c > jc) a[k] -= lr * lcown;
-          if (r == jc) e[k] = ej;
-          else if (r > jc) e[k] -= lr * ej;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int r = 4 * q + k;
-        if (r >= c) D[r * ld + c] = a[k];             // L
-        if (r > c) D[c * ld + r] = e[k];              // L^-1 (strictly lower part), transposed into the upper triangle
-        if (r == c) ivec[16 * kb + r] = e[k];         // its diagonal
+        const int c = 4 * g + k;
+        double av = a[k];                                                  // a[] is indexed with compile-time constants only
+        if (g == 1) av = a[4 + k];
+        if (g == 2) av = a[8 + k];
+        if (g == 3) av = a[12 + k];
+        if (c <= r) D[r * ld + c] = av;                                   // L
+        const double ev = e[k] * ipown;
+        if (c < r) D[c * ld + r] = ev;                                    // L^-1 (strictly lower part), transposed into the upper triangle
+        if (c == r) ivec[16 * kb + r] = ev;                               // its diagonal
       }
     }
     __syncthreads();

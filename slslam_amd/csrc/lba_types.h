@@ -34,7 +34,7 @@ struct WinDesc {
   int sys_off;            // offset (doubles) of this window's y_c vector
   int nfree_params;       // 6 Cf + 4 (free lines with >= 1 kept block)
   int nkept;              // residual blocks in the reduced program
-  int pad;
+  int map_off;            // this window's table in BatchPtrs.sys_map (entry of a chunk partial -> place in the reduced solve's LDS image)
 };
 
 // A tile is one 64-lane pass over a run of consecutive (sorted) lines.  Every line owns a run of
@@ -129,6 +129,7 @@ struct BatchPtrs {
   double* slab;               // linearise/Schur partials
   double* slab_sum;           // [nwin][slab_sum_stride] per-window sum of the chunk partials (k_slab_reduce), nullptr when unused
   long long slab_sum_stride;
+  const unsigned short* sys_map;   // per distinct n: chunk-partial entry -> place in the reduced solve's LDS image (WinDesc.map_off)
   double* bs_part;            // [nchunk][kBsStride]
   double* cost_part;          // [nchunk]
   double* ysys;               // y_c per window (sys_off)
