@@ -1,0 +1,77 @@
+// slslam_amd/csrc/dense_tile.h - Cholesky of one 16 x 16 diagonal tile in the registers of a wave (gfx950).
+//
+// Shared by the reduced camera solve of the line bundle adjustment (k_reduced_solve, lba_kernels.h) and the blocked
+// Cholesky of the pose-graph path (k_po_potrf_diag, po_kernels.h): both replace the dense factorisations Ceres' linear
+// solvers do inside ceres::Solve (reference src/lba_problem.cpp:99-110, src/po_problem.cpp:79-85 choose them).
+//
+// Lane r of every 16-lane row of the wave holds ROW r of the symmetric tile (a[16]; the four rows of the wave carry the
+// same values) and four columns of row r of the identity that the same row operations turn into L^-1 (row group
+// g = lane >> 4 owns columns 4g .. 4g+3).  Elimination form of the right-looking Cholesky, 16 steps: the pivot row reaches
+// the lanes through DPP row_newbcast (VALU moves: no LDS round trip on the dependent chain), row r > j takes
+//   a_r -= (a_r[j] / piv) a_j,   e_r -= (a_r[j] / piv) e_j        (one fma per element),
+// column j becomes L[., j] = a[j] / sqrt(piv); the rows of L^-1 get their 1 / L[r][r] (returned in ipown) at the end.
+#ifndef SLSLAM_DENSE_TILE_H_
+#define SLSLAM_DENSE_TILE_H_
+
+#include <hip/hip_runtime.h>
+
+namespace slslam {
+
+// lane J of every 16-lane row -> all lanes of the row
+template <int J>
+__device__ __forceinline__ double tile_bcast(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + J, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + J, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int J>
+__device__ __forceinline__ float tile_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + J, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double tile_rsqrt(double x) { return rsqrt(x); }      // v_rsq_f64 + refinement: no sqrt, no divide on the chain
+__device__ __forceinline__ float tile_rsqrt(float x) { return rsqrtf(x); }
+
+template <int JC, typename T>
+__device__ __forceinline__ void diag_tile_steps(T (&a)[16], T (&e)[4], T& ipown, int r, int& fail) {
+  if constexpr (JC < 16) {
+    const T piv = tile_bcast<JC>(a[JC]);
+    const bool okp = piv > T(0) && isfinite(piv);
+    if (!okp) fail = 1;
+    const T ip = okp ? tile_rsqrt(piv) : T(1);
+    T m = a[JC] * (ip * ip);
+    a[JC] *= ip;                                                         // L[r][JC] for r >= JC
+    m = (r > JC) ? m : T(0);
+    ipown = (r == JC) ? ip : ipown;
+#pragma unroll
+    for (int c = JC + 1; c < 16; ++c) a[c] = fma(-m, tile_bcast<JC>(a[c]), a[c]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = fma(-m, tile_bcast<JC>(e[k]), e[k]);
+    diag_tile_steps<JC + 1, T>(a, e, ipown, r, fail);
+  }
+}
+
+// The whole tile: D points at its (0, 0) element in LDS (leading dimension ld, LOWER triangle valid on entry).  On exit the
+// lower triangle holds L; the inverse goes where `put_inverse(row, col, value)` sends it (col <= row).  One full wave.
+template <typename T, typename PutInv>
+__device__ __forceinline__ void diag_tile_factor(T* D, int ld, int lane, int& fail, PutInv put_inverse) {
+  const int r = lane & 15, g = lane >> 4;
+  T a[16], e[4], ipown = T(1);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) a[c] = (r >= c) ? D[r * ld + c] : D[c * ld + r];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) e[k] = (r == 4 * g + k) ? T(1) : T(0);
+  diag_tile_steps<0, T>(a, e, ipown, r, fail);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * g + k;
+    T av = a[k];                                                          // a[] is indexed with compile-time constants only
+    if (g == 1) av = a[4 + k];
+    if (g == 2) av = a[8 + k];
+    if (g == 3) av = a[12 + k];
+    if (c <= r) { D[r * ld + c] = av; put_inverse(r, c, e[k] * ipown); }
+  }
+}
+
+}  // namespace slslam
+#endif

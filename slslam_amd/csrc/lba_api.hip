@@ -657,7 +657,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
             LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)(tb * (tb + 1) / 2)), blk256, 0, s, pp, pp.H, (const double*)(linv + (size_t)bk * kNB * kNB), k0, 1));
           }
         }
-        LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), blk256, 0, s, pp, (const double*)pp.H, (const double*)linv));
+        LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(1024), 0, s, pp, (const double*)pp.H, (const double*)linv));
       }
       LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_finish, g_win, blk64, 0, s, p, g));
       if (it == 0 && g.nobs > 0) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_rescale_cameras, g_obs256, blk256, 0, s, p, g));

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include "lba_math.h"
 #include "lba_types.h"
+#include "dense_tile.h"
 #include "lba_eliminate_mfma_maps.h"
 
 namespace slslam {
@@ -738,26 +739,6 @@ __device__ __forceinline__ unsigned long long solve_clock() {
   } while (0)
 
 
-// The 16 elimination steps of a diagonal tile of the reduced solve (see k_reduced_solve, step 3 (a)+(b)); JC is the step.
-template <int JC>
-__device__ __forceinline__ void diag_tile_steps(double (&a)[16], double (&e)[4], double& ipown, int r, int& fail) {
-  if constexpr (JC < 16) {
-    const double piv = dpp_move<0x150 + JC>(a[JC]);                      // row_newbcast: lane JC of the row to all 16 lanes
-    const bool okp = piv > 0.0 && isfinite(piv);
-    if (!okp) fail = 1;
-    const double ip = okp ? inv_sqrt<double>(piv) : 1.0;                 // v_rsq_f64 + refinement: no sqrt, no divide on the chain
-    double m = a[JC] * (ip * ip);
-    a[JC] *= ip;                                                         // L[r][JC] for r >= JC
-    m = (r > JC) ? m : 0.0;
-    ipown = (r == JC) ? ip : ipown;
-#pragma unroll
-    for (int c = JC + 1; c < 16; ++c) a[c] = fma(-m, dpp_move<0x150 + JC>(a[c]), a[c]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) e[k] = fma(-m, dpp_move<0x150 + JC>(e[k]), e[k]);
-    diag_tile_steps<JC + 1>(a, e, ipown, r, fail);
-  }
-}
-
 // Sum of a window's chunk partials, spread over the chip: launched ahead of k_reduced_solve when a window has many chunks
 // (a single window is cut into ~50 so that its sweeps fill the CUs; one workgroup reading all of them is bound by the
 // load bandwidth of its CU, ~10 B per cycle: 0.8 MB = 30 us on the latency path of every iteration).  One thread per entry,
@@ -1117,33 +1098,12 @@ __global__ __launch_bounds__(256, 4) void k_reduced_solve(BatchPtrs p, Policy po
   const int er = tid >> 4, ec = tid & 15;       // this thread's element of a 16x16 tile
   for (int kb = 0; kb < nt; ++kb) {
     double* D = A + (16 * kb) * ld + 16 * kb;   // diagonal tile
-    // (a)+(b) diagonal tile in the registers of wave 0.  Lane r of every 16-lane row holds ROW r of the symmetric tile
-    // (a[16], the four rows of the wave carry the same values) and four columns of row r of the identity that the same
-    // row operations turn into L^-1 (row group g = lane >> 4 owns columns 4g .. 4g+3).  Elimination form of the
-    // right-looking Cholesky, 16 steps: the pivot row reaches the lanes through DPP row_newbcast (VALU moves, no LDS round
-    // trip on the chain), row r > jc takes  a_r -= (a_r[jc] / piv) a_jc,  e_r -= (a_r[jc] / piv) e_jc  (one fma per
-    // element), column jc becomes L[., jc] = a[jc] / sqrt(piv); the rows of L^-1 get their 1 / L[r][r] at the end.
-    if (wave == 0) {
-      const int r = lane & 15, g = lane >> 4;
-      double a[16], e[4], ipown = 1.0;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = (r >= c) ? D[r * ld + c] : D[c * ld + r];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) e[k] = (r == 4 * g + k) ? 1.0 : 0.0;
-      diag_tile_steps<0>(a, e, ipown, r, fail);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = 4 * g + k;
-        double av = a[k];                                                  // a[] is indexed with compile-time constants only
-        if (g == 1) av = a[4 + k];
-        if (g == 2) av = a[8 + k];
-        if (g == 3) av = a[12 + k];
-        if (c <= r) D[r * ld + c] = av;                                   // L
-        const double ev = e[k] * ipown;
-        if (c < r) D[c * ld + r] = ev;                                    // L^-1 (strictly lower part), transposed into the upper triangle
-        if (c == r) ivec[16 * kb + r] = ev;                               // its diagonal
-      }
-    }
+    // (a)+(b) diagonal tile in the registers of wave 0 (dense_tile.h): L into the tile's lower triangle, L^-1 strictly
+    // lower part transposed into the tile's upper triangle, its diagonal into ivec
+    if (wave == 0)
+      diag_tile_factor<double>(D, ld, lane, fail, [&](int r, int c, double v) {
+        if (c < r) D[c * ld + r] = v; else ivec[16 * kb + r] = v;
+      });
     __syncthreads();
     SLS_SOLVE_STAMP(3);
     // (c) panel: L(i,kb) = A(i,kb) Linv^T, one tile per wave at a time

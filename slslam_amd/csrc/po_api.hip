@@ -285,7 +285,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
           hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, pj, pj.H, (const double*)(d_linv + (size_t)bk * kNB * kNB), k0, 1);
         }
       }
-      if (nj > 0) hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(256), 0, 0, pj, (const double*)pj.H, (const double*)d_linv);
+      if (nj > 0) hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(1024), 0, 0, pj, (const double*)pj.H, (const double*)d_linv);
       if (!chains.empty()) hipLaunchKernelGGL(k_po_chain_backsub, dim3((unsigned)chains.size()), dim3(64), 0, 0, p, (const PoChain*)d_chains);
     }
     for (int bk = 0; bk < (structured ? 0 : nblk); ++bk) {
@@ -307,8 +307,8 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
       }
     }
     if (structured) { /* solved above */ }
-    else if (f32) hipLaunchKernelGGL(k_po_trisolve<float>, dim3(1), dim3(256), 0, 0, p, (const float*)d_Hf, (const float*)d_linvf);
-    else hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(256), 0, 0, p, (const double*)p.H, (const double*)d_linv);
+    else if (f32) hipLaunchKernelGGL(k_po_trisolve<float>, dim3(1), dim3(1024), 0, 0, p, (const float*)d_Hf, (const float*)d_linvf);
+    else hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(1024), 0, 0, p, (const double*)p.H, (const double*)d_linv);
     stamp();
     hipLaunchKernelGGL(k_po_candidate, dim3(1), dim3(256), 0, 0, p);
     hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 1);

@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include "lba_types.h"
+#include "dense_tile.h"
 
 namespace slslam {
 
@@ -302,56 +303,89 @@ __global__ __launch_bounds__(256) void k_po_to_f32(PoPtrs p, float* Hf) {
     Hf[q] = (float)p.H[q];
 }
 
-// Factor the diagonal block A[k0:k0+nb, k0:k0+nb] in LDS, write L11 back and its inverse to linv.
 #endif
+// Factor the diagonal block A[k0:k0+nb, k0:k0+nb] in LDS, write L11 back and its inverse to linv.  One workgroup of four
+// waves, the 64 x 64 block as 4 x 4 tiles of 16: per tile column the diagonal tile is factored in the registers of wave 0
+// (dense_tile.h: row per lane, DPP broadcasts, the tile's inverse from the same sweep), the panel below it
+// (L_ik = A_ik X_kk^T) and the trailing update run on the 16x16x4 MFMA of T, one tile per wave at a time.  The inverse of
+// the whole block (TRSM of the panel kernel and the substitution use it as a matrix) is then assembled tile by tile,
+// X_ij = -X_ii sum_k L_ik X_kj, wave <-> tile column, the partial sums staged in the block's unused upper triangle.
 template <typename T>
 __global__ __launch_bounds__(256) void k_po_potrf_diag(PoPtrs p, T* A, T* linv, int k0) {
   if (p.st->status != kRunning) return;
   __shared__ T Tt[kNB * kLdT];
   __shared__ T Li[kNB * kLdT];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nb = min((int)kNB, p.n - k0);
   for (int q = tid; q < kNB * kNB; q += 256) {
     const int r = q / kNB, c = q - r * kNB;
     T v = (r == c) ? T(1) : T(0);
     if (r < nb && c <= r) v = A[(long long)(k0 + r) * p.ld + k0 + c];
     Tt[r * kLdT + c] = (c <= r) ? v : T(0);
+    Li[r * kLdT + c] = T(0);
   }
   __syncthreads();
   int fail = 0;
-  for (int j = 0; j < kNB; ++j) {
-    T s = T(0);
-    const int r = tid;
-    if (r < kNB && r >= j) {
-      s = Tt[r * kLdT + j];
-      for (int k = 0; k < j; ++k) s -= Tt[r * kLdT + k] * Tt[j * kLdT + k];
+  const int am = lane & 15, ak = lane >> 4, col = lane & 15;      // MFMA operand / result coordinates of this lane
+  for (int kb = 0; kb < 4; ++kb) {
+    T* D = Tt + (16 * kb) * kLdT + 16 * kb;
+    T* X = Li + (16 * kb) * kLdT + 16 * kb;
+    if (wave == 0) diag_tile_factor<T>(D, kLdT, lane, fail, [&](int r, int c, T v) { X[r * kLdT + c] = v; });
+    __syncthreads();
+    for (int i = kb + 1 + wave; i < 4; i += 4) {                  // panel: L(i,kb) = A(i,kb) X_kk^T
+      T* P = Tt + (16 * i) * kLdT + 16 * kb;
+      typename Mfma<T>::acc_t acc = Mfma<T>::zero();
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc = Mfma<T>::mac(P[am * kLdT + 4 * s4 + ak], X[am * kLdT + 4 * s4 + ak], acc);   // B[k][n] = X[n][k]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[Mfma<T>::row(lane, q) * kLdT + col] = acc[q];
     }
     __syncthreads();
-    if (r == j) { if (!(s > T(0)) || !isfinite(s)) { s = T(1); fail = 1; } Tt[j * kLdT + j] = sqrt(s); }
-    __syncthreads();
-    const T dj = Tt[j * kLdT + j];
-    if (r < kNB && r > j) Tt[r * kLdT + j] = s / dj;
+    int tile = 0;                                                 // trailing update: A(i,j) -= L(i,kb) L(j,kb)^T, kb < j <= i
+    for (int i = kb + 1; i < 4; ++i)
+      for (int j = kb + 1; j <= i; ++j, ++tile) {
+        if ((tile & 3) != wave) continue;
+        T* C = Tt + (16 * i) * kLdT + 16 * j;
+        const T* Pi = Tt + (16 * i) * kLdT + 16 * kb;
+        const T* Pj = Tt + (16 * j) * kLdT + 16 * kb;
+        typename Mfma<T>::acc_t acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = C[Mfma<T>::row(lane, q) * kLdT + col];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = Mfma<T>::mac(-Pi[am * kLdT + 4 * s4 + ak], Pj[am * kLdT + 4 * s4 + ak], acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[Mfma<T>::row(lane, q) * kLdT + col] = acc[q];
+      }
     __syncthreads();
   }
   if (__syncthreads_or(fail)) { if (tid == 0) p.flags[0] = 1; }
-  if (tid < kNB) {     // inverse of the lower-triangular block: thread c solves L x = e_c.
-    // The column lives in registers (fully unrolled, static indices); rows of L are LDS broadcasts.
-    const int c = tid;
-    T x[kNB];
+  // inverse of the block: wave j assembles tile column j below the diagonal, top down (X_ij needs X_kj, j <= k < i)
+  if (wave < 3) {
+    const int j = wave;
+    for (int i = j + 1; i < 4; ++i) {
+      typename Mfma<T>::acc_t acc = Mfma<T>::zero();
+      for (int k = j; k < i; ++k) {
+        const T* Lik = Tt + (16 * i) * kLdT + 16 * k;
+        const T* Xkj = Li + (16 * k) * kLdT + 16 * j;
 #pragma unroll
-    for (int r = 0; r < kNB; ++r) {
-      T s = (r == c) ? T(1) : T(0);
+        for (int s4 = 0; s4 < 4; ++s4) acc = Mfma<T>::mac(Lik[am * kLdT + 4 * s4 + ak], Xkj[(4 * s4 + ak) * kLdT + am], acc);   // B[k][n] = X_kj[k][n]
+      }
+      T* S = Tt + (16 * j) * kLdT + 16 * i;                       // scratch: tile (j, i) of the block's upper triangle
 #pragma unroll
-      for (int k = 0; k < r; ++k) s -= Tt[r * kLdT + k] * x[k];
-      x[r] = s / Tt[r * kLdT + r];
+      for (int q = 0; q < 4; ++q) S[Mfma<T>::row(lane, q) * kLdT + col] = acc[q];
+      const T* Xii = Li + (16 * i) * kLdT + 16 * i;
+      typename Mfma<T>::acc_t acc2 = Mfma<T>::zero();
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc2 = Mfma<T>::mac(-Xii[am * kLdT + 4 * s4 + ak], S[(4 * s4 + ak) * kLdT + am], acc2);
+      T* Xij = Li + (16 * i) * kLdT + 16 * j;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Xij[Mfma<T>::row(lane, q) * kLdT + col] = acc2[q];
     }
-#pragma unroll
-    for (int r = 0; r < kNB; ++r) Li[r * kLdT + c] = x[r];
   }
   __syncthreads();
   for (int q = tid; q < kNB * kNB; q += 256) {
     const int r = q / kNB, c = q - r * kNB;
-    linv[q] = Li[r * kLdT + c];
+    linv[q] = (c <= r) ? Li[r * kLdT + c] : T(0);
     if (r < nb && c <= r) A[(long long)(k0 + r) * p.ld + k0 + c] = Tt[r * kLdT + c];
   }
 }
@@ -419,18 +453,18 @@ __global__ __launch_bounds__(256) void k_po_panel_update(PoPtrs p, T* A, const T
 // linv_all (one 64x64 block per block column, kept by k_po_potrf_diag): every step is a parallel
 // matrix-vector product - no serial pivot loop.  rhs / solution stay fp64.  One workgroup.
 template <typename T>
-__global__ __launch_bounds__(256) void k_po_trisolve(PoPtrs p, const T* A, const T* linv_all) {
+__global__ __launch_bounds__(1024) void k_po_trisolve(PoPtrs p, const T* A, const T* linv_all) {
   if (p.st->status != kRunning) return;
   __shared__ double yb[kNB], yn[kNB];
   __shared__ T Ls[kNB * (kNB + 1)];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;     // 1024 threads: the matrix-vector updates are bound by loads in flight
   const int n = p.n;
   const int nblk = (n + kNB - 1) / kNB;
   // forward: y_k <- inv(L_kk) y_k ;  y_r -= L[r, k] y_k for the rows below
   for (int bk = 0; bk < nblk; ++bk) {
     const int k0 = bk * kNB, nb = min((int)kNB, n - k0);
     const T* Li = linv_all + (size_t)bk * kNB * kNB;
-    for (int q = tid; q < kNB * kNB; q += 256) Ls[(q / kNB) * (kNB + 1) + (q % kNB)] = Li[q];    // coalesced
+    for (int q = tid; q < kNB * kNB; q += nthr) Ls[(q / kNB) * (kNB + 1) + (q % kNB)] = Li[q];    // coalesced
     if (tid < kNB) yb[tid] = tid < nb ? p.y[k0 + tid] : 0.0;
     __syncthreads();
     if (tid < nb) {
@@ -440,7 +474,7 @@ __global__ __launch_bounds__(256) void k_po_trisolve(PoPtrs p, const T* A, const
       p.y[k0 + tid] = s;
     }
     __syncthreads();
-    for (int r = k0 + nb + tid; r < n; r += 256) {
+    for (int r = k0 + nb + tid; r < n; r += nthr) {
       double s = 0.0;
       for (int j = 0; j < nb; ++j) s += (double)A[(long long)r * p.ld + k0 + j] * yn[j];
       p.y[r] -= s;
@@ -452,7 +486,7 @@ __global__ __launch_bounds__(256) void k_po_trisolve(PoPtrs p, const T* A, const
     const int k0 = bk * kNB, nb = min((int)kNB, n - k0);
     const T* Li = linv_all + (size_t)bk * kNB * kNB;
     __syncthreads();
-    for (int q = tid; q < kNB * kNB; q += 256) Ls[(q / kNB) * (kNB + 1) + (q % kNB)] = Li[q];
+    for (int q = tid; q < kNB * kNB; q += nthr) Ls[(q / kNB) * (kNB + 1) + (q % kNB)] = Li[q];
     if (tid < kNB) yb[tid] = tid < nb ? p.y[k0 + tid] : 0.0;
     __syncthreads();
     if (tid < nb) {
@@ -462,7 +496,7 @@ __global__ __launch_bounds__(256) void k_po_trisolve(PoPtrs p, const T* A, const
       p.y[k0 + tid] = s;
     }
     __syncthreads();
-    for (int r = tid; r < k0; r += 256) {
+    for (int r = tid; r < k0; r += nthr) {
       double s = 0.0;
       for (int j = 0; j < nb; ++j) s += (double)A[(long long)(k0 + j) * p.ld + r] * yn[j];
       p.y[r] -= s;

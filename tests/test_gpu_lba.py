@@ -17,11 +17,20 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # at the same rate (tests/test_oracle.py::test_dense_and_schur_linear_solvers_agree), so the
 # tolerance widens with the iteration index.  Stated tolerances: cost rel 1e-13 (it 0),
 # 1e-10 (it 1), 1e-6 (later); final parameters 1e-5; final cost rel 1e-7.
+#
+# MEASURED (tools/parity_study.py on the MI355X, profiles/round2_parity_study.txt; the eleven shapes of
+# test_solve_trace_matches_oracle, test_long_and_short_line_runs and the 2000-line bench window): over ALL iterations
+# cost <= 1.1e-8, radius <= 2.8e-7, step norm <= 4.1e-8, gain ratio <= 1.9e-6 (relative); final camera parameters
+# <= 7.4e-11, final line parameters <= 4.5e-8 with a median of 3.5e-11 - the tail is a handful of depth-degenerate lines
+# per window (seen under a few degrees of parallax: an eigenvalue of their 4x4 block ~1e-8 of the others, the lines
+# profiles/round2_rejection_study.txt names), and the oracle's own dense-vs-Schur runs differ MORE on the same lines
+# (1.1e-7).  TIGHT below = those figures with a margin of ~30: asserted on every iteration of the studied shapes.
 REL = 1e-9
 REL_BY_ITER = {0: 1e-13, 1: 1e-10}
+TIGHT = dict(cost=3e-7, radius=1e-5, step_norm=2e-6, rho=5e-5, cam=3e-9, line=2e-6)
 
 
-def _assert_trace_parity(t_ref, t_hip, n=None):
+def _assert_trace_parity(t_ref, t_hip, n=None, tight=False):
     assert len(t_ref) == len(t_hip)
     for a, b in list(zip(t_ref, t_hip))[:n]:
         assert a["iteration"] == b["iteration"]
@@ -30,6 +39,20 @@ def _assert_trace_parity(t_ref, t_hip, n=None):
         assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-6 * a["trust_region_radius"]
         assert abs(a["step_norm"] - b["step_norm"]) <= 1e-5 * (a["step_norm"] + 1e-12)
         assert abs(a["relative_decrease"] - b["relative_decrease"]) <= 1e-4 * (abs(a["relative_decrease"]) + 1e-3)
+    if tight:                                         # every iteration, measured tolerances
+        for a, b in zip(t_ref, t_hip):
+            assert a["step_is_successful"] == b["step_is_successful"] and a["step_is_valid"] == b["step_is_valid"]
+            assert abs(a["cost"] - b["cost"]) <= TIGHT["cost"] * abs(a["cost"])
+            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= TIGHT["radius"] * a["trust_region_radius"]
+            assert abs(a["step_norm"] - b["step_norm"]) <= TIGHT["step_norm"] * (a["step_norm"] + 1e-12)
+            assert abs(a["relative_decrease"] - b["relative_decrease"]) <= TIGHT["rho"] * (abs(a["relative_decrease"]) + 1e-3)
+
+
+def _assert_params_parity(w, x_ref, x_hip):
+    """Final parameters by class: camera poses to 3e-9, line parameters to 2e-6 (see the measured figures above)."""
+    nc = 6 * int(w["num_cameras"])
+    assert np.abs(x_ref[:nc] - x_hip[:nc]).max() <= TIGHT["cam"]
+    assert np.abs(x_ref[nc:] - x_hip[nc:]).max() <= TIGHT["line"]
 
 
 def _assert_summary_parity(s_ref, s_hip):
@@ -63,10 +86,10 @@ def test_solve_trace_matches_oracle(hip, oracle, seed, lines, kf, free):
     w = synth.make_window(seed, num_lines=lines, num_kf=kf, num_free=free)
     x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
     x1, s1, t1 = hip.lba_solve(w)
-    _assert_trace_parity(t0, t1, n=4)                  # the first iterations agree to round-off ...
+    _assert_trace_parity(t0, t1, n=4, tight=True)      # the first iterations agree to round-off ...
     _assert_summary_parity(s0, s1)
     # ... later ones inherit the conditioning of the problem (oracle dense-vs-Schur differ as much)
-    assert np.abs(x0 - x1).max() < 1e-5
+    _assert_params_parity(w, x0, x1)
     assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-7 * s0["final_cost"]
 
 
@@ -94,9 +117,9 @@ def test_long_and_short_line_runs(hip, oracle):
     for w in (long_w, short_w, mixed, full_w):
         x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
         x1, s1, t1 = hip.lba_solve(w)
-        _assert_trace_parity(t0, t1, n=3)
+        _assert_trace_parity(t0, t1, n=3, tight=True)
         _assert_summary_parity(s0, s1)
-        assert np.abs(x0 - x1).max() < 1e-5
+        _assert_params_parity(w, x0, x1)
 
 
 def test_windows_beyond_the_tiled_sweeps(hip, oracle):
@@ -329,9 +352,10 @@ def test_full_size_window_properties(hip, oracle):
     w = synth.make_window(1234, num_lines=2000)
     x1, s1, t1 = hip.lba_solve(w)
     x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
-    _assert_trace_parity(t0, t1, n=3)
+    _assert_trace_parity(t0, t1, n=3, tight=True)      # all 10 iterations: same accept / reject decisions, measured tolerances
+    _assert_params_parity(w, x0, x1)
     assert s0["num_successful_steps"] == s1["num_successful_steps"]
-    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-6 * s0["final_cost"]
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 3e-7 * s0["final_cost"]
     costs = [r["cost"] for r in t1]
     assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
     assert np.array_equal(x1[60:120], w["parameters"][60:120])           # the 10 fixed keyframes
@@ -343,7 +367,7 @@ def test_full_size_window_properties(hip, oracle):
     e1 = np.linalg.norm(synth.camera_centers(x1[:60]) - c_true, axis=1)
     assert np.sqrt((e1 ** 2).mean()) < np.sqrt((e0 ** 2).mean())
     eo = np.linalg.norm(synth.camera_centers(x1[:60]) - synth.camera_centers(x0[:60]), axis=1)
-    assert np.sqrt((eo ** 2).mean()) < 1e-6                              # trajectory RMS vs the oracle solve
+    assert np.sqrt((eo ** 2).mean()) < 1e-9                              # trajectory RMS vs the oracle solve (measured 1e-10 m)
 
 
 def test_batched_motion_only(hip, oracle):

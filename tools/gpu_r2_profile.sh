@@ -15,4 +15,16 @@ for C in FETCH_SIZE WRITE_SIZE; do
   python tools/rocpd_pmc.py $(ls gpurun_out/${TAG}_pmc_$C/*.db | head -1) >> gpurun_out/${TAG}_pmc.txt 2>&1
   rm -rf gpurun_out/${TAG}_pmc_$C
 done
+# pose graph (BASELINE config 5): kernel trace of the structured and the dense factorisation, matrix-core busy cycles of the dense one
+for V in structured dense; do
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_po_$V -o t -- python tools/po_prof.py $V > gpurun_out/${TAG}_po_$V.log 2>&1
+  python tools/rocpd_summary.py $(ls gpurun_out/${TAG}_po_$V/*.db | head -1) > gpurun_out/${TAG}_po_kernel_trace_$V.txt 2>&1
+  rm -rf gpurun_out/${TAG}_po_$V
+done
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 -d gpurun_out/${TAG}_po_pmc -o p -- python tools/po_prof.py dense > gpurun_out/${TAG}_po_pmc.log 2>&1
+python tools/rocpd_pmc.py $(ls gpurun_out/${TAG}_po_pmc/*.db | head -1) > gpurun_out/${TAG}_po_pmc.txt 2>&1
+rm -rf gpurun_out/${TAG}_po_pmc
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 -d gpurun_out/${TAG}_lba_mfma -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap-run --no-extra-configs > gpurun_out/${TAG}_lba_mfma.log 2>&1
+python tools/rocpd_pmc.py $(ls gpurun_out/${TAG}_lba_mfma/*.db | head -1) > gpurun_out/${TAG}_lba_mfma_pmc.txt 2>&1
+rm -rf gpurun_out/${TAG}_lba_mfma
 tail -3 gpurun_out/${TAG}_gputests.log; head -12 gpurun_out/${TAG}_kernel_trace.txt; grep -A1 "k_linearise_schur\|k_backsub" gpurun_out/${TAG}_pmc.txt; cut -c1-400 gpurun_out/${TAG}_bench.json
