@@ -27,4 +27,8 @@ rm -rf gpurun_out/${TAG}_po_pmc
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 -d gpurun_out/${TAG}_lba_mfma -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap-run --no-extra-configs > gpurun_out/${TAG}_lba_mfma.log 2>&1
 python tools/rocpd_pmc.py $(ls gpurun_out/${TAG}_lba_mfma/*.db | head -1) > gpurun_out/${TAG}_lba_mfma_pmc.txt 2>&1
 rm -rf gpurun_out/${TAG}_lba_mfma
+# the fp64 issue ceilings the roofline `binding` field quotes (tools/micro/mfma_f64_bench.hip, built by hipcc in-tree)
+[ -x tools/micro/lab/mfma_f64_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/micro/lab/mfma_f64_bench tools/micro/mfma_f64_bench.hip
+timeout 300 tools/micro/lab/mfma_f64_bench > gpurun_out/${TAG}_micro_fp64.txt 2>&1
+bash tools/gpu_r2_dist.sh > gpurun_out/${TAG}_dist_two_ranks.log 2>&1
 tail -3 gpurun_out/${TAG}_gputests.log; head -12 gpurun_out/${TAG}_kernel_trace.txt; grep -A1 "k_linearise_schur\|k_backsub" gpurun_out/${TAG}_pmc.txt; cut -c1-400 gpurun_out/${TAG}_bench.json
