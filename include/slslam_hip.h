@@ -32,7 +32,11 @@ enum {
 };
 
 /* Termination of one solve: mirrors ceres::Solver::Summary::termination_type of Ceres 1.7.
- * The reference never inspects it (src/slam.cpp:663,944,1293); reported for diagnostics. */
+ * The reference never inspects it (src/slam.cpp:663,944,1293); reported for diagnostics.
+ * Known deviation: when max_num_iterations ends a solve right after an ACCEPTED step, Ceres 1.7 still evaluates the
+ * gradient at the new point inside that iteration and can report GRADIENT_TOLERANCE; here the gradient of a point is
+ * evaluated by the next linearisation, which never comes, so such a solve reports NO_CONVERGENCE and its last trace
+ * record keeps the previous point's gradient_max_norm.  Parameters, costs and step counts are the same. */
 enum {
   SLSLAM_NO_CONVERGENCE = 0,       /* max_num_iterations reached */
   SLSLAM_GRADIENT_TOLERANCE = 1,
