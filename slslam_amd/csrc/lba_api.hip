@@ -753,7 +753,7 @@ extern "C" int slslam_lba_batch_reset(slslam_lba_batch* b, void* stream) {
   if (!b->finalized) return SLSLAM_ERR_STATE;
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
-  const long long total = (long long)b->ncam + b->nline + b->ptrs.nwin;
+  const long long total = 6LL * b->ncam + 4LL * b->nline + b->ptrs.nwin;      // one thread per parameter / per window state
   if (total > 0)
     hipLaunchKernelGGL(k_reset, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b->ptrs, b->pol);
   HIP_TRY(hipGetLastError());

@@ -1794,16 +1794,20 @@ __global__ __launch_bounds__(64) void k_debug_linearise(BatchPtrs p, Policy pol,
 // Restores the initial parameters and LM state of every window (repeated solves of the same
 // inputs).  lane <-> parameter block / window.
 __global__ __launch_bounds__(256) void k_reset(BatchPtrs p, Policy pol) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < p.ncam) {
-    double* x = p.cam_x + (long long)i * 2 * kCamRec;
-    for (int a = 0; a < 6; ++a) { x[a] = p.cam_x0[(long long)i * 6 + a]; x[kCamRec + a] = x[a]; }
-  } else if (i < p.ncam + p.nline) {
-    const int ls = i - p.ncam;
-    double* x = p.line_x + (long long)ls * 2 * kLineRec;
-    for (int a = 0; a < 4; ++a) { x[a] = p.line_u0[(long long)ls * 4 + a]; x[kLineRec + a] = x[a]; }
-  } else if (i < p.ncam + p.nline + p.nwin) {
-    LMState* st = p.state + (i - p.ncam - p.nline);
+  // thread <-> one parameter (both buffers), four threads per line / six per camera: coalesced reads, 32 / 48-byte runs written
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long ncp = 6LL * p.ncam, nlp = 4LL * p.nline;
+  if (i < nlp) {
+    const long long ls = i >> 2;
+    const int a = (int)(i & 3);
+    const double v = p.line_u0[i];
+    p.line_x[ls * 2 * kLineRec + a] = v; p.line_x[ls * 2 * kLineRec + kLineRec + a] = v;
+  } else if (i < nlp + ncp) {
+    const long long q = i - nlp, c = q / 6;
+    const double v = p.cam_x0[q];
+    p.cam_x[c * 2 * kCamRec + (q - 6 * c)] = v; p.cam_x[c * 2 * kCamRec + kCamRec + (q - 6 * c)] = v;
+  } else if (i < nlp + ncp + p.nwin) {
+    LMState* st = p.state + (i - nlp - ncp);
     LMState z;
     z.radius = pol.initial_radius; z.decrease_factor = 2.0; z.cost = 0; z.x_norm = 0; z.fixed_cost = 0;
     z.initial_cost = 0; z.min_cost = 0; z.abs_grad_tol = 0; z.grad_max = 0; z.cam_model = 0; z.cam_dn2 = 0; z.cam_xn2 = 0;
