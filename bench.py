@@ -375,7 +375,7 @@ def main():
             # one launch covers the windows of ONE stream's batch
             bytes_launch = algorithmic_bytes_linearise(counts) / ns
             achieved = bytes_launch / (ms / n * 1e-3) / 1e9
-            traffic = None
+            traffic, tj = None, {}
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 try:
@@ -403,8 +403,14 @@ def main():
             if bn > 0:
                 bb = algorithmic_bytes_backsub(counts) / ns
                 ach = bb / (bms / bn * 1e-3) / 1e9
+                btraffic = None
+                try:
+                    if tj.get("lines") == args.lines and "k_backsub" in tj:
+                        btraffic = tj["k_backsub"]["hbm_bytes_per_launch"] * (B / ns) / tj.get("windows")
+                except Exception:
+                    btraffic = None
                 out["roofline_backsub"] = {"bound": "hbm", "kernel": "k_backsub", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bb,
+                                           "frac": ach / HBM_PEAK_GBS, "traffic": btraffic, "algorithmic_bytes_per_launch": bb,
                                            "avg_launch_ms": bms / bn, "launches": bn,
                                            "binding": "fp64 VALU issue at 2 waves/SIMD"}
             sms, sn = kt["reduced_solve"]
