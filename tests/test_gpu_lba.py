@@ -400,6 +400,11 @@ def test_randomised_shapes_against_oracle(hip, oracle):
     bad, worst = mod.run(60, seed=3, verbose=True)
     assert bad == 0
     assert worst["trace"] < 1e-6
+    # ... and 18 random windows beyond the tiled sweeps (65-90 keyframes, 21-45 free cameras, lines tracked through more than
+    # 64 keyframes; scrambled order, constant lines, loss on / off, iteration caps): the global-memory path
+    bad, worst = mod.run(18, seed=5, verbose=True, oversize=True)
+    assert bad == 0
+    assert worst["trace"] < 1e-6
 
 
 def test_one_shot_solves_reuse_their_device_block(hip, oracle):

@@ -12,7 +12,7 @@ from oracle import pyoracle as O     # noqa: E402  (developer tool: the oracle i
 
 
 
-def run(cases, seed=2026, verbose=True):
+def run(cases, seed=2026, verbose=True, oversize=False):
   rng = np.random.default_rng(seed)
   worst = {"cost": 0.0, "x": 0.0, "trace": 0.0}
   bad = 0
@@ -22,10 +22,17 @@ def run(cases, seed=2026, verbose=True):
       nl = int(rng.integers(3, 120))
       kw = dict(num_lines=nl, num_kf=nkf, num_free=nfree, noise_px=float(rng.choice([0.0, 0.3, 1.0, 3.0])),
                 mean_track=float(rng.choice([2.0, 5.0, 9.0, 30.0])))
+      if oversize:                      # windows beyond the tiled sweeps (lba_big.h): > 64 cameras, > 20 free, or lines tracked through > 64 keyframes
+          kind = case % 3
+          nkf = int(rng.integers(65, 91)) if kind == 0 else int(rng.integers(22, 64))
+          nfree = int(rng.integers(21, min(nkf, 45) + 1)) if kind == 1 else int(rng.integers(2, min(nkf, 20) + 1))
+          if kind == 2: nkf, nfree = int(rng.integers(66, 80)), int(rng.integers(2, 30))
+          nl = int(rng.integers(3, 70))
+          kw.update(num_lines=nl, num_kf=nkf, num_free=nfree, mean_track=float(rng.choice([9.0, 30.0, 200.0]) if kind != 2 else 300.0))
       if rng.random() < 0.15:
           kw["line_init"] = "triangulate"
       try:
-          if rng.random() < 0.12:        # the motion_only_ba shape (one-launch kernel): one free camera, constant lines
+          if not oversize and rng.random() < 0.12:        # the motion_only_ba shape (one-launch kernel): one free camera, constant lines
               w = synth.make_motion_only(1000 * (seed % 1000) + case, num_lines=nl, noise_px=kw["noise_px"])
               w["parameters"] = w["parameters"].copy()
               w["parameters"][:6] += rng.normal(0, 1.0, 6) * float(rng.choice([0.0, 0.01, 0.2]))
@@ -74,7 +81,7 @@ def run(cases, seed=2026, verbose=True):
 
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-    bad, worst = run(cases, int(os.environ.get("FUZZ_SEED", "2026")))
+    bad, worst = run(cases, int(os.environ.get("FUZZ_SEED", "2026")), oversize=bool(int(os.environ.get("FUZZ_OVERSIZE", "0"))))
     print("cases %d, hard failures %d, worst rel final-cost diff %.2e, worst |dx| %.2e, worst early-trace diff %.2e" % (
         cases, bad, worst["cost"], worst["x"], worst["trace"]))
     sys.exit(1 if bad else 0)
