@@ -370,20 +370,25 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
       for (int a = 0; a < 6; ++a) cam_x0.push_back(P.cam_x[6 * (size_t)c + a]);
       cam_cf.push_back(P.cam_cf[c]); cam_win.push_back(wi);
     }
-    for (int s = 0; s < P.L; ++s) {
-      for (int buf = 0; buf < 2; ++buf) {
-        for (int a = 0; a < 4; ++a) line_x.push_back(P.line_u[4 * (size_t)s + a]);
-        for (int a = 4; a < kLineRec; ++a) line_x.push_back(0.0);
-      }
-      for (int a = 0; a < 4; ++a) line_u0.push_back(P.line_u[4 * (size_t)s + a]);
-      line_ptr.push_back((int)obs_cursor + P.line_ptr[s]);
-      line_flags.push_back(P.line_flags[s]); line_win.push_back(wi); line_orig.push_back(P.line_order[s]);
+    {
+      const size_t l0 = line_x.size();
+      line_x.resize(l0 + (size_t)P.L * 2 * kLineRec, 0.0);              // both parameter buffers: (a, b, g, t) | sin/cos table (filled on the device)
+      double* lx = line_x.data() + l0;
+      for (int s = 0; s < P.L; ++s)
+        for (int buf = 0; buf < 2; ++buf)
+          for (int a = 0; a < 4; ++a) lx[((size_t)s * 2 + buf) * kLineRec + a] = P.line_u[4 * (size_t)s + a];
+      line_u0.insert(line_u0.end(), P.line_u.begin(), P.line_u.end());
+      const size_t p0 = line_ptr.size();
+      line_ptr.resize(p0 + (size_t)P.L);
+      for (int s = 0; s < P.L; ++s) line_ptr[p0 + s] = (int)obs_cursor + P.line_ptr[s];
+      line_flags.insert(line_flags.end(), P.line_flags.begin(), P.line_flags.end());
+      line_win.insert(line_win.end(), (size_t)P.L, wi);
+      line_orig.insert(line_orig.end(), P.line_order.begin(), P.line_order.end());
     }
-    for (int o = 0; o < P.M; ++o) {
-      ob_cam.push_back(P.ob_cam[o]); ob_orig.push_back(P.ob_orig[o]);
-      for (int q = 0; q < 8; ++q)   // planes of (x,y) pairs: ob[((q/2) * nobs + o) * 2 + (q & 1)]
-        ob[((size_t)(q >> 1) * (size_t)nobs + (size_t)(obs_cursor + o)) * 2 + (q & 1)] = P.ob[(size_t)q * P.M + o];
-    }
+    ob_cam.insert(ob_cam.end(), P.ob_cam.begin(), P.ob_cam.end());
+    ob_orig.insert(ob_orig.end(), P.ob_orig.begin(), P.ob_orig.end());
+    for (int pl = 0; pl < 4 && P.M > 0; ++pl)     // planes of (x,y) pairs, batch-wide: ob[(plane * nobs + o) * 2 + {0, 1}] (the packer's layout per window)
+      std::memcpy(ob.data() + ((size_t)pl * (size_t)nobs + (size_t)obs_cursor) * 2, P.ob.data() + (size_t)pl * 2 * (size_t)P.M, sizeof(double) * 2 * (size_t)P.M);
     ncam += P.C; nline += P.L; obs_cursor += P.M; sys += wd.n;
   }
   line_ptr.push_back((int)obs_cursor);

@@ -3,9 +3,23 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 
 namespace slslam {
+
+namespace {
+// true iff every value is finite: exponent field all ones <=> NaN / Inf.  Branch-free integer form (the compiler vectorises it).
+bool all_finite(const double* v, size_t n) {
+  uint64_t acc = 0;
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t x;
+    std::memcpy(&x, v + i, 8);
+    acc |= ((x & 0x7ff0000000000000ull) + 0x0010000000000000ull) & 0x8000000000000000ull;
+  }
+  return acc == 0;
+}
+}  // namespace
 
 int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   if (!w || !out) return SLSLAM_ERR_INVALID_ARGUMENT;
@@ -18,7 +32,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   P = PackedWindow();
   P.C = C; P.L = L; P.M = M;
   P.params0.assign(w->parameters, w->parameters + (size_t)6 * C + (size_t)4 * L);
-  for (size_t i = 0; i < P.params0.size(); ++i) if (!std::isfinite(P.params0[i])) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!all_finite(P.params0.data(), P.params0.size()) || (M > 0 && !all_finite(w->observations, (size_t)8 * M))) return SLSLAM_ERR_INVALID_ARGUMENT;
 
   // block constness: one flagged observation makes the block constant (lba_problem.cpp:88-91)
   std::vector<char> cam_const(C, 0), cam_used(C, 0), line_const(L, 0);
@@ -29,7 +43,6 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
     cam_used[c] = 1; line_cnt[l]++;
     if (w->fixed_index[2 * i]) cam_const[c] = 1;
     if (w->fixed_index[2 * i + 1]) line_const[l] = 1;
-    for (int q = 0; q < 8; ++q) if (!std::isfinite(w->observations[8 * (size_t)i + q])) return SLSLAM_ERR_INVALID_ARGUMENT;
   }
   P.cam_cf.assign(C, -1);
   for (int c = 0; c < C; ++c) if (cam_used[c] && !cam_const[c]) P.cam_cf[c] = P.Cf++;
@@ -174,11 +187,15 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   P.ob_cam.resize(M);
   P.ob.resize((size_t)8 * M);
   P.nkept = 0;
-  for (int o = 0; o < M; ++o) {
-    const int i = P.ob_orig[o];
-    P.ob_cam[o] = w->camera_index[i];
-    for (int q = 0; q < 8; ++q) P.ob[(size_t)q * M + o] = w->observations[8 * (size_t)i + q];
-    if (!(cam_const[w->camera_index[i]] && line_const[w->line_index[i]])) ++P.nkept;
+  {
+    double* pl[4] = { P.ob.data(), P.ob.data() + 2 * (size_t)M, P.ob.data() + 4 * (size_t)M, P.ob.data() + 6 * (size_t)M };
+    for (int o = 0; o < M; ++o) {
+      const int i = P.ob_orig[o];
+      P.ob_cam[o] = w->camera_index[i];
+      const double* src = w->observations + 8 * (size_t)i;
+      for (int q = 0; q < 4; ++q) { pl[q][2 * (size_t)o] = src[2 * q]; pl[q][2 * (size_t)o + 1] = src[2 * q + 1]; }
+      if (!(cam_const[w->camera_index[i]] && line_const[w->line_index[i]])) ++P.nkept;
+    }
   }
 
   // tiles, their lane maps and their off-diagonal camera-pair work items
@@ -186,13 +203,16 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   if (!P.big) {
     int s = 0;
     P.tiles.reserve(tile_ptr.size());
-    { size_t ni = 0; for (int l = 0; l < L; ++l) ni += (size_t)items_of(l); P.items.reserve(2 * ni); }
+    size_t items_total = 0;
+    for (int l = 0; l < L; ++l) items_total += (size_t)items_of(l);
+    P.items.resize(2 * items_total);
+    uint8_t* item_w = P.items.data();                         // the items are written through a cursor (sized exactly above)
     P.lane_map.reserve(64 * tile_ptr.size());
     P.line_desc.assign(L, 0u);
     uint16_t map[64];
     for (size_t ti = 0; ti + 1 < tile_ptr.size(); ++ti) {
       Tile t;
-      t.line_begin = s; t.item_off = (int)(P.items.size() / 2);
+      t.line_begin = s; t.item_off = (int)((item_w - P.items.data()) / 2);
       for (int q = 0; q < 64; ++q) map[q] = (uint16_t)0x00FF;
       int lane = 0, nl = 0, min_lanes = 64, max_run = 1, multi = 0;
       for (int ri = tile_ptr[ti]; ri < tile_ptr[ti + 1]; ++ri) {
@@ -207,7 +227,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
             int kf = 0;                                      // free-camera observations come first
             while (kf < k && P.cam_cf[P.ob_cam[P.line_ptr[s] + kf]] >= 0) ++kf;
             for (int i = 0; i < kf; ++i)
-              for (int j = i + 1; j < kf; ++j) { P.items.push_back((uint8_t)(lane + i)); P.items.push_back((uint8_t)(lane + j)); }
+              for (int j = i + 1; j < kf; ++j) { *item_w++ = (uint8_t)(lane + i); *item_w++ = (uint8_t)(lane + j); }
           }
           {
             // what the matrix-core elimination needs to find the line's F blocks and to know which accumulator tiles the line
@@ -229,10 +249,11 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
       const int rounds_log2 = min_lanes >= 4 ? 0 : min_lanes >= 2 ? 1 : 2;
       t.nlines = (int16_t)nl;
       t.flags = (int16_t)(multi | (rounds_log2 << 1) | (max_run << 3));
-      t.nitems = (int)(P.items.size() / 2) - t.item_off;
+      t.nitems = (int)((item_w - P.items.data()) / 2) - t.item_off;
       P.tiles.push_back(t);
       P.lane_map.insert(P.lane_map.end(), map, map + 64);
     }
+    P.items.resize((size_t)(item_w - P.items.data()));
   }
   return SLSLAM_OK;
 }

@@ -31,7 +31,7 @@ struct PackedWindow {
   std::vector<int> line_ptr;        // [L+1] sorted; window-local offsets into the sorted observations
   std::vector<int> ob_orig;         // [M]  sorted position -> original observation
   std::vector<int> ob_cam;          // [M]  sorted
-  std::vector<double> ob;           // [8*M] SoA: ob[q*M + o]
+  std::vector<double> ob;           // [8*M] four planes of (x, y) pairs: ob[(plane * M + o) * 2 + {0, 1}], plane = endpoint 0..3 of the observation
   std::vector<Tile> tiles;          // line_begin window-local; item_off window-local
   std::vector<uint16_t> lane_map;   // [64 per tile] lane -> line slot | position << 8 (0x00FF: idle)
   std::vector<uint8_t> items;       // 2 bytes per item
