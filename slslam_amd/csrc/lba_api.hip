@@ -302,8 +302,9 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     for (const PackedWindow& P : b->wins) if (P.Cf > kMfmaMaxFree || P.dup_free_obs) mfma_ok = false;
     const int want = b->opt.lba_elimination;
     if (want < 0 || want > 3) return SLSLAM_ERR_INVALID_ARGUMENT;
-    // automatic = the LDS-atomic sweep: on MI355X one wave issues a v_mfma_f64_16x16x4_f64 every ~141 cycles (tools/micro/
-    // mfma_f64_bench.hip: the same flop rate as its fp64 VALU), so the matrix-core sweep measures slower
+    // automatic = the LDS-atomic sweep: the matrix-core sweep measures slower on MI355X - not because of the matrix pipe (a wave
+    // issues a v_mfma_f64_16x16x4_f64 every 64 cycles, tools/micro/mfma_f64_bench.hip) but because of its operand path through
+    // LDS and its front end
     b->big_mode = false;
     for (const PackedWindow& P : b->wins) if (P.big) b->big_mode = true;       // one oversize window sends the batch down lba_big.h
     if (b->big_mode) { mfma_ok = false; if (b->opt.reuse_elimination) return SLSLAM_ERR_UNSUPPORTED; }
