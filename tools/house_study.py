@@ -22,6 +22,7 @@ import argparse
 import json
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -128,6 +129,8 @@ def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10):
     kf_pose, kf_obs, lines = [], [], {}                             # estimated (w,t)[6]; {line id: obs[8]}; world orth[4]
     s_it = s_c0 = s_c1 = 0.0
     per_frame = []
+    t_mo = t_lba = 0.0                                              # seconds inside the solver calls (motion-only / window LBA)
+    n_mo = n_lba = obs_lba = 0
     for k in range(frames):
         ids, ob = observe(truth[k][0], truth[k][1], segs0, sigma_px, rng)
         obs_k = dict(zip(ids, ob))
@@ -147,7 +150,9 @@ def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10):
                 w = {"num_cameras": 1, "num_lines": m, "camera_index": np.zeros(m, np.int32), "line_index": np.arange(m, dtype=np.int32),
                      "fixed_index": np.tile([0, 1], m).astype(np.int32), "observations": np.array([obs_k[i] for i in common]),
                      "parameters": np.concatenate([pose, np.concatenate([lines[i] for i in common])])}
+                tq = time.perf_counter()
                 x, _ = solve(w, max_iter)
+                t_mo += time.perf_counter() - tq; n_mo += 1
                 pose = x[:6]
         kf_pose.append(pose); kf_obs.append(obs_k)
         # ---- new landmarks: stereo triangulation in the keyframe, moved to the map frame (initialize_lm, gc_line_from_pose)
@@ -179,7 +184,9 @@ def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10):
         w = {"num_cameras": len(cams), "num_lines": len(lm_ids), "camera_index": np.array(ci, np.int32), "line_index": np.array(li, np.int32),
              "fixed_index": np.array(fi, np.int32), "observations": np.array(oo),
              "parameters": np.concatenate([np.concatenate([kf_pose[f] for f in cams]), np.concatenate([lines[i] for i in lm_ids])])}
+        tq = time.perf_counter()
         x, s = solve(w, max_iter)
+        t_lba += time.perf_counter() - tq; n_lba += 1; obs_lba += len(ci)
         for cpos, f in enumerate(free):
             kf_pose[f] = x[6 * cpos:6 * cpos + 6]
         for i in lm_ids:
@@ -201,6 +208,9 @@ def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10):
     tail = per_frame[half:]
     return {"sigma_px": sigma_px, "W": W, "frames": frames, "avg_iterations": s_it / frames, "avg_initial_cost": s_c0 / frames,
             "avg_final_cost": s_c1 / frames, "mean_position_error_m": float(err.mean()),
+            "solver_time": {"lba_ms_per_call": 1e3 * t_lba / max(1, n_lba), "lba_calls": n_lba, "avg_observations_per_window": obs_lba / max(1, n_lba),
+                            "motion_only_ms_per_call": 1e3 * t_mo / max(1, n_mo), "motion_only_calls": n_mo,
+                            "optimisation_ms_per_keyframe": 1e3 * (t_lba + t_mo) / frames},
             "second_half": {"avg_iterations": float(np.mean([q[0] for q in tail])), "avg_initial_cost": float(np.mean([q[1] for q in tail])),
                             "avg_final_cost": float(np.mean([q[2] for q in tail])), "rejected_step_fraction": float(np.sum([q[3] for q in tail]) / max(1, np.sum([q[0] for q in tail])))},
             "positions": est}
