@@ -27,6 +27,14 @@
 #include "dense_tile.h"
 #include "lba_eliminate_mfma_maps.h"
 
+// ISA audit (tools/isa_audit.py): the SLSLAM_ISA_MARKERS build leaves '; @PHASE name' comments in the assembly and pins the
+// schedule at each of them, so that the instructions of the tile loop can be counted per phase.  Not a product build.
+#if defined(SLSLAM_ISA_MARKERS)
+#define SLS_PHASE(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; @PHASE " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SLS_PHASE(name) do { } while (0)
+#endif
+
 namespace slslam {
 
 enum { kCamTab = 21 };   // doubles per camera in LDS: R[9] JL[9] t[3]; odd stride (42 dwords): conflict-free
@@ -88,13 +96,26 @@ struct SegCtx {
 // from a neighbouring line would leak through 0 * t, but a non-finite block already invalidates the whole window's
 // step, so the outcome is the same.  (Not used by the elimination kernel: there the fma form costs the few registers
 // that separate 2 waves per SIMD from 1.)
+// The non-fma form masks the shifted value with an integer AND on both halves (m ? ~0 : 0): the AND takes the DPP
+// modifier itself (v_and_b32_dpp), so a masked step of one value is two VALU instructions + the add instead of two moves +
+// two v_cndmask + the add, and a masked-out term is exactly +0.0 as before.
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift0_and(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true) & mask;
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true) & mask;
+  return __hiloint2double(hi, lo);
+}
 template <int CTRL, bool FMA_MASK>
 __device__ __forceinline__ double seg_step(double v, bool m) {
-  const double t = dpp_shift0<CTRL>(v);
-  return FMA_MASK ? fma(t, m ? 1.0 : 0.0, v) : v + (m ? t : 0.0);
+  if (FMA_MASK) return fma(dpp_shift0<CTRL>(v), m ? 1.0 : 0.0, v);
+  int mask = m ? -1 : 0;
+  asm("" : "+v"(mask));            // opaque: keeps the AND an AND (the optimiser would turn it back into selects)
+  return v + dpp_shift0_and<CTRL>(v, mask);
 }
 template <int N, bool FMA_MASK = false>
 __device__ __forceinline__ void seg_sum_n(double (&v)[N], const SegCtx& s) {
+  SLS_PHASE("seg_scan_1_2_4");
   if (s.max_run > 1) {
 #pragma unroll
     for (int q = 0; q < N; ++q) v[q] = seg_step<0x111, FMA_MASK>(v[q], s.j >= 1);
@@ -107,12 +128,15 @@ __device__ __forceinline__ void seg_sum_n(double (&v)[N], const SegCtx& s) {
 #pragma unroll
     for (int q = 0; q < N; ++q) v[q] = seg_step<0x114, FMA_MASK>(v[q], s.j >= 4);
   }
+  SLS_PHASE("seg_scan_8");
   if (s.max_run > 8) {
 #pragma unroll
     for (int q = 0; q < N; ++q) v[q] = seg_step<0x118, FMA_MASK>(v[q], s.j >= 8);
   }
+  SLS_PHASE("seg_total");
 #pragma unroll
   for (int q = 0; q < N; ++q) v[q] = bperm64(v[q], s.rl4);
+  SLS_PHASE("seg_multirow");
   if (s.multirow) {
     const bool spans = s.r1 > s.r0;
 #pragma unroll
@@ -127,6 +151,13 @@ __device__ __forceinline__ void seg_sum_n(double (&v)[N], const SegCtx& s) {
     }
   }
 }
+// 1 / x for the gradient-norm test (x = Jacobi scale in (0, 1]): hardware estimate + two Newton steps (within ~1 ulp) instead of the
+// ~13-instruction IEEE division; the norm only meets a tolerance and the trace.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return fma(fma(-x, y, 1.0), y, y);
+}
 __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
@@ -137,6 +168,23 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 __device__ __forceinline__ void lds_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Timing experiments of the elimination sweep (SLSLAM_EXTRA_FLAGS=-DSLSLAM_ABLATE=<bits>, tools/gpu_variant_bench.sh; results are
+// WRONG when set): 1 pair-block atomics dropped (products still computed), 4 camera-record atomics dropped, 8 pair-block
+// atomics replaced by plain stores, 16 camera-record atomics replaced by stores.
+#if !defined(SLSLAM_ABLATE)
+#define SLSLAM_ABLATE 0
+#endif
+__device__ __forceinline__ void keep_alive(double v) { asm volatile("" : : "v"(v)); }
+__device__ __forceinline__ void lds_add_pair(double* p, double v) {
+  if (SLSLAM_ABLATE & 1) keep_alive(v);
+  else if (SLSLAM_ABLATE & 8) *(volatile double*)p = v;
+  else lds_add(p, v);
+}
+__device__ __forceinline__ void lds_add_rec(double* p, double v) {
+  if (SLSLAM_ABLATE & 4) keep_alive(v);
+  else if (SLSLAM_ABLATE & 16) *(volatile double*)p = v;
+  else lds_add(p, v);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -337,8 +385,10 @@ __device__ __forceinline__ void lane_linearise_bs(const Policy& pol, const doubl
 
 // Per-line normal-equation block, summed over the line's run of lanes (every lane of the run
 // ends with the same values): H = sum Jl^T Jl (lower triangle, 10 values), g = sum Jl^T r.
+// No mask on the lanes' terms: a run never reads outside itself (the scan steps are masked by the position in the run), every
+// lane of a free line with observations carries one of them, and the sums of the other runs (idle lanes, lines without
+// observations, constant lines) are never used - line_active guards every consumer.
 __device__ __forceinline__ void line_block(const LaneLin& L, const SegCtx& sg, double H[10], double g[4]) {
-  const bool m = L.valid && L.line_free;
   double v[14];
   int q = 0;
 #pragma unroll
@@ -348,7 +398,7 @@ __device__ __forceinline__ void line_block(const LaneLin& L, const SegCtx& sg, d
       double h = 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) h += L.Jl[4 * r + a] * L.Jl[4 * r + b];
-      v[q++] = m ? h : 0.0;
+      v[q++] = h;
     }
   }
 #pragma unroll
@@ -356,7 +406,7 @@ __device__ __forceinline__ void line_block(const LaneLin& L, const SegCtx& sg, d
     double ga = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) ga += L.Jl[4 * r + a] * L.rs[r];
-    v[10 + a] = m ? ga : 0.0;
+    v[10 + a] = ga;
   }
   seg_sum_n<14>(v, sg);
 #pragma unroll
@@ -480,6 +530,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
   ObsPref pfn;
   prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
+    SLS_PHASE("tile_head");
     const TileCtx tc = nxt;
     const ObsPref pf = pfn;
     nxt = fetch_tile(p, t + 1, ck.tile_end, lane);      // in flight while this tile is processed
@@ -488,11 +539,13 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     const bool line_ok = tc.line_ok;
     LaneLin L;
     double ob[8];
+    SLS_PHASE("linearise");
     lane_linearise<!INIT>(p, pol, camtab, camscale, camcf, ls, j, k, o0, line_ok, tc.lflags, cur, wd.obs_off, L, ob, &pf, fresh);
     if (L.kept) acc_cost += L.cost;
     if ((INIT || fresh) && L.valid && !L.kept) acc_fixed += L.cost;
 
     double H[10], g[4];
+    SLS_PHASE("line_block");
     line_block(L, sg, H, g);
     const bool line_active = L.line_free && k > 0;   // uniform over the line's run
 
@@ -520,6 +573,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       continue;
     }
 
+    SLS_PHASE("fresh_scale");
     if (fresh) {
       // first sweep of a solve: H, g are those of the UNSCALED line columns.  Jacobi scale of the line from them
       // (1 / (1 + ||J_col||), Ceres: once at x0), the line's share of the initial gradient norm and of |x|, then the
@@ -547,6 +601,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     }
 
     // ---- eliminate the line: A = H + D^2, A^-1 = K^T K
+    SLS_PHASE("factor4x4");
     double D2[4], K[10], u[4] = { 0, 0, 0, 0 }, F[24];
     lm_diag4(H, pol, inv_radius, D2);
     bool okc = true;
@@ -559,15 +614,17 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       u[2] = K[3] * g[0] + K[4] * g[1] + K[5] * g[2];
       u[3] = K[6] * g[0] + K[7] * g[1] + K[8] * g[2] + K[9] * g[3];
       if (need_grad && line_ok && j == 0) {       // only the launch after an accepted step tests the gradient
-        for (int a = 0; a < 4; ++a) acc_gmax = fmax(acc_gmax, fabs(g[a] / pf.lsc[a]));
+        for (int a = 0; a < 4; ++a) acc_gmax = fmax(acc_gmax, fabs(g[a] * fast_rcp(pf.lsc[a])));
       }
     }
+    SLS_PHASE("lane_F");
     const bool cam_free = L.valid && L.cf >= 0;
     const bool elim = cam_free && L.line_free;       // this observation couples a free camera to a free line
-    if (elim) lane_F(L, K, F);
-    else { for (int q = 0; q < 24; ++q) F[q] = 0.0; }
+    lane_F(L, K, F);                                  // K = 0 for a constant line: F = 0 where the diagonal block reads it; lanes
+                                                      // without a free camera never have their F read
     // keep what the back-substitution needs (24 doubles per coupled observation, 22 per line) so
     // that it does not have to linearise again
+    SLS_PHASE("keep_factor");
     if (pol.store_f && elim) {
       const long long o = (long long)o0 + j;
 #pragma unroll
@@ -588,8 +645,10 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       }
     }
 
+    SLS_PHASE("prefetch_next");
     prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
     __builtin_amdgcn_sched_barrier(0);
+    SLS_PHASE("diag_block");
     if (cam_free) {
       double* rec = S + L.cf * kCamAcc;
 #pragma unroll
@@ -599,10 +658,10 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
         for (int r = 0; r < 4; ++r) { ga += L.Jc[6 * r + a] * L.rs[r]; ha += L.Jc[6 * r + a] * L.Jc[6 * r + a]; }
         const double fu = F[4 * a] * u[0] + F[4 * a + 1] * u[1] + F[4 * a + 2] * u[2] + F[4 * a + 3] * u[3];
         if (!same_point) {
-          lds_add(&rec[kRecG + a], ga);
-          lds_add(&rec[kRecH + a], ha);
+          lds_add_rec(&rec[kRecG + a], ga);
+          lds_add_rec(&rec[kRecH + a], ha);
         }
-        lds_add(&rec[kRecB + a], ga - fu);
+        lds_add_rec(&rec[kRecB + a], ga - fu);
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
           double v = 0.0;
@@ -610,13 +669,15 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
           for (int r = 0; r < 4; ++r) v += L.Jc[6 * r + a] * L.Jc[6 * r + b];
 #pragma unroll
           for (int m = 0; m < 4; ++m) v -= F[4 * a + m] * F[4 * b + m];
-          lds_add(&rec[tri_index(a, b)], v);
+          lds_add_rec(&rec[tri_index(a, b)], v);
         }
       }
     }
 
     // ---- off-diagonal camera pairs of the tile, balanced over the lanes
+    SLS_PHASE("pair_loop_ctl");
     for (int base_it = 0; base_it < tc.nitems; base_it += 64) {
+      SLS_PHASE("pair_gather");
       const int it = base_it + lane;
       const bool has = it < tc.nitems;
       int li = 0, lj = 0;
@@ -630,6 +691,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
 #pragma unroll
       for (int q = 0; q < 24; ++q) { Fi[q] = __shfl(F[q], li); Fj[q] = __shfl(F[q], lj); }
       const int ci = __shfl(L.cf, li), cj = __shfl(L.cf, lj);
+      SLS_PHASE("pair_product");
       if (has) {
         if (cj != ci) {        // cj > ci by construction
           double* blk = S + pair_base(ncf, cj, ci);
@@ -640,9 +702,10 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
               double v = 0.0;                       // - F_j F_i^T: the sign rides on the fma's operand modifier
 #pragma unroll
               for (int m = 0; m < 4; ++m) v -= Fj[4 * a + m] * Fi[4 * b + m];
-              lds_add(&blk[6 * a + b], v);
+              lds_add_pair(&blk[6 * a + b], v);
             }
         } else {               // the same camera observes the line twice: symmetric part
+          SLS_PHASE("pair_same_camera");
           for (int a = 0; a < 6; ++a)
             for (int b = 0; b <= a; ++b) {
               double v = 0.0;
@@ -651,8 +714,10 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
             }
         }
       }
+      SLS_PHASE("pair_loop_ctl");
     }
   }
+  SLS_PHASE("epilogue");
 
   __syncthreads();
   double* slab = p.slab + ck.slab_off;
@@ -1300,7 +1365,12 @@ __device__ __forceinline__ void line_trig_step(const double trig0[7], const doub
 }
 
 // One or two waves per chunk workgroup (blockDim.x = 64 or 128): wave w takes the tiles tile_begin + w, + nw, ...
-__global__ __launch_bounds__(128) void k_backsub(BatchPtrs p, Policy pol) {
+#if defined(SLSLAM_BACKSUB_WAVES_PER_EU)       // occupancy experiments (SLSLAM_EXTRA_FLAGS=-DSLSLAM_BACKSUB_WAVES_PER_EU=3)
+#define SLS_BACKSUB_OCC __attribute__((amdgpu_waves_per_eu(SLSLAM_BACKSUB_WAVES_PER_EU, SLSLAM_BACKSUB_WAVES_PER_EU)))
+#else
+#define SLS_BACKSUB_OCC
+#endif
+__global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const Chunk ck = p.chunks[blockIdx.x];
@@ -1348,6 +1418,7 @@ __global__ __launch_bounds__(128) void k_backsub(BatchPtrs p, Policy pol) {
   ObsPref pfn;
   prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
   for (int t = ck.tile_begin + wave; t < ck.tile_end; t += nw) {
+    SLS_PHASE("bs_tile_head");
     const TileCtx tc = nxt;
     const ObsPref pf = pfn;
     nxt = fetch_tile(p, t + nw, ck.tile_end, lane);
@@ -1366,6 +1437,7 @@ __global__ __launch_bounds__(128) void k_backsub(BatchPtrs p, Policy pol) {
     }
     LaneBs L;
     double ob[8], wo[4];
+    SLS_PHASE("bs_linearise_w");
     lane_linearise_bs(pol, bstab, camcf, j, k, line_ok, tc.lflags, L, ob, wo, pf);
     const bool line_active = L.line_free && k > 0;
     // w = sum_i (Jc_i^T Jl_i)^T y_c[cam_i] = sum_i Jl_i^T (Jc_i y_c)
@@ -1375,9 +1447,11 @@ __global__ __launch_bounds__(128) void k_backsub(BatchPtrs p, Policy pol) {
       for (int a = 0; a < 4; ++a) wv[a] = wo[a];
     }
     // the next tile's loads go out here (the linearisation's temporaries are dead), see prefetch_obs
+    SLS_PHASE("bs_prefetch_next");
     prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
     __builtin_amdgcn_sched_barrier(0);
     seg_sum_n<4, true>(wv, sg);
+    SLS_PHASE("bs_line_step");
     // every lane of the run holds the same H, g, w: all of them take the step (the candidate
     // parameters are needed by every lane below); lane 0 of the run writes and accumulates
     const int lsafe = line_ok ? ls : 0;
@@ -1407,6 +1481,7 @@ __global__ __launch_bounds__(128) void k_backsub(BatchPtrs p, Policy pol) {
       }
     }
     double trig[7];
+    SLS_PHASE("bs_candidate_trig");
     {
       // (the step actually taken: new minus old, exact in floating point for small steps)
       const double e[4] = { xn[0] - pf.u[0], xn[1] - pf.u[1], xn[2] - pf.u[2], xn[3] - pf.u[3] };
@@ -1414,11 +1489,13 @@ __global__ __launch_bounds__(128) void k_backsub(BatchPtrs p, Policy pol) {
       if (__any(!(emax <= 0.0625))) seg_line_trig(xn, sg, trig);
       else line_trig_step(pf.trig, e, trig);
     }
+    SLS_PHASE("bs_store_candidate");
     if (head) {
       double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
       for (int a = 0; a < 4; ++a) xc[a] = xn[a];
       for (int a = 0; a < 7; ++a) xc[4 + a] = trig[a];
     }
+    SLS_PHASE("bs_candidate_cost");
     // cost of this observation at the candidate point (cameras from the reduced solve, line from above)
     {
       const double* ct = candtab + L.cam * kCandTab;
@@ -1432,6 +1509,7 @@ __global__ __launch_bounds__(128) void k_backsub(BatchPtrs p, Policy pol) {
       if (L.kept) acc_cost += c;
     }
   }
+  SLS_PHASE("epilogue");
   const double m = wave_sum(acc_model), d = wave_sum(acc_dn2), x = wave_sum(acc_xn2), cs = wave_sum(acc_cost);
   if (nw > 1) {
     if (lane == 0) { red[4 * wave] = m; red[4 * wave + 1] = d; red[4 * wave + 2] = x; red[4 * wave + 3] = cs; }
