@@ -77,14 +77,59 @@ def cpu_baseline(windows, budget_s=12.0):
     return its / dt, "%d of the bench windows (%.1f s, %d LM iterations), 1 thread" % (len(outs), dt, its), outs
 
 
+def host_cpu_info():
+    """What this process may actually use of the host: scheduler affinity, the cgroup CPU bandwidth quota (cgroup v2 cpu.max or
+    v1 cpu.cfs_quota_us / cpu.cfs_period_us; None = unlimited), the cgroup's effective cpuset and the host's 1-minute load average
+    (a shared host shows up there: other tenants' runnable threads)."""
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        info["sched_affinity"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        info["sched_affinity"] = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    info["cgroup_cpu_quota"] = quota
+    for path in ("/sys/fs/cgroup/cpuset.cpus.effective", "/sys/fs/cgroup/cpuset/cpuset.effective_cpus"):
+        try:
+            txt = open(path).read().strip()
+            n = 0
+            for part in filter(None, txt.split(",")):
+                a, _, b = part.partition("-")
+                n += (int(b) - int(a) + 1) if b else 1
+            info["cgroup_cpuset_effective"] = n
+            break
+        except Exception:
+            continue
+    try:
+        info["loadavg_1min"] = os.getloadavg()[0]
+    except OSError:
+        pass
+    usable = info["sched_affinity"]
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.999)))
+    if info.get("cgroup_cpuset_effective"):
+        usable = min(usable, info["cgroup_cpuset_effective"])
+    info["usable_threads"] = usable
+    return info
+
+
 def cpu_baseline_all_cores(windows, budget_s=15.0):
     """Same oracle, fanned out over independent windows on every host core: one window per
-    OpenMP task inside the C library, as many windows as fit the time budget."""
+    OpenMP task inside the C library, as many windows as fit the time budget.  Threads = min(scheduler affinity, cgroup CPU
+    quota, cgroup cpuset): what the container may use, not what the host advertises."""
     from oracle import pyoracle          # cpu_baseline leg only
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cpu_info()["usable_threads"]
     per_core = max(1, int(budget_s / 0.25 / 2))      # ~0.2-0.25 s per 2000-line window and thread
     # bounded sample: on a shared host the usable parallelism can be far below the advertised core count
     sample = windows[:min(len(windows), cores * per_core, 384)]
@@ -131,6 +176,59 @@ def ceres_probe():
     except Exception:
         pass
     return {"ceres_available": bool(hits), "found": hits[:4]}
+
+
+def cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank, lines, elim, k_check=4):
+    """Results are a function of the window alone, so every rank's results can be checked against ANY rank's solve of the same
+    window id, bit for bit.  Outside the timed region: every rank exports the solved parameters of
+    the first `k_check` windows of its shard on the device, ONE all-gather (RCCL for N > 1) brings them to every rank, and rank 0
+    solves the same window ids itself - in a small batch of its own, cut into the same number of chunks - and compares the
+    bytes.  At N = 1 this is the same check against a differently composed batch.  Returns the dict for the JSON line."""
+    import zlib
+    import torch.distributed as dist
+    k = min(k_check, B)
+    vecs, chunks = [], []
+    for i in range(k):
+        si, li = where[i]
+        batches[si].download()
+        vecs.append(batches[si].parameters(li))
+        chunks.append(batches[si].window_chunks(li))
+    width = sum(v.size for v in vecs)
+    local = torch.from_numpy(np.concatenate(vecs)).to(dev)
+    meta = torch.tensor([lo] + chunks + [v.size for v in vecs], dtype=torch.int64, device=dev)
+    if world > 1:
+        allp = torch.empty(world * width, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allp, local)                      # the collective under test: RCCL all-gather over xGMI
+        allm = torch.empty(world * meta.numel(), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allm, meta)
+    else:
+        allp, allm = local, meta
+    if rank != 0:
+        return None
+    allp = allp.cpu().numpy().reshape(world, width)
+    allm = allm.cpu().numpy().reshape(world, -1)
+    ids, crcs, equal, maxdiff = [], [], True, 0.0
+    for r in range(world):
+        lo_r, ch, sizes = int(allm[r, 0]), [int(x) for x in allm[r, 1:1 + k]], [int(x) for x in allm[r, 1 + k:1 + 2 * k]]
+        off = 0
+        for i in range(k):
+            got = allp[r, off:off + sizes[i]]
+            off += sizes[i]
+            bt = capi.LBABatch(device=local_rank)
+            bt.add(synth.make_window(lo_r + i, num_lines=lines))
+            bt.finalize(use_graph=0, chunks_per_window=ch[i], lba_elimination=elim)
+            bt.solve(); bt.download()
+            mine = bt.parameters(0)
+            bt.close()
+            ids.append(lo_r + i)
+            crcs.append("%08x" % (zlib.crc32(got.tobytes()) & 0xffffffff))
+            if not np.array_equal(got, mine):
+                equal = False
+                maxdiff = max(maxdiff, float(np.abs(got - mine).max()))
+    return {"window_ids": ids, "crc32_of_gathered_parameters": crcs, "bitwise_equal_to_rank0_resolve": equal,
+            "max_abs_diff": maxdiff, "checked_per_rank": k,
+            "how": "first %d windows of every rank's shard: parameters all-gathered on the device, rank 0 solves the same ids in "
+                   "1-window batches with the same chunk count and compares bytes" % k}
 
 
 def time_batch(windows, device, steps, warmup, **opt):
@@ -195,8 +293,16 @@ def pose_graph_block():
     out["structured_vs_dense_max_diff"] = float(np.abs(res["structured"] - res["dense_fp64"]).max())
     t0 = time.perf_counter()
     xo, so, _ = pyoracle.po_solve(g)
-    out["cpu_oracle_ms"] = 1e3 * (time.perf_counter() - t0)
+    out["cpu_oracle_ms"] = 1e3 * (time.perf_counter() - t0)                  # dense 1554^2 Cholesky: NOT what the reference configures
     out["max_diff_vs_oracle"] = float(np.abs(res["structured"] - xo).max())
+    # the fair CPU figure: the reference configures SPARSE_NORMAL_CHOLESKY (src/po_problem.cpp:68); the oracle's envelope
+    # Cholesky exploits the same sparsity (block tridiagonal chain + loop-closure fill), one thread as the reference pins it
+    pyoracle.po_solve(g, linear_solver=2)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        xs, ss, _ = pyoracle.po_solve(g, linear_solver=2)
+    out["cpu_oracle_sparse_ms"] = 1e3 * (time.perf_counter() - t0) / 5
+    out["cpu_oracle_sparse_max_diff_vs_dense"] = float(np.abs(xs - xo).max())
     return out
 
 
@@ -216,6 +322,7 @@ def main():
     ap.add_argument("--gather-results", action="store_true",
                     help="also all-gather the solved parameters of every rank inside the timed region (one RCCL all-gather per step)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the 500-line, latency and pose-graph blocks")
+    ap.add_argument("--no-result-check", action="store_true", help="skip the cross-rank bitwise check of the results (outside the timed region)")
     ap.add_argument("--streams", type=int, default=1,
                     help="the rank's windows are split into this many batches on separate HIP streams, so that the "
                          "latency-bound kernels of one batch (reduced solve, LM update) overlap the sweeps of the other")
@@ -236,6 +343,7 @@ def main():
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("SLSLAM_BENCH_BACKEND", "nccl")      # "nccl" is RCCL over xGMI on ROCm
@@ -243,6 +351,15 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    # who is in the job: communicator size after init and the device every rank sits on (one distinct GPU per rank expected)
+    props = torch.cuda.get_device_properties(local_rank)
+    me = "%s|%s|%s" % (os.uname().nodename, getattr(props, "pci_bus_id", local_rank), getattr(props, "uuid", ""))
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        ranks_seen = dist.get_world_size()
+    else:
+        seen, ranks_seen = [me], 1
 
     # ---- synthetic inputs of the named shape, distinct per rank, resident in HBM before timing
     # BASELINE configs[3]: a stream of world x B independent windows, window i = synth.make_window(i), split contiguously
@@ -298,9 +415,14 @@ def main():
     barrier()
     dt_local = time.perf_counter() - t0
     t = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+    per_rank = [dt_local]
     if world > 1:
+        tt = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(tt, t)
+        per_rank = tt.tolist()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    check = cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank, args.lines, args.elim) if not args.no_result_check else None
 
     # ---- second, informational measurement (not `value`): the same windows as two half-batches on two HIP
     # streams, each replaying its captured hipGraph, so that the latency-bound kernels of one half (reduced
@@ -365,6 +487,11 @@ def main():
                        "launch": "hipGraph replay" if args.graph else "eager + hipEvents", "hip_streams": ns},
             "lm_iterations": iters_total,
             "sum_initial_cost_rank0": init_cost, "sum_final_cost_rank0": final_cost,
+            # multi-rank evidence: size of the communicator after init (RCCL when backend == "nccl"), distinct devices the ranks
+            # sit on, every rank's own clock over the timed region, and the cross-rank bitwise check of the results
+            "rccl_ranks_seen": ranks_seen, "collective_backend": backend, "distinct_devices_seen": len(set(seen)),
+            "per_rank_ms_per_step": [1e3 * x / max(args.steps, 1) for x in per_rank],
+            "results_check": check,
         }
         if overlap is not None:
             out["two_streams_overlapped"] = overlap
@@ -376,18 +503,22 @@ def main():
             bytes_launch = algorithmic_bytes_linearise(counts) / ns
             achieved = bytes_launch / (ms / n * 1e-3) / 1e9
             traffic, tj = None, {}
+            traffic_source = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     if tj.get("lines") == args.lines:
                         traffic = tj.get("hbm_bytes_per_launch") * (B / ns) / tj.get("windows")
+                        # NOT measured in this run: PMC counters need rocprofv3 around the process; the figure is the committed
+                        # result of the separate --pmc passes (tools/gpu_r3_profile.sh), scaled to this batch size
+                        traffic_source = "profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, not this run" % tj.get("source", "round2_v3")
                 except Exception:
                     traffic = None
             flops_launch = algorithmic_flops_linearise(windows) / ns
             tflops = flops_launch / (ms / n * 1e-3) / 1e12
             out["roofline"] = {"bound": "hbm", "kernel": "k_linearise_schur", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": ms / n, "launches": n,
                                # what actually bounds the kernel: fp64 issue at two waves per SIMD
                                # (256 VGPRs) - a v_fma_f64 stream reaches 48.5 TFLOP/s there, not the 78.6 of the spec -
@@ -410,7 +541,8 @@ def main():
                 except Exception:
                     btraffic = None
                 out["roofline_backsub"] = {"bound": "hbm", "kernel": "k_backsub", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": ach / HBM_PEAK_GBS, "traffic": btraffic, "algorithmic_bytes_per_launch": bb,
+                                           "frac": ach / HBM_PEAK_GBS, "traffic": btraffic, "traffic_source": traffic_source if btraffic else None,
+                                           "algorithmic_bytes_per_launch": bb,
                                            "avg_launch_ms": bms / bn, "launches": bn,
                                            "binding": "fp64 VALU issue at 2 waves/SIMD"}
             sms, sn = kt["reduced_solve"]
@@ -422,8 +554,10 @@ def main():
                                              "note": "60x60 systems: latency-bound (one workgroup per window), 3 % of the step"}
         if world == 1 and not args.no_cpu_baseline:
             v, sample, outs = cpu_baseline(windows)
+            hinfo = host_cpu_info()
             out["cpu_baseline"] = {"value": v, "unit": "LM iterations/s", "cores": 1, "kind": "port", "sample": sample,
-                                   "host_cores_available": os.cpu_count()}
+                                   "host_cores_available": os.cpu_count(), "cgroup_cpu_quota": hinfo["cgroup_cpu_quota"],
+                                   "host": hinfo}
             va, ca, sa = cpu_baseline_all_cores(windows)
             out["cpu_baseline_all_cores"] = {"value": va, "unit": "LM iterations/s", "cores": ca, "kind": "port", "sample": sa,
                                              # threads the process may run on (sched_getaffinity) vs how well they scale:

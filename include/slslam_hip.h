@@ -178,6 +178,11 @@ int  slslam_lba_batch_export_device(slslam_lba_batch* b, double* device_out, voi
 /* Problem-size accounting for throughput reporting: totals over the batch. */
 int  slslam_lba_batch_counts(const slslam_lba_batch* b, long long* num_windows, long long* num_cameras,
                              long long* num_free_cameras, long long* num_lines, long long* num_observations);
+/* After finalize: the number of chunks (waves cooperating on the window's observation sweeps) window `index` was cut into.  A
+ * window's result is a function of its inputs, the options and this number only (the chunk partials are summed in chunk order):
+ * a window solved again with chunks_per_window set to it - in any batch that keeps the chunk count at 8 or below, or above 8 -
+ * reproduces its result bit for bit, which is how results are compared across the ranks of a multi-GPU run (bench.py). */
+int  slslam_lba_batch_window_chunks(const slslam_lba_batch* b, int index, int* num_chunks);
 /* Device time (ms) spent in each kernel family during the last solve, measured with HIP events
  * on the solve stream while profiling is enabled (solves are then launched eagerly instead of
  * replaying the captured graph); times accumulate over solves until set_profiling is called again.

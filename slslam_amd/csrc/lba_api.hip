@@ -511,7 +511,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     ar.scratch(b->d_big_linv, (size_t)std::max<long long>(1, linv_cursor));
   }
   ar.zeroed(b->d_iter_counter, 1);
-  ar.zeroed(b->d_dbg_cycles, b->pol.debug_flags ? (size_t)32 * std::max(1, b->nchunk) : 1);
+  ar.zeroed(b->d_dbg_cycles, b->pol.debug_flags ? std::max((size_t)32 * std::max(1, b->nchunk), (size_t)16 * std::max(1, B)) : 1);
   ar.zeroed(b->d_active, 1);
   if ((rc = ar.commit())) return rc;
 
@@ -701,7 +701,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       else LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_linearise_schur<false>, g_chunk, blk64, b->lds_lin, s, p, pol));
     }
     if (b->slab_sum_stride)
-      LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((b->slab_sum_stride + 255) / 256), (unsigned)B), blk256, 0, s, p));
+      LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)B, (unsigned)((b->slab_sum_stride + 255) / 256)), blk256, 0, s, p));   // windows on grid.x (no 65535 limit)
     LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve, g_win, blk256, b->lds_solve, s, p, pol));
     if (b->nchunk > 0) {
       if (pol.store_f) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub_stream, g_chunk, blk64, b->lds_bs_stream, s, p, pol));
@@ -863,11 +863,17 @@ extern "C" int slslam_lba_batch_counts(const slslam_lba_batch* b, long long* nw,
   return SLSLAM_OK;
 }
 
+extern "C" int slslam_lba_batch_window_chunks(const slslam_lba_batch* b, int index, int* num_chunks) {
+  if (!b || !num_chunks || !b->finalized || index < 0 || index >= (int)b->h_wins.size()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  *num_chunks = b->h_wins[index].nchunks;
+  return SLSLAM_OK;
+}
+
 // Timing experiments only (SLSLAM_DEBUG_ABLATE bit 8; not part of include/slslam_hip.h): per-phase wave cycles of the last
 // matrix-core sweep, summed over all waves; out[16].
 extern "C" int slslam_debug_phase_cycles(slslam_lba_batch* b, double* out) {
   if (!b || !out || !b->finalized) return SLSLAM_ERR_INVALID_ARGUMENT;
-  const size_t n = (size_t)32 * std::max(1, b->nchunk);
+  const size_t n = std::max((size_t)32 * std::max(1, b->nchunk), (size_t)16 * std::max<size_t>(1, b->wins.size()));
   if (!b->pol.debug_flags) return SLSLAM_ERR_STATE;
   std::vector<unsigned long long> h(n);
   HIP_TRY(hipSetDevice(b->device));

@@ -810,12 +810,12 @@ __device__ __forceinline__ unsigned long long solve_clock() {
 // partials added in chunk order (the sum k_reduced_solve would form); per-chunk scalars: cost / fixed cost / |x|^2 summed,
 // gradient norm and failure flag maxed.  Result: one slab per window in slab_sum, same layout.
 __global__ __launch_bounds__(256) void k_slab_reduce(BatchPtrs p) {
-  const int w = blockIdx.y;
+  const int w = blockIdx.x;
   const WinDesc wd = p.wins[w];
   if (p.state[w].status != kRunning || wd.nchunks <= 0) return;
   const int nsys = p.elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n);
   const long long sstride = (long long)nsys + kSlabScalars;
-  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int q = blockIdx.y * 256 + threadIdx.x;
   if (q >= nsys + kSlabScalars) return;
   const double* src = p.slab + p.chunks[wd.chunk_off].slab_off + q;
   const bool is_max = q == nsys + kScGradMaxLine || q == nsys + kScFail;
@@ -1379,6 +1379,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
   if (st->status != kRunning) return;
   const int cur = st->cur;
   const int n = wd.n;
+  const bool refresh_table = (st->n_success & 15) == 15;
   double* bstab = smem;
   double* candtab = bstab + wd.C * kBsTab;
   double* red = candtab + wd.C * kCandTab;             // [2][4] per-wave sums
@@ -1486,7 +1487,10 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
       // (the step actually taken: new minus old, exact in floating point for small steps)
       const double e[4] = { xn[0] - pf.u[0], xn[1] - pf.u[1], xn[2] - pf.u[2], xn[3] - pf.u[3] };
       const double emax = fmax(fmax(fabs(e[0]), fabs(e[1])), fmax(fabs(e[2]), fabs(e[3])));
-      if (__any(!(emax <= 0.0625))) seg_line_trig(xn, sg, trig);
+      // library sin / cos of the new angles when a step of the wave's lines is large - and on every 16th accepted step of the
+      // window, so that the round-off the angle-addition updates leave in the table (a few ulp per accepted step) does not
+      // accumulate over a long solve (max_num_iterations >> 10); idle lanes carry no line and do not vote
+      if (__any(line_ok && !(emax <= 0.0625)) || refresh_table) seg_line_trig(xn, sg, trig);
       else line_trig_step(pf.trig, e, trig);
     }
     SLS_PHASE("bs_store_candidate");

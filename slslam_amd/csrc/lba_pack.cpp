@@ -60,7 +60,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   //     back-substitution) are kept in tiles of their own.
   std::vector<int> kfree(L, 0);
   std::vector<unsigned> fmask(L, 0u);            // free cameras that see the line
-  for (int i = 0; i < M; ++i)
+  for (int i = 0; i < M && !P.big; ++i)        // (oversize windows have up to 64 free cameras and no tiles: no masks, no work items)
     if (P.cam_cf[w->camera_index[i]] >= 0) {
       const unsigned bit = 1u << P.cam_cf[w->camera_index[i]];
       if (fmask[w->line_index[i]] & bit) P.dup_free_obs = true;

@@ -354,6 +354,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     }
   }
 done:
+  for (hipEvent_t e : tev) (void)hipEventDestroy(e);       // a failed solve leaves through here with its profiling events alive
   DeviceBlockCache::give_back(arena, arena_bytes, arena_device);
   return rc;
 }

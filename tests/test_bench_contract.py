@@ -53,3 +53,11 @@ def test_bench_line_contract():
         assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9)
     # the dominant kernel's time fits inside the step
     assert d["kernel_ms_per_step"]["linearise_schur"] < d["ms_per_step"]
+    # multi-rank evidence fields are there at N = 1 too; the results of the checked windows are reproduced bit for bit by a
+    # solve of the same window ids in a different batch (what rank 0 does with the other ranks' results at N > 1)
+    assert d["rccl_ranks_seen"] == 1 and d["distinct_devices_seen"] == 1 and len(d["per_rank_ms_per_step"]) == 1
+    assert d["per_rank_ms_per_step"][0] == pytest.approx(d["ms_per_step"], rel=0.2)
+    chk = d["results_check"]
+    assert chk["window_ids"] == [0, 1, 2, 3] and len(chk["crc32_of_gathered_parameters"]) == 4
+    assert chk["bitwise_equal_to_rank0_resolve"] is True and chk["max_abs_diff"] == 0.0
+    assert "traffic_source" in d["roofline"]

@@ -195,3 +195,16 @@ def test_lm_trace_matches_independent_numpy_lm(oracle):
     assert np.abs(x - z["final_parameters"]).max() < 1e-5
     x1, s1, tr1 = oracle.lba_solve(w, linear_solver=1)                  # the Schur back-end walks it too
     assert [r["step_is_successful"] for r in tr1] == [int(v) for v in z["successful"]]
+
+
+def test_po_envelope_cholesky_equals_dense(oracle):
+    """linear_solver = 2 (envelope Cholesky in the natural pose order, the sparse stand-in for SPARSE_NORMAL_CHOLESKY at
+    reference src/po_problem.cpp:68) solves the same normal equations as the dense factorisation: same steps, same poses."""
+    for seed, n, loops in ((7, 120, 4), (3, 60, 0), (5, 90, 7)):
+        g = synth.make_pose_graph(seed, num_poses=n, num_loops=loops)
+        xd, sd, td = oracle.po_solve(g)
+        xs, ss, ts = oracle.po_solve(g, linear_solver=2)
+        assert (sd["num_successful_steps"], sd["num_unsuccessful_steps"]) == (ss["num_successful_steps"], ss["num_unsuccessful_steps"])
+        assert abs(sd["final_cost"] - ss["final_cost"]) <= 1e-12 * max(sd["final_cost"], 1e-30) + 1e-20
+        assert np.abs(xd - xs).max() < 1e-10
+        assert len(td) == len(ts)
