@@ -99,14 +99,20 @@ def wave_trajectory(n=400, radius=5.1, amp=0.5, house_centre=(2.25, 2.25, 1.75),
     return poses
 
 
-def observe(R, t, segs, sigma_px, rng):
-    """Stereo observation [8] (normalised, as SLAM::insert_curr_obs) of every segment fully inside both images."""
+def observe(R, t, segs, sigma_px, rng, visibility="both"):
+    """Stereo observation [8] (normalised, as SLAM::insert_curr_obs) of every segment fully inside both images
+    (visibility "both"), inside the left image only ("left") or merely in front of the camera ("front")."""
     ids, obs = [], []
     for i, (A, B) in enumerate(segs):
         o, ok = np.empty(8), True
         for e, P in enumerate((A, B)):
             ul, vl, ur, z = synth._project(R, t, P)
-            ok &= bool(z > 0.3 and 0 <= ul < synth.WIDTH and 0 <= ur < synth.WIDTH and 0 <= vl < synth.HEIGHT)
+            if visibility == "both":
+                ok &= bool(z > 0.3 and 0 <= ul < synth.WIDTH and 0 <= ur < synth.WIDTH and 0 <= vl < synth.HEIGHT)
+            elif visibility == "left":
+                ok &= bool(z > 0.3 and 0 <= ul < synth.WIDTH and 0 <= vl < synth.HEIGHT)
+            else:
+                ok &= bool(z > 0.3)
             o[2 * e], o[2 * e + 1], o[4 + 2 * e], o[4 + 2 * e + 1] = ul, vl, ur, vl
         if ok:
             o = o + rng.normal(0, sigma_px, 8)
@@ -116,10 +122,25 @@ def observe(R, t, segs, sigma_px, rng):
     return ids, np.array(obs).reshape(-1, 8)
 
 
-def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10):
+def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10, lm_init="stereo", frames_per_keyframe=1, visibility="both",
+        noise_scale=1.0, pose_noise=(0.2, 0.005), motion_only=True):
     """One simulated run; `solve(window_dict, max_num_iterations)` -> (parameters, summary).  Returns the averages the
-    reference prints (src/main.cpp:84-89: sums over LBA calls divided by the frame count) and the estimated positions."""
+    reference prints (src/main.cpp:84-89: sums over LBA calls divided by the frame count) and the estimated positions.
+
+    The simulator unknowns (the reference's observation generator is not shipped), swept by --sweep:
+      lm_init              "stereo": a new landmark is triangulated from its first noisy stereo observation (initialize_lm);
+                           "truth": the true line with a small perturbation (1 mm / 0.05 deg on its end points)
+      frames_per_keyframe  the reference divides its sums by frame_id (src/main.cpp:84-89), the number of FRAMES read; only
+                           keyframes run the LBA (main.cpp:61-69).  k > 1 models a sequence with k frames per keyframe:
+                           the same keyframes, denominators k times larger
+      visibility           which segments a keyframe observes (see observe)
+      noise_scale          the file name's noise level times this (a generator that perturbs, e.g., both the end points and the
+                           stereo match adds more than sigma per coordinate)
+      pose_noise           (deg, m) perturbation of the predicted pose that stands in for the visual odometry
+      motion_only          run motion-only BA on the predicted pose before the window LBA (pose_estimation, slam.cpp:303)"""
     rng = np.random.default_rng([seed, int(round(100 * sigma_px)), W])
+    sigma_nominal = sigma_px
+    sigma_px = sigma_px * noise_scale
     segs = house_segments()
     truth = wave_trajectory(frames)
     R0, t0 = truth[0]
@@ -129,10 +150,11 @@ def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10):
     kf_pose, kf_obs, lines = [], [], {}                             # estimated (w,t)[6]; {line id: obs[8]}; world orth[4]
     s_it = s_c0 = s_c1 = 0.0
     per_frame = []
+    term_hist, iter_hist = {}, {}
     t_mo = t_lba = 0.0                                              # seconds inside the solver calls (motion-only / window LBA)
     n_mo = n_lba = obs_lba = 0
     for k in range(frames):
-        ids, ob = observe(truth[k][0], truth[k][1], segs0, sigma_px, rng)
+        ids, ob = observe(truth[k][0], truth[k][1], segs0, sigma_px, rng, visibility)
         obs_k = dict(zip(ids, ob))
         # ---- pose prediction: last estimate composed with the true relative motion, perturbed (stands in for RANSAC VO)
         if k == 0:
@@ -141,11 +163,11 @@ def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10):
             Rp, tp = synth.wt_to_rt(kf_pose[-1])
             Rrel = truth[k][0] @ truth[k - 1][0].T
             trel = truth[k][1] - Rrel @ truth[k - 1][1]
-            Rn = synth.rodrigues(rng.normal(0, np.deg2rad(0.2), 3)) @ Rrel @ Rp
-            pose = synth.rt_to_wt(Rn, Rrel @ tp + trel + rng.normal(0, 0.005, 3))
+            Rn = synth.rodrigues(rng.normal(0, np.deg2rad(pose_noise[0]), 3)) @ Rrel @ Rp
+            pose = synth.rt_to_wt(Rn, Rrel @ tp + trel + rng.normal(0, pose_noise[1], 3))
             # ---- motion-only BA against the mapped lines (SLAM::motion_only_ba: camera 0 free, lines constant)
             common = [i for i in ids if i in lines]
-            if len(common) >= 5:
+            if len(common) >= 5 and motion_only:
                 m = len(common)
                 w = {"num_cameras": 1, "num_lines": m, "camera_index": np.zeros(m, np.int32), "line_index": np.arange(m, dtype=np.int32),
                      "fixed_index": np.tile([0, 1], m).astype(np.int32), "observations": np.array([obs_k[i] for i in common]),
@@ -159,8 +181,14 @@ def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10):
         R, t = synth.wt_to_rt(pose)
         for i in ids:
             if i not in lines:
-                lm = synth._initialize_lm(obs_k[i][None])[0]
-                lines[i] = synth.av_to_orth(np.concatenate([R.T @ (lm[:3] - t), R.T @ lm[3:]])[None])[0]
+                if lm_init == "stereo":
+                    lm = synth._initialize_lm(obs_k[i][None])[0]
+                    lines[i] = synth.av_to_orth(np.concatenate([R.T @ (lm[:3] - t), R.T @ lm[3:]])[None])[0]
+                else:
+                    A, B = segs0[i][0] + rng.normal(0, 1e-3, 3), segs0[i][1] + rng.normal(0, 1e-3, 3)
+                    dv = (B - A) / np.linalg.norm(B - A)
+                    cp = A - dv * (A @ dv)                                   # closest point of the line to the map origin
+                    lines[i] = synth.av_to_orth(np.concatenate([cp, dv])[None])[0]
         # ---- sliding-window LBA: the 2 W newest keyframes, the W newest free (src/slam.cpp:1376-1382, 811-832)
         if k == 0:
             continue
@@ -193,6 +221,10 @@ def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10):
             lines[i] = x[6 * len(cams) + 4 * lpos[i]:][:4]
         s_it += s["num_successful_steps"] + s["num_unsuccessful_steps"]
         s_c0 += s["initial_cost"]; s_c1 += s["final_cost"]
+        tt = int(s.get("termination_type", -1))
+        term_hist[tt] = term_hist.get(tt, 0) + 1
+        ni = s["num_successful_steps"] + s["num_unsuccessful_steps"]
+        iter_hist[ni] = iter_hist.get(ni, 0) + 1
         per_frame.append((s["num_successful_steps"] + s["num_unsuccessful_steps"], s["initial_cost"], s["final_cost"], s["num_unsuccessful_steps"]))
     # positions relative to the (estimated) first keyframe, as SLAM::save_trajectory re-roots them (metric_embedding(0))
     Re0, te0 = synth.wt_to_rt(kf_pose[0])
@@ -206,14 +238,168 @@ def run(sigma_px, W, solve, frames=400, seed=4, max_iter=10):
     err = np.linalg.norm(est - gt, axis=1)
     half = len(per_frame) // 2
     tail = per_frame[half:]
-    return {"sigma_px": sigma_px, "W": W, "frames": frames, "avg_iterations": s_it / frames, "avg_initial_cost": s_c0 / frames,
-            "avg_final_cost": s_c1 / frames, "mean_position_error_m": float(err.mean()),
+    denom = frames * frames_per_keyframe                  # frame_id of src/main.cpp:84-89
+    return {"sigma_px": sigma_nominal, "W": W, "frames": frames, "avg_iterations": s_it / denom, "avg_initial_cost": s_c0 / denom,
+            "avg_final_cost": s_c1 / denom, "mean_position_error_m": float(err.mean()),
+            "per_call": {"iterations": s_it / max(1, n_lba), "initial_cost": s_c0 / max(1, n_lba), "final_cost": s_c1 / max(1, n_lba)},
+            # 0 NO_CONVERGENCE (iteration cap), 1 GRADIENT_TOLERANCE, 2 FUNCTION_TOLERANCE, 3 PARAMETER_TOLERANCE, 4 NUMERICAL_FAILURE
+            "termination_histogram": {str(k): v for k, v in sorted(term_hist.items())},
+            "iterations_histogram": {str(k): v for k, v in sorted(iter_hist.items())},
+            "settings": {"lm_init": lm_init, "frames_per_keyframe": frames_per_keyframe, "visibility": visibility,
+                         "noise_scale": noise_scale, "pose_noise": list(pose_noise), "motion_only": motion_only},
             "solver_time": {"lba_ms_per_call": 1e3 * t_lba / max(1, n_lba), "lba_calls": n_lba, "avg_observations_per_window": obs_lba / max(1, n_lba),
                             "motion_only_ms_per_call": 1e3 * t_mo / max(1, n_mo), "motion_only_calls": n_mo,
                             "optimisation_ms_per_keyframe": 1e3 * (t_lba + t_mo) / frames},
             "second_half": {"avg_iterations": float(np.mean([q[0] for q in tail])), "avg_initial_cost": float(np.mean([q[1] for q in tail])),
                             "avg_final_cost": float(np.mean([q[2] for q in tail])), "rejected_step_fraction": float(np.sum([q[3] for q in tail]) / max(1, np.sum([q[0] for q in tail])))},
             "positions": est}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The same simulated run driven through the REFERENCE's data flow around the two solves (numpy restatement of the glue the host
+# library implements in C++: slslam_amd/host/window_packer.cpp, gc_lite.cpp):
+#   * the visual odometry hands over the RELATIVE motion previous keyframe -> current frame; motion-only BA refines it with the
+#     two-camera problem of SLAM::motion_only_ba (src/slam.cpp:578-675: camera 0 = the motion, camera 1 = identity and constant,
+#     lines constant, given in the previous keyframe's frame); the new keyframe's pose is gc_T_20(motion, previous pose);
+#   * a landmark keeps its line as (point, direction) in the frame of the keyframe that initialised it (lm->line, init_kf);
+#   * the window arrays follow SLAM::bundle_adjustment (src/slam.cpp:811-921): free keyframes in ascending id, landmarks that are
+#     members of >= 2 free keyframes in ascending id, each with all its observations in ba_kfs in chronological order, keyframes
+#     of rank >= W appended as constant cameras when first met; write-back as src/slam.cpp:957-972.
+# tests/host_cxx/house_replay.cpp does the same with the C++ host library from the scene file `dump` writes;
+# tests/test_host_cxx.py::test_house_replay_cxx_equals_python compares the two trajectories.
+def _line_to_pose(line, R, t):
+    return np.concatenate([R @ line[:3] + t, R @ line[3:]])
+
+
+def _line_from_pose(line, R, t):
+    return _line_to_pose(line, R.T, -(R.T @ t))
+
+
+def run_reference_protocol(sigma_px, W, solve, frames=400, seed=4, max_iter=10, dump=None):
+    rng = np.random.default_rng([seed, int(round(100 * sigma_px)), W])
+    segs = house_segments()
+    truth = wave_trajectory(frames)
+    R0, t0 = truth[0]
+    truth = [(R @ R0.T, t - R @ R0.T @ t0) for R, t in truth]
+    segs0 = np.einsum("ij,nej->nei", R0, segs) + t0
+    kfT, members, lms, prev_obs = [], [], {}, None
+    s_it = s_c0 = s_c1 = 0.0
+    n_lba = n_mo = 0
+    digests = []
+
+    def fnv1a(data, h=1469598103934665603):
+        for b in data:
+            h = ((h ^ b) * 1099511628211) & 0xffffffffffffffff
+        return h
+    f = open(dump, "wb") if dump else None
+    if f:
+        np.array([frames, W, max_iter], dtype=np.int32).tofile(f)
+    for k in range(frames):
+        ids, ob = observe(truth[k][0], truth[k][1], segs0, sigma_px, rng)
+        obs_k = dict(zip(ids, ob))
+        tri = synth._initialize_lm(ob) if len(ids) else np.zeros((0, 6))          # stereo triangulation in the frame (initialize_lm)
+        motion_wt = np.zeros(6)
+        if k > 0:
+            Rrel = truth[k][0] @ truth[k - 1][0].T
+            trel = truth[k][1] - Rrel @ truth[k - 1][1]
+            motion_wt = synth.rt_to_wt(synth.rodrigues(rng.normal(0, np.deg2rad(0.2), 3)) @ Rrel, trel + rng.normal(0, 0.005, 3))
+        if f:
+            np.array([len(ids)], dtype=np.int32).tofile(f)
+            np.asarray(ids, dtype=np.int32).tofile(f)
+            np.asarray(ob, dtype=np.float64).tofile(f)
+            np.asarray(tri, dtype=np.float64).tofile(f)
+            motion_wt.tofile(f)
+        if k == 0:
+            R, t = np.eye(3), np.zeros(3)
+        else:
+            Rm, tm = synth.wt_to_rt(motion_wt)
+            Rp, tp = kfT[-1]
+            common = [i for i in ids if i in lms and i in prev_obs]
+            if len(common) >= 5:                                                    # SLAM::motion_only_ba
+                m = len(common)
+                lines_prev = [_line_to_pose(_line_from_pose(lms[i]["line"], *kfT[lms[i]["init"]]), Rp, tp) for i in common]
+                w = {"num_cameras": 2, "num_lines": m, "camera_index": np.tile([0, 1], m).astype(np.int32),
+                     "line_index": np.repeat(np.arange(m, dtype=np.int32), 2), "fixed_index": np.tile([0, 1, 1, 1], m).astype(np.int32),
+                     "observations": np.array([[obs_k[i], prev_obs[i]] for i in common]).reshape(2 * m, 8),
+                     "parameters": np.concatenate([synth.rt_to_wt(Rm, tm), synth.rt_to_wt(np.eye(3), np.zeros(3)),
+                                                   synth.av_to_orth(np.array(lines_prev)).reshape(-1)])}
+                x, _ = solve(w, max_iter)
+                Rm, tm = synth.wt_to_rt(x[:6])
+                n_mo += 1
+            R, t = Rm @ Rp, Rm @ tp + tm                                            # gc_T_20(motion, previous pose)
+        kfT.append((R, t)); members.append(list(ids))
+        for n, i in enumerate(ids):
+            if i not in lms:
+                lms[i] = {"line": tri[n].copy(), "init": k, "obs": []}
+            lms[i]["obs"].append((k, obs_k[i]))
+        prev_obs = obs_k
+        if k == 0:
+            continue
+        # ---- SLAM::bundle_adjustment on ba_kfs = the 2 W newest keyframes, rank = distance from the newest
+        rank = lambda j: (k - j) if k - j < 2 * W else -1
+        free = [j for j in range(k + 1) if 0 <= rank(j) < W]
+        count = {}
+        for j in free:
+            for i in members[j]:
+                count[i] = count.get(i, 0) + 1
+        slot = {j: n for n, j in enumerate(free)}
+        cam_kf = list(free)
+        ci, li, fi, oo, lm_ids = [], [], [], [], []
+        for i in sorted(count):
+            if count[i] < 2:
+                continue
+            for (j, o8) in lms[i]["obs"]:
+                if rank(j) < 0:
+                    continue
+                if j not in slot:
+                    slot[j] = len(cam_kf); cam_kf.append(j)
+                ci.append(slot[j]); li.append(len(lm_ids)); fi += [0 if slot[j] < W else 1, 0]; oo.append(o8)
+            lm_ids.append(i)
+        if not lm_ids:
+            continue
+        cams = np.concatenate([synth.rt_to_wt(*kfT[j]) for j in cam_kf])
+        lines_w = np.array([_line_from_pose(lms[i]["line"], *kfT[lms[i]["init"]]) for i in lm_ids])
+        w = {"num_cameras": len(cam_kf), "num_lines": len(lm_ids), "camera_index": np.array(ci, np.int32), "line_index": np.array(li, np.int32),
+             "fixed_index": np.array(fi, np.int32), "observations": np.array(oo), "parameters": np.concatenate([cams, synth.av_to_orth(lines_w).reshape(-1)])}
+        h = fnv1a(w["fixed_index"].tobytes(), fnv1a(w["line_index"].tobytes(), fnv1a(w["camera_index"].tobytes())))
+        digests.append((k, len(cam_kf) | (len(lm_ids) << 16) | (len(ci) << 32), h, fnv1a(np.ascontiguousarray(w["observations"]).tobytes())))
+        x, s = solve(w, max_iter)
+        n_lba += 1
+        for c, j in enumerate(cam_kf):                                              # slam.cpp:957-962: every camera, the constant ones too
+            kfT[j] = synth.wt_to_rt(x[6 * c:6 * c + 6])
+        for n, i in enumerate(lm_ids):                                              # :964-972: back into the (updated) initial keyframe
+            lms[i]["line"] = _line_to_pose(synth.orth_to_av(x[6 * len(cam_kf) + 4 * n:][:4]), *kfT[lms[i]["init"]])
+        s_it += s["num_successful_steps"] + s["num_unsuccessful_steps"]
+        s_c0 += s["initial_cost"]; s_c1 += s["final_cost"]
+    if f:
+        f.close()
+    poses = np.array([np.concatenate([R.reshape(-1), t]) for R, t in kfT])
+    return {"poses": poses, "window_digests": digests, "lm_iterations": int(s_it), "sum_initial_cost": s_c0, "sum_final_cost": s_c1, "lba_calls": n_lba, "motion_only_calls": n_mo}
+
+
+
+def sweep(solve, frames):
+    """Which simulator setting, if any, reproduces BOTH published columns (LM iterations per frame and cost per frame) of
+    the sigma = 0.2 and 1.0 px rows?  One factor at a time around the base setting, then the combinations the single factors
+    point to.  Prints one line per (setting, sigma, W) with the ratios to the reference file."""
+    base = dict(lm_init="stereo", frames_per_keyframe=1, visibility="both", noise_scale=1.0, pose_noise=(0.2, 0.005), motion_only=True)
+    variants = [("base", {}), ("lm_init=truth", dict(lm_init="truth")), ("visibility=left", dict(visibility="left")),
+                ("visibility=front", dict(visibility="front")), ("no motion-only BA", dict(motion_only=False)),
+                ("pose prediction exact", dict(pose_noise=(0.0, 0.0))), ("pose prediction 5x worse", dict(pose_noise=(1.0, 0.025))),
+                ("noise x1.36", dict(noise_scale=1.36)), ("noise x1.36, frames/kf=2", dict(noise_scale=1.36 * 2 ** 0.5, frames_per_keyframe=2)),
+                ("noise x1.36, frames/kf=3", dict(noise_scale=1.36 * 3 ** 0.5, frames_per_keyframe=3)),
+                ("frames/kf=3", dict(frames_per_keyframe=3)),
+                ("truth init, noise x1.36", dict(lm_init="truth", noise_scale=1.36)),
+                ("truth init, front, noise x1.25", dict(lm_init="truth", visibility="front", noise_scale=1.25))]
+    print("%-34s %5s %3s | %8s %8s %6s | %9s %9s %6s | %5s | %s" % ("setting", "sigma", "W", "it/frame", "file", "ratio", "cost/frm", "file", "ratio", "it/call", "termination (0 cap, 2 function tol.) / iterations histogram"))
+    for name, kw in variants:
+        for sg in (0.2, 1.0):
+            for W in (5, 10, 20):
+                r = run(sg, W, solve, frames=frames, **{**base, **kw})
+                ref = REFERENCE[(sg, W)]
+                print("%-34s %5.1f %3d | %8.3f %8.3f %6.2f | %9.3e %9.3e %6.2f | %5.2f | %s %s" % (
+                    name, sg, W, r["avg_iterations"], ref[0], r["avg_iterations"] / ref[0], r["avg_final_cost"], ref[2],
+                    r["avg_final_cost"] / ref[2], r["per_call"]["iterations"], r["termination_histogram"], r["iterations_histogram"]), flush=True)
 
 
 def make_solver(backend):
@@ -230,8 +416,19 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=400)
     ap.add_argument("--sigmas", default="0.2,0.6,1.0")
     ap.add_argument("--windows", default="5,10,20,40")
+    ap.add_argument("--dump-scene", default=None, help="run the reference-protocol pipeline (first sigma / window) and write the scene "
+                    "file tests/host_cxx/house_replay.cpp replays")
+    ap.add_argument("--sweep", action="store_true", help="sweep the simulator unknowns against the reference's two columns (profiles/round3_house_sweep.txt)")
     args = ap.parse_args()
     solve = make_solver(args.backend)
+    if args.sweep:
+        sweep(solve, args.frames)
+        sys.exit(0)
+    if args.dump_scene:
+        r = run_reference_protocol(float(args.sigmas.split(",")[0]), int(args.windows.split(",")[0]), solve, frames=args.frames, dump=args.dump_scene)
+        r.pop("poses"); r.pop("window_digests")
+        print(json.dumps(r))
+        sys.exit(0)
     for s in [float(x) for x in args.sigmas.split(",")]:
         for W in [int(x) for x in args.windows.split(",")]:
             r = run(s, W, solve, frames=args.frames)
