@@ -200,6 +200,7 @@ struct slslam_lba_batch {
   DevBuf<long long> d_big_sys_off;
   DevBuf<double> d_slab_sum;
   long long slab_sum_stride = 0;           // > 0: k_slab_reduce runs ahead of the reduced solve
+  int line_elim_stride = kLineElim;
   DevBuf<double> d_slab, d_bs_part, d_cost_part, d_ysys, d_params_out, d_fstore, d_line_elim;
   DevBuf<LMState> d_state; DevBuf<IterRec> d_trace; DevBuf<long long> d_param_off;
   BatchPtrs ptrs;
@@ -372,12 +373,6 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
       cam_cf.push_back(P.cam_cf[c]); cam_win.push_back(wi);
     }
     {
-      const size_t l0 = line_x.size();
-      line_x.resize(l0 + (size_t)P.L * 2 * kLineRec, 0.0);              // both parameter buffers: (a, b, g, t) | sin/cos table (filled on the device)
-      double* lx = line_x.data() + l0;
-      for (int s = 0; s < P.L; ++s)
-        for (int buf = 0; buf < 2; ++buf)
-          for (int a = 0; a < 4; ++a) lx[((size_t)s * 2 + buf) * kLineRec + a] = P.line_u[4 * (size_t)s + a];
       line_u0.insert(line_u0.end(), P.line_u.begin(), P.line_u.end());
       const size_t p0 = line_ptr.size();
       line_ptr.resize(p0 + (size_t)P.L);
@@ -440,7 +435,14 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if (cam_cf.empty()) { cam_cf.push_back(-1); cam_win.push_back(0); }
   ar.upload(b->d_cam_cf, cam_cf);
   ar.upload(b->d_cam_win, cam_win);
-  if (line_x.empty()) line_x.assign(2 * kLineRec, 0.0);
+  {
+    // both parameter buffers, buffer-major [2][nline][kLineRec]: (a, b, g, t) | sin/cos table (filled on the device)
+    const size_t nl = (size_t)std::max<long long>(1, nline);
+    line_x.assign(2 * nl * kLineRec, 0.0);
+    for (size_t ls = 0; ls < (size_t)nline; ++ls)
+      for (int buf = 0; buf < 2; ++buf)
+        for (int a = 0; a < 4; ++a) line_x[((size_t)buf * nl + ls) * kLineRec + a] = line_u0[4 * ls + a];
+  }
   ar.upload(b->d_line_x, line_x);
   if (line_u0.empty()) line_u0.assign(4, 0.0);
   ar.upload(b->d_line_x0, line_u0);
@@ -470,7 +472,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.scratch(b->d_cost_part, std::max<size_t>(1, (size_t)b->nchunk));
   ar.scratch(b->d_ysys, std::max<size_t>(1, (size_t)sys));
   ar.scratch(b->d_fstore, b->opt.reuse_elimination ? (size_t)24 * (size_t)std::max<long long>(1, nobs) : 2);
-  ar.scratch(b->d_line_elim, std::max<size_t>(1, (size_t)nline * kLineElim));
+  b->line_elim_stride = (b->opt.reuse_elimination || b->big_mode) ? kLineElim : kLeU;      // K g is kept for those two paths only
+  ar.scratch(b->d_line_elim, std::max<size_t>(1, (size_t)nline * b->line_elim_stride));
   ar.scratch(b->d_params_out, std::max<size_t>(1, (size_t)param_off));
   ar.upload(b->d_state, b->h_state0);
   ar.zeroed(b->d_trace, std::max<size_t>(1, (size_t)B * kMaxTrace));
@@ -523,7 +526,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.ob = b->d_ob.p; p.ob_cam = b->d_ob_cam.p; p.ob_stride = std::max<long long>(1, nobs);
   p.slab_sum = b->slab_sum_stride ? b->d_slab_sum.p : nullptr; p.slab_sum_stride = b->slab_sum_stride;
   p.slab = b->d_slab.p; p.bs_part = b->d_bs_part.p; p.cost_part = b->d_cost_part.p; p.ysys = b->d_ysys.p;
-  p.fstore = b->d_fstore.p; p.line_elim = b->d_line_elim.p;
+  p.fstore = b->d_fstore.p; p.line_elim = b->d_line_elim.p; p.line_elim_stride = b->line_elim_stride;
   p.state = b->d_state.p; p.trace = b->d_trace.p;
   p.iter_counter = b->d_iter_counter.p; p.active_counter = b->d_active.p; p.cam_x0 = b->d_cam_x0.p; p.line_u0 = b->d_line_x0.p;
   p.nwin = B; p.nchunk = b->nchunk; p.nline = b->nline; p.ncam = b->ncam;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(128) void k_big_linearise(BatchPtrs p, BigPtrs bg, 
   double R[9], JL[9], t[3], trig[7], ob[8];
   for (int q = 0; q < 9; ++q) { R[q] = ct[q]; JL[q] = ct[9 + q]; }
   for (int q = 0; q < 3; ++q) t[q] = ct[18 + q];
-  const double* lrec = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
+  const double* lrec = p.line_x + line_rec(p, ls, cur);
   for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
   for (int q = 0; q < 4; ++q) {
     const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(128) void k_big_line(BatchPtrs p, BigPtrs bg, Polic
   double* lsc = p.line_scale + (long long)ls * 4;
   if (fresh) {
     const double d[4] = { H[0], H[2], H[5], H[9] };
-    const double* ul = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
+    const double* ul = p.line_x + line_rec(p, ls, cur);
     double sl[4], gm = 0.0, xn2 = 0.0;
     for (int a = 0; a < 4; ++a) {
       sl[a] = (pol.jacobi_scaling && line_active) ? 1.0 / (1.0 + sqrt(d[a])) : 1.0;
@@ -188,9 +188,9 @@ __global__ __launch_bounds__(128) void k_big_line(BatchPtrs p, BigPtrs bg, Polic
       atomic_max_nonneg(&sc[kBgGmaxLine], gm);
     }
   }
-  double* le = p.line_elim + (long long)ls * kLineElim;
+  double* le = p.line_elim + (long long)ls * p.line_elim_stride;
   for (int q = 0; q < 10; ++q) le[q] = K[q];
-  for (int q = 0; q < 4; ++q) { le[10 + q] = u[q]; le[14 + q] = D2[q]; le[18 + q] = g[q]; }
+  for (int q = 0; q < 4; ++q) { le[kLeU + q] = u[q]; le[kLeD2 + q] = D2[q]; le[kLeG + q] = g[q]; }
 }
 
 // first sweep only: the line Jacobians were kept unscaled (the scale comes out of k_big_line)
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(128) void k_big_schur(BatchPtrs p, BigPtrs bg) {
   const int ls = bg.ob_line[oi], w = p.line_win[ls];
   const WinDesc wd = p.wins[w];
   if (p.state[w].status != kRunning) return;
-  const double* le = p.line_elim + (long long)ls * kLineElim;
+  const double* le = p.line_elim + (long long)ls * p.line_elim_stride;
   double K[10], Fi[24], Fj[24];
   for (int q = 0; q < 10; ++q) K[q] = le[q];
   big_F(bg.J + (long long)oi * kBigObs, K, Fi);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(128) void k_big_schur(BatchPtrs p, BigPtrs bg) {
   if (oi == oj) {
     double* bvec = S + (long long)n * ld;
     for (int a = 0; a < 6; ++a) {
-      atomicAdd(&bvec[6 * ci + a], -(Fi[4 * a] * le[10] + Fi[4 * a + 1] * le[11] + Fi[4 * a + 2] * le[12] + Fi[4 * a + 3] * le[13]));
+      atomicAdd(&bvec[6 * ci + a], -(Fi[4 * a] * le[kLeU] + Fi[4 * a + 1] * le[kLeU + 1] + Fi[4 * a + 2] * le[kLeU + 2] + Fi[4 * a + 3] * le[kLeU + 3]));
       for (int b = 0; b <= a; ++b) {
         double v = 0.0;
         for (int m = 0; m < 4; ++m) v += Fi[4 * a + m] * Fi[4 * b + m];
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(128) void k_big_backsub_obs(BatchPtrs p, BigPtrs bg
   if (p.state[w].status != kRunning) return;
   const int cf = p.cam_cf[wd.cam_off + p.ob_cam[o]];
   if (cf < 0 || (p.line_flags[ls] & 1)) return;
-  const double* le = p.line_elim + (long long)ls * kLineElim;
+  const double* le = p.line_elim + (long long)ls * p.line_elim_stride;
   double K[10], F[24];
   for (int q = 0; q < 10; ++q) K[q] = le[q];
   big_F(bg.J + o * kBigObs, K, F);
@@ -464,14 +464,14 @@ __global__ __launch_bounds__(128) void k_big_backsub_line(BatchPtrs p, BigPtrs b
   const int cur = st->cur;
   const int k = p.line_ptr[ls + 1] - p.line_ptr[ls];
   const bool line_active = !(p.line_flags[ls] & 1) && k > 0;
-  const double* xl = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
-  double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
+  const double* xl = p.line_x + line_rec(p, ls, cur);
+  double* xc = p.line_x + line_rec(p, ls, (1 - cur));
   double xn[4] = { xl[0], xl[1], xl[2], xl[3] };
   if (line_active) {
-    const double* le = p.line_elim + (long long)ls * kLineElim;
+    const double* le = p.line_elim + (long long)ls * p.line_elim_stride;
     const double* wv = bg.line_acc + (long long)ls * kBigLine + 14;
     const double* lsc = p.line_scale + (long long)ls * 4;
-    const double z0 = le[10] - wv[0], z1 = le[11] - wv[1], z2 = le[12] - wv[2], z3 = le[13] - wv[3];
+    const double z0 = le[kLeU] - wv[0], z1 = le[kLeU + 1] - wv[1], z2 = le[kLeU + 2] - wv[2], z3 = le[kLeU + 3] - wv[3];
     double y[4];
     y[0] = le[0] * z0 + le[1] * z1 + le[3] * z2 + le[6] * z3;
     y[1] = le[2] * z1 + le[4] * z2 + le[7] * z3;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(128) void k_big_backsub_line(BatchPtrs p, BigPtrs b
     y[3] = le[9] * z3;
     double model = 0.0, dn2 = 0.0, xn2 = 0.0;
     for (int a = 0; a < 4; ++a) {
-      model += 0.5 * y[a] * (le[18 + a] + le[14 + a] * y[a]);
+      model += 0.5 * y[a] * (le[kLeG + a] + le[kLeD2 + a] * y[a]);
       const double v = xn[a] - y[a] * lsc[a];
       const double dd = xn[a] - v;
       dn2 += dd * dd; xn2 += v * v;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(128) void k_big_cost(BatchPtrs p, BigPtrs bg, Polic
   const int cam = wd.cam_off + p.ob_cam[o], cf = p.cam_cf[cam];
   if (cf < 0 && (p.line_flags[ls] & 1)) return;                         // not in the reduced program
   const double* ct = bg.camtab + ((long long)cam * 2 + 1) * kBigCam;
-  const double* lrec = p.line_x + ((long long)ls * 2 + (1 - st->cur)) * kLineRec;
+  const double* lrec = p.line_x + line_rec(p, ls, (1 - st->cur));
   double R[9], t[3] = { ct[18], ct[19], ct[20] }, trig[7], ob[8], cp[3], dv[3], r[4], c;
   for (int q = 0; q < 9; ++q) R[q] = ct[q];
   for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];

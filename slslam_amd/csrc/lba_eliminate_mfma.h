@@ -277,7 +277,7 @@ void k_eliminate_mfma(BatchPtrs p, Policy pol) {
         for (int a = 0; a < 4; ++a) sl[a] = (pol.jacobi_scaling && line_active) ? 1.0 / (1.0 + sqrt(d[a])) : 1.0;
         if (line_ok && j == 0) {
           double* lsc = p.line_scale + (long long)ls * 4;
-          const double* ul = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
+          const double* ul = p.line_x + line_rec(p, ls, cur);
           for (int a = 0; a < 4; ++a) {
             lsc[a] = sl[a];
             if (line_active) { acc_gmax = fmax(acc_gmax, fabs(g[a])); acc_xn2 += ul[a] * ul[a]; }
@@ -310,11 +310,11 @@ void k_eliminate_mfma(BatchPtrs p, Policy pol) {
           for (int a = 0; a < 4; ++a) acc_gmax = fmax(acc_gmax, fabs(g[a] / pf.lsc[a]));
         }
         if (j == 0) {                                  // the line's factor, for the back-substitution of this iteration
-          double* le = p.line_elim + (long long)ls * kLineElim;
+          double* le = p.line_elim + (long long)ls * p.line_elim_stride;
 #pragma unroll
           for (int q = 0; q < 10; ++q) le[q] = K[q];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { le[14 + q] = D2[q]; le[18 + q] = g[q]; }
+          for (int q = 0; q < 4; ++q) { le[kLeD2 + q] = D2[q]; le[kLeG + q] = g[q]; }
         }
       }
       SLS_STAMP(4);

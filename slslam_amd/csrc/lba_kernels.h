@@ -260,7 +260,7 @@ __device__ __forceinline__ void prefetch_obs(const BatchPtrs& p, const TileCtx& 
   }
   f.cam = p.ob_cam[o];
   const int lsafe = c.line_ok ? c.ls : 0;
-  const double* lrec = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
+  const double* lrec = p.line_x + line_rec(p, lsafe, cur);
 #pragma unroll
   for (int q = 0; q < 7; ++q) f.trig[q] = lrec[4 + q];
   const double* ls = p.line_scale + (long long)lsafe * 4;
@@ -301,7 +301,7 @@ __device__ __forceinline__ void lane_linearise(const BatchPtrs& p, const Policy&
       ob[2 * q] = e.x; ob[2 * q + 1] = e.y;
     }
     L.cam = p.ob_cam[o];
-    const double* lrec = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
+    const double* lrec = p.line_x + line_rec(p, lsafe, cur);
 #pragma unroll
     for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
   }
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       if (line_ok && j == 0) {
         const double d[4] = { H[0], H[2], H[5], H[9] };
         double* lsc = p.line_scale + (long long)ls * 4;
-        const double* u = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
+        const double* u = p.line_x + line_rec(p, ls, cur);
         for (int a = 0; a < 4; ++a) {
           lsc[a] = (pol.jacobi_scaling && line_active) ? 1.0 / (1.0 + sqrt(d[a])) : 1.0;
           if (line_active) { acc_gmax = fmax(acc_gmax, fabs(g[a])); acc_xn2 += u[a] * u[a]; }
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
       for (int a = 0; a < 4; ++a) sl[a] = (pol.jacobi_scaling && line_active) ? 1.0 / (1.0 + sqrt(d[a])) : 1.0;
       if (line_ok && j == 0) {
         double* lsc = p.line_scale + (long long)ls * 4;
-        const double* ul = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
+        const double* ul = p.line_x + line_rec(p, ls, cur);
         for (int a = 0; a < 4; ++a) {
           lsc[a] = sl[a];
           if (line_active) { acc_gmax = fmax(acc_gmax, fabs(g[a])); acc_xn2 += ul[a] * ul[a]; }
@@ -634,14 +634,14 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     // the per-line factor is kept for the back-substitution of the same iteration (176 B per line against
     // ~500 B of observations): it does not have to rebuild and refactor the 4x4 block
     if (line_active && j == 0) {
-      double* le = p.line_elim + (long long)ls * kLineElim;
+      double* le = p.line_elim + (long long)ls * p.line_elim_stride;
 #pragma unroll
       for (int q = 0; q < 10; ++q) le[q] = K[q];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { le[14 + q] = D2[q]; le[18 + q] = g[q]; }
+      for (int q = 0; q < 4; ++q) { le[kLeD2 + q] = D2[q]; le[kLeG + q] = g[q]; }
       if (pol.store_f) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) le[10 + q] = u[q];      // only the streaming back-substitution wants K g
+        for (int q = 0; q < 4; ++q) le[kLeU + q] = u[q];      // only the streaming back-substitution wants K g
       }
     }
 
@@ -1430,11 +1430,11 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     // D^2, g_l (the same values this sweep would recompute); every lane of the line's run reads the same record
     double K[10], D2[4], g[4];
     {
-      const double* le = p.line_elim + (long long)(tc.line_ok ? tc.ls : 0) * kLineElim;
+      const double* le = p.line_elim + (long long)(tc.line_ok ? tc.ls : 0) * p.line_elim_stride;
 #pragma unroll
       for (int q = 0; q < 10; ++q) K[q] = le[q];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { D2[q] = le[14 + q]; g[q] = le[18 + q]; }
+      for (int q = 0; q < 4; ++q) { D2[q] = le[kLeD2 + q]; g[q] = le[kLeG + q]; }
     }
     LaneBs L;
     double ob[8], wo[4];
@@ -1495,7 +1495,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     }
     SLS_PHASE("bs_store_candidate");
     if (head) {
-      double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
+      double* xc = p.line_x + line_rec(p, ls, (1 - cur));
       for (int a = 0; a < 4; ++a) xc[a] = xn[a];
       for (int a = 0; a < 7; ++a) xc[4 + a] = trig[a];
     }
@@ -1578,15 +1578,15 @@ __global__ __launch_bounds__(64) void k_backsub_stream(BatchPtrs p, Policy pol) 
     }
     seg_sum_n<4>(v, sg);
     if (line_ok && j == 0) {
-      const double* xl = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
-      double* xc = p.line_x + ((long long)ls * 2 + (1 - cur)) * kLineRec;
+      const double* xl = p.line_x + line_rec(p, ls, cur);
+      double* xc = p.line_x + line_rec(p, ls, (1 - cur));
       double xn[4] = { xl[0], xl[1], xl[2], xl[3] };
       if (line_active) {
-        const double* le = p.line_elim + (long long)ls * kLineElim;
+        const double* le = p.line_elim + (long long)ls * p.line_elim_stride;
         double K[10];
 #pragma unroll
         for (int q = 0; q < 10; ++q) K[q] = le[q];
-        const double z0 = le[10] - v[0], z1 = le[11] - v[1], z2 = le[12] - v[2], z3 = le[13] - v[3];
+        const double z0 = le[kLeU] - v[0], z1 = le[kLeU + 1] - v[1], z2 = le[kLeU + 2] - v[2], z3 = le[kLeU + 3] - v[3];
         double y[4];
         y[0] = K[0] * z0 + K[1] * z1 + K[3] * z2 + K[6] * z3;
         y[1] = K[2] * z1 + K[4] * z2 + K[7] * z3;
@@ -1595,7 +1595,7 @@ __global__ __launch_bounds__(64) void k_backsub_stream(BatchPtrs p, Policy pol) 
         const double* lsc = p.line_scale + (long long)ls * 4;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          acc_model += 0.5 * y[a] * (le[18 + a] + le[14 + a] * y[a]);
+          acc_model += 0.5 * y[a] * (le[kLeG + a] + le[kLeD2 + a] * y[a]);
           const double vv = xn[a] - y[a] * lsc[a];
           const double dd = xn[a] - vv;
           acc_dn2 += dd * dd;
@@ -1623,7 +1623,7 @@ __global__ __launch_bounds__(256) void k_line_trig(BatchPtrs p, int which) {
   const LMState* st = p.state + p.line_win[ls];
   if (st->status != kRunning) return;
   const int buf = which ? 1 - st->cur : st->cur;
-  double* rec = p.line_x + ((long long)ls * 2 + buf) * kLineRec;
+  double* rec = p.line_x + line_rec(p, ls, buf);
   double u[4] = { rec[0], rec[1], rec[2], rec[3] }, trig[7];
   line_trig<double>(u, trig);
   for (int q = 0; q < 7; ++q) rec[4 + q] = trig[q];
@@ -1661,7 +1661,7 @@ __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) 
     }
     const int cam = p.ob_cam[o];
     const int lsafe = line_ok ? ls : 0;
-    const double* lrec = p.line_x + ((long long)lsafe * 2 + cand) * kLineRec;
+    const double* lrec = p.line_x + line_rec(p, lsafe, cand);
     double trig[7];
 #pragma unroll
     for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
@@ -1883,7 +1883,7 @@ __global__ __launch_bounds__(256) void k_reset(BatchPtrs p, Policy pol) {
     const long long ls = i >> 2;
     const int a = (int)(i & 3);
     const double v = p.line_u0[i];
-    p.line_x[ls * 2 * kLineRec + a] = v; p.line_x[ls * 2 * kLineRec + kLineRec + a] = v;
+    p.line_x[line_rec(p, ls, 0) + a] = v; p.line_x[line_rec(p, ls, 1) + a] = v;
   } else if (i < nlp + ncp) {
     const long long q = i - nlp, c = q / 6;
     const double v = p.cam_x0[q];
@@ -1916,7 +1916,7 @@ __global__ __launch_bounds__(256) void k_export(BatchPtrs p, const long long* wi
     const int w = p.line_win[ls];
     const WinDesc wd = p.wins[w];
     const int cur = p.state[w].cur;
-    const double* x = p.line_x + ((long long)ls * 2 + cur) * kLineRec;
+    const double* x = p.line_x + line_rec(p, ls, cur);
     double* o = out + win_param_off[w] + 6 * (long long)wd.C + 4 * (long long)line_orig[ls];
     for (int a = 0; a < 4; ++a) o[a] = x[a];
   }

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64) void k_motion_only(BatchPtrs p, Policy pol) {
       }
       const int cam = p.ob_cam[o];
       const int lsafe = tc.line_ok ? tc.ls : 0;
-      const double* lrec = p.line_x + ((long long)lsafe * 2 + cur) * kLineRec;
+      const double* lrec = p.line_x + line_rec(p, lsafe, cur);
       double trig[7];
 #pragma unroll
       for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];

@@ -12,8 +12,11 @@ namespace slslam {
 
 enum { kRunning = -1 };                 // LMState.status while the window is still iterating
 enum { kMaxTrace = 64 };                // iteration records kept per window
-enum { kLineRec = 12 };                 // doubles per line record: u[4], trig[7], pad
-enum { kLineElim = 22 };               // doubles per line kept by the elimination: K[10], u[4], D2[4], g[4]
+enum { kLineRec = 11 };                 // doubles per line record: u[4], trig[7] (88 B, no pad: the sweeps stream whole records)
+enum { kLineElim = 22 };               // doubles per line kept by the elimination: K[10], D2[4], g[4] and - for the streaming
+                                       // back-substitution and the global-memory path only - u[4] = K g; the record stride is
+                                       // BatchPtrs.line_elim_stride (18 without u: the back-substitution reads whole records)
+enum { kLeD2 = 10, kLeG = 14, kLeU = 18 };
 enum { kCamRec = 6 };                   // doubles per camera record: w[3], t[3]
 enum { kSlabScalars = 8 };              // per-chunk scalars written by the linearise kernel
 enum { kMaxCams = 64, kMaxFreeCams = 20 };
@@ -116,7 +119,7 @@ struct BatchPtrs {
   double* cam_scale;          // [ncam][6]
   const int* cam_cf;          // [ncam] index among the window's free cameras, or -1
   // lines (sorted order)
-  double* line_x;             // [nline][2][12]
+  double* line_x;             // [2][nline][12]: buffer-major, so that a sweep reading one buffer of consecutive lines streams dense memory
   double* line_scale;         // [nline][4]
   const int* line_ptr;        // [nline+1] first sorted observation of each line
   const int* line_flags;      // [nline] bit0: constant
@@ -134,7 +137,8 @@ struct BatchPtrs {
   double* cost_part;          // [nchunk]
   double* ysys;               // y_c per window (sys_off)
   double* fstore;             // [12][ob_stride] double2: F = (Jc^T Jl) K^T (6x4, row-major) of every coupled observation
-  double* line_elim;          // [nline][kLineElim]
+  double* line_elim;          // [nline][line_elim_stride]
+  int line_elim_stride;
   LMState* state;
   IterRec* trace;             // [nwin][kMaxTrace]
   unsigned long long* iter_counter;   // LM iterations executed by the batch since the counter was cleared
@@ -147,6 +151,12 @@ struct BatchPtrs {
                               // (lba_eliminate_mfma.h), slab layout sys_doubles_mfma()
   int elim_waves;             // waves per chunk workgroup of the sweeps (1 or 2)
 };
+
+// offset (doubles) of line ls's record in parameter buffer buf of BatchPtrs.line_x
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline long long line_rec(const BatchPtrs& p, long long ls, int buf) { return ((long long)buf * p.nline + ls) * kLineRec; }
 
 }  // namespace slslam
 #endif

@@ -402,6 +402,20 @@ def sweep(solve, frames):
                     r["avg_final_cost"] / ref[2], r["per_call"]["iterations"], r["termination_histogram"], r["iterations_histogram"]), flush=True)
 
 
+def function_tolerance_study(frames):
+    """The one LM-policy number the iteration column is sensitive to: Ceres' function_tolerance (default 1e-6, which the reference
+    does not override: src/lba_problem.cpp:95-132).  Oracle runs of the base setting with 1e-6 .. 1e-3."""
+    from oracle import pyoracle
+    for ftol in (1e-6, 1e-5, 1e-4, 1e-3):
+        solve = lambda w, it: pyoracle.lba_solve(w, linear_solver=1, max_num_iterations=it, function_tolerance=ftol)[:2]
+        out = []
+        for sg, W in ((0.2, 5), (0.2, 10), (0.2, 20), (1.0, 5), (1.0, 10), (1.0, 20)):
+            r = run(sg, W, solve, frames=frames)
+            ref = REFERENCE[(sg, W)]
+            out.append("%.1f/%d it %.2f (file %.2f) cost %.2f" % (sg, W, r["avg_iterations"], ref[0], r["avg_final_cost"] / ref[2]))
+        print("function_tolerance %g: " % ftol + " | ".join(out), flush=True)
+
+
 def make_solver(backend):
     if backend == "oracle":
         from oracle import pyoracle
@@ -423,6 +437,8 @@ if __name__ == "__main__":
     solve = make_solver(args.backend)
     if args.sweep:
         sweep(solve, args.frames)
+        if args.backend == "oracle":
+            function_tolerance_study(args.frames)
         sys.exit(0)
     if args.dump_scene:
         r = run_reference_protocol(float(args.sigmas.split(",")[0]), int(args.windows.split(",")[0]), solve, frames=args.frames, dump=args.dump_scene)
