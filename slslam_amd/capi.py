@@ -81,7 +81,7 @@ EXPORTS = [
     "slslam_default_options", "slslam_lba_solve", "slslam_lba_batch_create", "slslam_lba_batch_destroy",
     "slslam_lba_batch_add", "slslam_lba_batch_finalize", "slslam_lba_batch_solve", "slslam_lba_batch_reset",
     "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
-    "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts", "slslam_lba_batch_window_chunks",
+    "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts", "slslam_lba_batch_window_chunks", "slslam_lba_batch_path",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
     "slslam_po_solve", "slslam_po_structure", "slslam_po_set_profiling", "slslam_po_last_timing", "slslam_debug_phase_cycles", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_release_cached_memory", "slslam_version", "slslam_status_string",
 ]
@@ -116,6 +116,7 @@ def lib():
     L.slslam_lba_batch_export_device.argtypes = [vp, vp, vp]
     L.slslam_lba_batch_counts.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 5
     L.slslam_lba_batch_window_chunks.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.slslam_lba_batch_path.argtypes = [vp, C.POINTER(C.c_int)]
     L.slslam_lba_batch_iterations.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.c_int]
     L.slslam_lba_batch_set_profiling.argtypes = [vp, C.c_int]
     L.slslam_lba_batch_kernel_times.argtypes = [vp, dp, ip]
@@ -280,6 +281,11 @@ class LBABatch:
         v = [C.c_longlong(0) for _ in range(5)]
         _check(lib().slslam_lba_batch_counts(self._h, *[C.byref(x) for x in v]), "slslam_lba_batch_counts")
         return dict(zip(["windows", "cameras", "free_cameras", "lines", "observations"], [x.value for x in v]))
+
+    def path(self):
+        v = C.c_int(-1)
+        _check(lib().slslam_lba_batch_path(self._h, C.byref(v)), "slslam_lba_batch_path")
+        return v.value
 
     def window_chunks(self, i):
         v = C.c_int(0)

@@ -195,8 +195,8 @@ struct slslam_lba_batch {
   bool big_mode = false;
   BigPtrs big;
   std::vector<long long> h_big_sys_off, h_big_linv_off;
-  DevBuf<int> d_big_ob_line, d_big_pair_i, d_big_pair_j, d_big_flags;
-  DevBuf<double> d_big_J, d_big_camtab, d_big_line_acc, d_big_sys, d_big_scal, d_big_linv;
+  DevBuf<int> d_big_ob_line, d_big_cam_ptr, d_big_cam_obs, d_big_pair_ptr, d_big_pair_row, d_big_pair_col, d_big_pair_desc, d_big_flags;
+  DevBuf<double> d_big_J, d_big_F, d_big_cost, d_big_camtab, d_big_line_acc, d_big_sys, d_big_scal, d_big_linv;
   DevBuf<long long> d_big_sys_off;
   DevBuf<double> d_slab_sum;
   long long slab_sum_stride = 0;           // > 0: k_slab_reduce runs ahead of the reduced solve
@@ -239,7 +239,8 @@ struct slslam_lba_batch {
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
     d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release(); d_active.release();
     d_fstore.release(); d_line_elim.release(); d_slab_sum.release();
-    d_big_ob_line.release(); d_big_pair_i.release(); d_big_pair_j.release(); d_big_flags.release(); d_big_J.release();
+    d_big_ob_line.release(); d_big_cam_ptr.release(); d_big_cam_obs.release(); d_big_pair_ptr.release(); d_big_pair_row.release();
+    d_big_pair_col.release(); d_big_pair_desc.release(); d_big_flags.release(); d_big_J.release(); d_big_F.release(); d_big_cost.release();
     d_big_camtab.release(); d_big_line_acc.release(); d_big_sys.release(); d_big_scal.release(); d_big_linv.release(); d_big_sys_off.release();
     arena.release();
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -478,15 +479,40 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.upload(b->d_state, b->h_state0);
   ar.zeroed(b->d_trace, std::max<size_t>(1, (size_t)B * kMaxTrace));
   ar.upload(b->d_param_off, b->h_param_off);
-  std::vector<int> big_ob_line, big_pair_i, big_pair_j;
+  std::vector<int> big_ob_line, big_cam_ptr, big_cam_obs, big_pair_ptr, big_pair_row, big_pair_col, big_pair_desc;
   if (b->big_mode) {
+    // gather lists of the global-memory path (lba_big.h): per camera its observations, per (window, camera pair r >= c) the
+    // observation pairs of the lines both cameras see - every sum is walked in list order, so results are reproducible
+    if (B > 0xffff) return SLSLAM_ERR_UNSUPPORTED;
     long long sys_cursor = 0, linv_cursor = 0, oc = 0, lc = 0;
     b->h_big_sys_off.resize(B); b->h_big_linv_off.resize(B);
     big_ob_line.reserve((size_t)nobs);
+    big_cam_ptr.assign((size_t)ncam + 1, 0);
+    big_cam_obs.resize((size_t)std::max<long long>(1, nobs));
+    std::vector<int> pr_row, pr_col, pr_id;                  // unsorted items with their global pair id
+    {
+      size_t items = 0, pairs = 0;
+      for (const PackedWindow& P : b->wins) {
+        pairs += (size_t)(P.Cf * (P.Cf + 1)) / 2;
+        for (int s2 = 0; s2 < P.L; ++s2) {
+          if (P.line_flags[s2] & 1) continue;
+          const int o0 = P.line_ptr[s2], k = P.line_ptr[s2 + 1] - o0;
+          int kf = 0;
+          while (kf < k && P.cam_cf[P.ob_cam[o0 + kf]] >= 0) ++kf;
+          items += (size_t)(kf * (kf - 1)) / 2;
+        }
+      }
+      pr_row.reserve(items); pr_col.reserve(items); pr_id.reserve(items); big_pair_desc.reserve(pairs);
+    }
+    long long pair_base = 0;
     for (int wi = 0; wi < B; ++wi) {
       const PackedWindow& P = b->wins[wi];
+      const int cam_off = b->h_wins[wi].cam_off;
       b->h_big_sys_off[wi] = sys_cursor; sys_cursor += big_sys_doubles(6 * P.Cf);
       b->h_big_linv_off[wi] = linv_cursor; linv_cursor += (long long)((6 * P.Cf + kNB - 1) / kNB + 1) * kNB * kNB;
+      for (int o = 0; o < P.M; ++o) big_cam_ptr[(size_t)cam_off + P.ob_cam[o] + 1]++;
+      for (int r = 0; r < P.Cf; ++r)
+        for (int c = 0; c <= r; ++c) big_pair_desc.push_back(wi | (r << 16) | (c << 24));
       for (int s2 = 0; s2 < P.L; ++s2) {
         const int o0 = P.line_ptr[s2], k = P.line_ptr[s2 + 1] - o0;
         for (int j = 0; j < k; ++j) big_ob_line.push_back((int)lc + s2);
@@ -494,18 +520,49 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
         int kf = 0;                                        // free-camera observations come first
         while (kf < k && P.cam_cf[P.ob_cam[o0 + kf]] >= 0) ++kf;
         for (int i = 0; i < kf; ++i)
-          for (int j = i; j < kf; ++j) { big_pair_i.push_back((int)(oc + o0 + i)); big_pair_j.push_back((int)(oc + o0 + j)); }
+          for (int j = i + 1; j < kf; ++j) {
+            const int ci = P.cam_cf[P.ob_cam[o0 + i]], cj = P.cam_cf[P.ob_cam[o0 + j]];
+            const bool jr = cj >= ci;                      // row: the camera with the larger free index (lower triangle)
+            const int r = jr ? cj : ci, c = jr ? ci : cj;
+            pr_row.push_back((int)(oc + o0 + (jr ? j : i))); pr_col.push_back((int)(oc + o0 + (jr ? i : j)));
+            pr_id.push_back((int)(pair_base + (r * (r + 1)) / 2 + c));
+          }
       }
+      pair_base += (long long)(P.Cf * (P.Cf + 1)) / 2;
       oc += P.M; lc += P.L;
     }
+    for (size_t c = 0; c < (size_t)ncam; ++c) big_cam_ptr[c + 1] += big_cam_ptr[c];
+    {
+      std::vector<int> fill(big_cam_ptr.begin(), big_cam_ptr.end() - 1);
+      long long og = 0;
+      for (int wi = 0; wi < B; ++wi) {
+        const PackedWindow& P = b->wins[wi];
+        for (int o = 0; o < P.M; ++o, ++og) big_cam_obs[(size_t)fill[(size_t)b->h_wins[wi].cam_off + P.ob_cam[o]]++] = (int)og;
+      }
+    }
+    const size_t npairs = big_pair_desc.size();
+    big_pair_ptr.assign(npairs + 1, 0);
+    for (int id : pr_id) big_pair_ptr[(size_t)id + 1]++;
+    for (size_t q = 0; q < npairs; ++q) big_pair_ptr[q + 1] += big_pair_ptr[q];
+    big_pair_row.resize(std::max<size_t>(1, pr_id.size())); big_pair_col.resize(std::max<size_t>(1, pr_id.size()));
+    {
+      std::vector<int> fill(big_pair_ptr.begin(), big_pair_ptr.end() - 1);          // counting sort: items of a pair stay in line order
+      for (size_t q = 0; q < pr_id.size(); ++q) { const int at = fill[(size_t)pr_id[q]]++; big_pair_row[(size_t)at] = pr_row[q]; big_pair_col[(size_t)at] = pr_col[q]; }
+    }
     if (big_ob_line.empty()) big_ob_line.push_back(0);
-    b->big.npairs = (long long)big_pair_i.size();
-    if (big_pair_i.empty()) { big_pair_i.push_back(0); big_pair_j.push_back(0); }
+    b->big.npairs = (long long)npairs;
+    if (big_pair_desc.empty()) big_pair_desc.push_back(0);
     ar.upload(b->d_big_ob_line, big_ob_line);
-    ar.upload(b->d_big_pair_i, big_pair_i);
-    ar.upload(b->d_big_pair_j, big_pair_j);
+    ar.upload(b->d_big_cam_ptr, big_cam_ptr);
+    ar.upload(b->d_big_cam_obs, big_cam_obs);
+    ar.upload(b->d_big_pair_ptr, big_pair_ptr);
+    ar.upload(b->d_big_pair_row, big_pair_row);
+    ar.upload(b->d_big_pair_col, big_pair_col);
+    ar.upload(b->d_big_pair_desc, big_pair_desc);
     ar.upload(b->d_big_sys_off, b->h_big_sys_off);
     ar.scratch(b->d_big_J, (size_t)std::max<long long>(1, nobs) * kBigObs);
+    ar.scratch(b->d_big_F, (size_t)std::max<long long>(1, nobs) * kBigF);
+    ar.scratch(b->d_big_cost, (size_t)std::max<long long>(1, nobs) * 2);
     ar.scratch(b->d_big_camtab, (size_t)std::max<long long>(1, ncam) * 2 * kBigCam);
     ar.zeroed(b->d_big_line_acc, (size_t)std::max<long long>(1, nline) * kBigLine);
     ar.zeroed(b->d_big_sys, (size_t)std::max<long long>(1, sys_cursor));
@@ -534,8 +591,9 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if (b->big_mode) {
     BigPtrs& g = b->big;
     g.ob_line = b->d_big_ob_line.p; g.cam_win = b->d_cam_win.p; g.J = b->d_big_J.p; g.camtab = b->d_big_camtab.p;
-    g.line_acc = b->d_big_line_acc.p; g.sys = b->d_big_sys.p; g.sys_off = b->d_big_sys_off.p; g.pair_i = b->d_big_pair_i.p;
-    g.pair_j = b->d_big_pair_j.p; g.scal = b->d_big_scal.p; g.flags = b->d_big_flags.p; g.nobs = nobs;
+    g.line_acc = b->d_big_line_acc.p; g.sys = b->d_big_sys.p; g.sys_off = b->d_big_sys_off.p; g.F = b->d_big_F.p; g.cost = b->d_big_cost.p;
+    g.cam_ptr = b->d_big_cam_ptr.p; g.cam_obs = b->d_big_cam_obs.p; g.pair_ptr = b->d_big_pair_ptr.p; g.pair_row = b->d_big_pair_row.p;
+    g.pair_col = b->d_big_pair_col.p; g.pair_desc = b->d_big_pair_desc.p; g.scal = b->d_big_scal.p; g.flags = b->d_big_flags.p; g.nobs = nobs;
   }
   p.line_desc = b->d_line_desc.p; p.elim_mode = b->elim_mode; p.elim_waves = b->elim_waves;
   b->lds_elim = (size_t)lds_bytes_eliminate_mfma(maxC, maxn, b->elim_waves);
@@ -625,8 +683,8 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     // blocked MFMA Cholesky
     const BigPtrs& g = b->big;
     const dim3 blk128(128);
-    const dim3 g_obs128((unsigned)((g.nobs + 127) / 128)), g_obs256((unsigned)((g.nobs + 255) / 256)), g_line128((unsigned)((b->nline + 127) / 128)),
-        g_cam((unsigned)((b->ncam + 255) / 256)), g_pair((unsigned)((g.npairs + 127) / 128));
+    const dim3 g_obs128((unsigned)((g.nobs + 127) / 128)), g_obs256((unsigned)((g.nobs + 255) / 256)), g_line128((unsigned)((b->nline + 127) / 128)), g_linew((unsigned)((b->nline + 3) / 4)),
+        g_cam((unsigned)((b->ncam + 255) / 256)), g_pair((unsigned)std::max<long long>(1, g.npairs)), g_camwg((unsigned)std::max(1, b->ncam));
     const int iters = std::max(1, pol.max_num_iterations);      // (max_num_iterations = 0: the first sweep's initial evaluation only)
     for (int it = 0; it < iters; ++it) {
       if (!capturing && it > 0 && (it % 16) == 0) {
@@ -636,17 +694,17 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
         if (active == 0) break;
       }
       if (!capturing && ((it + 1) % 16) == 0) HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
+      // (the reduced system is rebuilt by stores: only what the factorisation leaves behind - its upper triangle - and the
+      // failure flags need clearing; the per-line / per-observation outputs are overwritten)
       HIP_TRY(hipMemsetAsync(b->d_big_sys.p, 0, b->d_big_sys.n * sizeof(double), s));
-      HIP_TRY(hipMemsetAsync(b->d_big_line_acc.p, 0, b->d_big_line_acc.n * sizeof(double), s));
-      HIP_TRY(hipMemsetAsync(b->d_big_scal.p, 0, b->d_big_scal.n * sizeof(double), s));
       HIP_TRY(hipMemsetAsync(b->d_big_flags.p, 0, b->d_big_flags.n * sizeof(int), s));
-      HIP_TRY(hipMemsetAsync(b->d_bs_part.p, 0, b->d_bs_part.n * sizeof(double), s));
-      HIP_TRY(hipMemsetAsync(b->d_cost_part.p, 0, b->d_cost_part.n * sizeof(double), s));
       LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_cameras, g_cam, blk256, 0, s, p, g, 0));
       if (g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_linearise, g_obs128, blk128, 0, s, p, g, pol));
-      if (b->nline > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_line, g_line128, blk128, 0, s, p, g, pol));
-      if (g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_rescale, g_obs256, blk256, 0, s, p, g));
-      if (g.npairs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_schur, g_pair, blk128, 0, s, p, g));
+      if (b->nline > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_line, g_linew, blk256, 0, s, p, g, pol));
+      if (it == 0 && g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_rescale, g_obs256, blk256, 0, s, p, g));
+      if (g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_F, g_obs128, blk128, 0, s, p, g));
+      if (b->ncam > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_cam, g_camwg, blk256, 0, s, p, g));
+      if (g.npairs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_pairs, g_pair, blk256, 0, s, p, g));
       LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_prepare, g_win, blk256, 0, s, p, g, pol));
       if (pol.max_num_iterations <= 0) break;
       for (int wi = 0; wi < B; ++wi) {
@@ -671,9 +729,9 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_finish, g_win, blk64, 0, s, p, g));
       if (it == 0 && g.nobs > 0) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_rescale_cameras, g_obs256, blk256, 0, s, p, g));
       LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_cameras, g_cam, blk256, 0, s, p, g, 1));
-      if (g.nobs > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_backsub_obs, g_obs128, blk128, 0, s, p, g));
-      if (b->nline > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_backsub_line, g_line128, blk128, 0, s, p, g));
+      if (b->nline > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_backsub_line, g_linew, blk256, 0, s, p, g));
       if (g.nobs > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_cost, g_obs128, blk128, 0, s, p, g, pol));
+      LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_reduce, g_win, blk256, 0, s, p, g));
       LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol));
     }
     HIP_TRY(hipGetLastError());
@@ -863,6 +921,12 @@ extern "C" int slslam_lba_batch_counts(const slslam_lba_batch* b, long long* nw,
   long long w = 0, c = 0, fc = 0, l = 0, o = 0;
   for (const PackedWindow& P : b->wins) { ++w; c += P.C; fc += P.Cf; l += P.L; o += P.M; }
   if (nw) *nw = w; if (nc) *nc = c; if (nfc) *nfc = fc; if (nl) *nl = l; if (no) *no = o;
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_path(const slslam_lba_batch* b, int* path) {
+  if (!b || !path || !b->finalized) return SLSLAM_ERR_INVALID_ARGUMENT;
+  *path = b->big_mode ? SLSLAM_PATH_GLOBAL_MEMORY : b->fused_motion_only ? SLSLAM_PATH_FUSED_MOTION_ONLY : SLSLAM_PATH_TILED;
   return SLSLAM_OK;
 }
 

@@ -467,17 +467,22 @@ __global__ __launch_bounds__(1024) void k_po_trisolve(PoPtrs p, const T* A, cons
     for (int q = tid; q < kNB * kNB; q += nthr) Ls[(q / kNB) * (kNB + 1) + (q % kNB)] = Li[q];    // coalesced
     if (tid < kNB) yb[tid] = tid < nb ? p.y[k0 + tid] : 0.0;
     __syncthreads();
-    if (tid < nb) {
+    // sixteen threads per row (a row of the factor is contiguous in memory: coalesced loads), partial dot products combined
+    // over the sixteen with a fixed butterfly; 64 rows per pass of the 1024 threads
+    const int rsub = tid >> 4, csub = tid & 15, rows_per_pass = nthr >> 4;
+    for (int r = rsub; r < kNB; r += rows_per_pass) {
       double s = 0.0;
-      for (int j = 0; j <= tid; ++j) s += (double)Ls[tid * (kNB + 1) + j] * yb[j];
-      yn[tid] = s;
-      p.y[k0 + tid] = s;
+      if (r < nb) for (int j = csub; j <= r; j += 16) s += (double)Ls[r * (kNB + 1) + j] * yb[j];
+      s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
+      if (r < nb && csub == 0) { yn[r] = s; p.y[k0 + r] = s; }
     }
     __syncthreads();
-    for (int r = k0 + nb + tid; r < n; r += nthr) {
+    for (int r0 = k0 + nb; r0 < n; r0 += rows_per_pass) {
+      const int r = r0 + rsub;
       double s = 0.0;
-      for (int j = 0; j < nb; ++j) s += (double)A[(long long)r * p.ld + k0 + j] * yn[j];
-      p.y[r] -= s;
+      if (r < n) for (int j = csub; j < nb; j += 16) s += (double)A[(long long)r * p.ld + k0 + j] * yn[j];
+      s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
+      if (r < n && csub == 0) p.y[r] -= s;
     }
     __syncthreads();
   }
@@ -489,11 +494,14 @@ __global__ __launch_bounds__(1024) void k_po_trisolve(PoPtrs p, const T* A, cons
     for (int q = tid; q < kNB * kNB; q += nthr) Ls[(q / kNB) * (kNB + 1) + (q % kNB)] = Li[q];
     if (tid < kNB) yb[tid] = tid < nb ? p.y[k0 + tid] : 0.0;
     __syncthreads();
-    if (tid < nb) {
-      double s = 0.0;
-      for (int j = tid; j < nb; ++j) s += (double)Ls[j * (kNB + 1) + tid] * yb[j];
-      yn[tid] = s;
-      p.y[k0 + tid] = s;
+    {
+      const int rsub = tid >> 4, csub = tid & 15, rows_per_pass = nthr >> 4;
+      for (int r = rsub; r < kNB; r += rows_per_pass) {               // row r of inv(L_kk)^T: column r of the stored inverse
+        double s = 0.0;
+        if (r < nb) for (int j = r + csub; j < nb; j += 16) s += (double)Ls[j * (kNB + 1) + r] * yb[j];
+        s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
+        if (r < nb && csub == 0) { yn[r] = s; p.y[k0 + r] = s; }
+      }
     }
     __syncthreads();
     for (int r = tid; r < k0; r += nthr) {

@@ -125,7 +125,8 @@ def test_long_and_short_line_runs(hip, oracle):
 def test_windows_beyond_the_tiled_sweeps(hip, oracle):
     """The reference's window size is a flag (src/main.cpp:22) and its study runs W = 40: 80 keyframes, 40 free, lines tracked
     through all of them.  Such windows (more than 20 free / 64 cameras, or a line with more than 64 observations) take the
-    global-memory path (lba_big.h, reduced system on the pose-graph MFMA Cholesky); same algorithm, so the same traces.
+    global-memory path (lba_big.h: per-observation Jacobians in HBM, every sum a gather in list order, reduced system on the
+    pose-graph MFMA Cholesky); same algorithm, so the same traces, and reproducible bit for bit.
     (Lines observed by more than 64 keyframes: tests/test_house_study.py, W = 40.)"""
     ws = [synth.make_window(31, num_lines=100, num_kf=80, num_free=40, mean_track=30.0),
           synth.make_window(33, num_lines=80, num_kf=70, num_free=12, mean_track=20.0),        # > 64 cameras only
@@ -133,19 +134,35 @@ def test_windows_beyond_the_tiled_sweeps(hip, oracle):
     for w in ws:
         x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
         x1, s1, t1 = hip.lba_solve(w)
-        _assert_trace_parity(t0, t1, n=3)
+        _assert_trace_parity(t0, t1, n=4, tight=True)       # every iteration at the tolerances of the tiled path
         _assert_summary_parity(s0, s1)
-        assert np.abs(x0 - x1).max() < 1e-5
-    # a batch that mixes an oversize window with ordinary ones goes down the same path as a whole
+        _assert_params_parity(w, x0, x1)
+        x2, s2, t2 = hip.lba_solve(w)                       # gather sums in list order: bitwise reproducible (round 2: atomics)
+        assert np.array_equal(x1, x2) and s1 == s2 and t1 == t2
+    # a batch that mixes an oversize window with ordinary ones goes down the same path as a whole - and says so
     b = hip.LBABatch()
     mix = [ws[0], synth.make_window(35, num_lines=120), synth.make_motion_only(6, num_lines=30)]
     for w in mix:
         b.add(w)
     b.finalize(); b.solve(); b.download()
+    assert b.path() == 2                                     # SLSLAM_PATH_GLOBAL_MEMORY
+    first = [b.parameters(i).copy() for i in range(len(mix))]
     for i, w in enumerate(mix):
-        xo, so, _ = oracle.lba_solve(w, linear_solver=1)
-        assert np.abs(xo - b.parameters(i)).max() < 1e-5
-        assert b.summary(i)["num_successful_steps"] == so["num_successful_steps"]
+        xo, so, to = oracle.lba_solve(w, linear_solver=1)
+        _assert_params_parity(w, xo, first[i])
+        _assert_summary_parity(so, b.summary(i))
+        _assert_trace_parity(to, b.trace(i), n=4, tight=True)
+    b.reset(); b.solve(); b.download()
+    for i in range(len(mix)):
+        assert np.array_equal(first[i], b.parameters(i))
+    b.close()
+    b = hip.LBABatch()
+    b.add(mix[1]); b.finalize()
+    assert b.path() == 0                                     # SLSLAM_PATH_TILED
+    b.close()
+    b = hip.LBABatch()
+    b.add(mix[2]); b.finalize()
+    assert b.path() == 1                                     # SLSLAM_PATH_FUSED_MOTION_ONLY
     b.close()
     # max_num_iterations = 0: the initial evaluation only
     x1, s1, t1 = hip.lba_solve(ws[0], max_num_iterations=0)
