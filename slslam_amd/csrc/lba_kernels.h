@@ -113,7 +113,58 @@ __device__ __forceinline__ double seg_step(double v, bool m) {
   asm("" : "+v"(mask));            // opaque: keeps the AND an AND (the optimiser would turn it back into selects)
   return v + dpp_shift0_and<CTRL>(v, mask);
 }
-template <int N, bool FMA_MASK = false>
+// row_shl: lane i reads lane i + d of its 16-lane row.  The run's total sits in its last lane (of the row) after the prefix scan;
+// it travels back down the run in 1, 2, 4, 8-lane hops on the VALU (a lane takes the hop iff its source is still inside the run)
+// instead of one ds_bpermute round trip per value: the sweeps are bound by their LDS instructions, not by VALU ones.
+// One v_cndmask_b32 with the DPP modifier per register, in place: vcc = (room < d) keeps the lane's own value.  (Inline
+// assembly: the compiler does not form the DPP select; s_nop 1 covers the VALU-write -> DPP-read wait states.)
+#define SLS_BACK_ASM(SHL)                                                                                                     \
+  asm volatile("s_nop 1\n\tv_cmp_gt_i32 vcc, " #SHL ", %28\n\t"                                                               \
+               "v_cndmask_b32_dpp %0, %0, %0, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+               "v_cndmask_b32_dpp %1, %1, %1, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+               "v_cndmask_b32_dpp %2, %2, %2, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+               "v_cndmask_b32_dpp %3, %3, %3, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+               "v_cndmask_b32_dpp %4, %4, %4, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+               "v_cndmask_b32_dpp %5, %5, %5, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+               "v_cndmask_b32_dpp %6, %6, %6, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+               "v_cndmask_b32_dpp %7, %7, %7, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+               "v_cndmask_b32_dpp %8, %8, %8, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+               "v_cndmask_b32_dpp %9, %9, %9, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+               "v_cndmask_b32_dpp %10, %10, %10, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %11, %11, %11, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %12, %12, %12, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %13, %13, %13, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %14, %14, %14, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %15, %15, %15, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %16, %16, %16, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %17, %17, %17, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %18, %18, %18, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %19, %19, %19, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %20, %20, %20, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %21, %21, %21, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %22, %22, %22, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %23, %23, %23, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %24, %24, %24, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %25, %25, %25, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %26, %26, %26, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+               "v_cndmask_b32_dpp %27, %27, %27, vcc row_shl:" #SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1"                   \
+               : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]),   \
+                 "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]), "+v"(w[16]), "+v"(w[17]), "+v"(w[18]),      \
+                 "+v"(w[19]), "+v"(w[20]), "+v"(w[21]), "+v"(w[22]), "+v"(w[23]), "+v"(w[24]), "+v"(w[25]), "+v"(w[26]), "+v"(w[27])       \
+               : "v"(room) : "vcc")
+// the run totals of 14 values (28 dwords) brought back from the run's last lane to every lane of the run
+__device__ __forceinline__ void seg_back_14(double (&v)[14], int room, int max_run) {
+  int w[28];
+#pragma unroll
+  for (int q = 0; q < 14; ++q) { w[2 * q] = __double2loint(v[q]); w[2 * q + 1] = __double2hiint(v[q]); }
+  if (max_run > 1) SLS_BACK_ASM(1);
+  if (max_run > 2) SLS_BACK_ASM(2);
+  if (max_run > 4) SLS_BACK_ASM(4);
+  if (max_run > 8) SLS_BACK_ASM(8);
+#pragma unroll
+  for (int q = 0; q < 14; ++q) v[q] = __hiloint2double(w[2 * q + 1], w[2 * q]);
+}
+template <int N, bool FMA_MASK = false, bool BACK_DPP = false>
 __device__ __forceinline__ void seg_sum_n(double (&v)[N], const SegCtx& s) {
   SLS_PHASE("seg_scan_1_2_4");
   if (s.max_run > 1) {
@@ -134,8 +185,12 @@ __device__ __forceinline__ void seg_sum_n(double (&v)[N], const SegCtx& s) {
     for (int q = 0; q < N; ++q) v[q] = seg_step<0x118, FMA_MASK>(v[q], s.j >= 8);
   }
   SLS_PHASE("seg_total");
+  if (BACK_DPP && N == 14) {
+    seg_back_14(reinterpret_cast<double (&)[14]>(v), (s.rl4 >> 2) - (int)(threadIdx.x & 63), s.max_run);
+  } else {
 #pragma unroll
-  for (int q = 0; q < N; ++q) v[q] = bperm64(v[q], s.rl4);
+    for (int q = 0; q < N; ++q) v[q] = bperm64(v[q], s.rl4);
+  }
   SLS_PHASE("seg_multirow");
   if (s.multirow) {
     const bool spans = s.r1 > s.r0;
@@ -408,7 +463,11 @@ __device__ __forceinline__ void line_block(const LaneLin& L, const SegCtx& sg, d
     for (int r = 0; r < 4; ++r) ga += L.Jl[4 * r + a] * L.rs[r];
     v[10 + a] = ga;
   }
+#if defined(SLSLAM_SEG_TOTAL_BPERMUTE)        // round-2 form, for comparison: 28 ds_bpermute per tile
   seg_sum_n<14>(v, sg);
+#else
+  seg_sum_n<14, false, true>(v, sg);
+#endif
 #pragma unroll
   for (int i = 0; i < 10; ++i) H[i] = v[i];
 #pragma unroll
@@ -1451,7 +1510,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     SLS_PHASE("bs_prefetch_next");
     prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
     __builtin_amdgcn_sched_barrier(0);
-    seg_sum_n<4, true>(wv, sg);
+    seg_sum_n<4, true>(wv, sg);        // (the DPP form of the run total measured slower here: 0.505 -> 0.518 ms; this sweep has no atomics)
     SLS_PHASE("bs_line_step");
     // every lane of the run holds the same H, g, w: all of them take the step (the candidate
     // parameters are needed by every lane below); lane 0 of the run writes and accumulates
