@@ -258,20 +258,22 @@ struct LaneLin {
 // the dependent chain  tile descriptor -> line_ptr -> observation  is off the critical path.
 struct TileCtx {
   int flags, ls, j, o0, k, lflags, nitems, item_off;
+  bool skew;                // lane_map bit 15: this lane adds its camera-record entries one step late (see the diagonal block)
   int slot, nlines;         // the lane's line slot in the tile (matrix-core sweep), lines of the tile (wave-uniform)
   bool line_ok;
 };
 __device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_end, int lane) {
   TileCtx c;
   c.flags = 0; c.ls = 0; c.j = 0; c.o0 = 0; c.k = 0; c.lflags = 1; c.nitems = 0; c.item_off = 0; c.line_ok = false;
-  c.slot = 0; c.nlines = 0;
+  c.slot = 0; c.nlines = 0; c.skew = false;
   if (t < t_end) {
     const Tile tl = p.tiles[t];
     const int m = p.lane_map[(long long)t * 64 + lane];
     c.flags = tl.flags; c.nitems = tl.nitems; c.item_off = tl.item_off; c.nlines = tl.nlines; c.slot = m & 0xff;
     c.line_ok = (m & 0xff) != 0xff;
     if (c.line_ok) {
-      c.j = m >> 8;
+      c.j = (m >> 8) & 0x3f;
+      c.skew = (m & 0x8000) != 0;
       c.ls = tl.line_begin + (m & 0xff);
       c.o0 = p.line_ptr[c.ls]; c.k = p.line_ptr[c.ls + 1] - c.o0; c.lflags = p.line_flags[c.ls];
     }
@@ -560,8 +562,10 @@ __host__ __device__ inline int lds_doubles_linearise(int C, int n) {
 // Kernel 1: linearise + per-line Schur elimination, partial reduced system per chunk.
 // INIT = initial evaluation (Ceres: cost, gradient and column norms at x0 for the Jacobi scaling):
 // no elimination, unit scaling, writes the per-line scale.
+// (two waves per SIMD - 256 registers, arch + accumulation VGPRs together - is the occupancy the sweep is tuned for; without the
+// bound the allocator parks a few values in AGPRs and the kernel drops to one wave per SIMD)
 template <bool INIT>
-__global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearise_schur(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const Chunk ck = p.chunks[blockIdx.x];
@@ -709,7 +713,22 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
     __builtin_amdgcn_sched_barrier(0);
     SLS_PHASE("diag_block");
     if (cam_free) {
+      // Lanes of one 16-lane row whose observations belong to the same camera add to the same addresses, and the LDS takes
+      // such lanes one after the other.  The packer marks every second of them (TileCtx.skew): a marked lane adds each entry ONE
+      // step later than its neighbours - in any one ds_add_f64 the two then name different entries of the record.  The
+      // delayed value waits in two registers; selects and address arithmetic are VALU work, which this sweep has to spare.
       double* rec = S + L.cf * kCamAcc;
+#if defined(SLSLAM_NO_SKEW)
+      const bool skew = false;
+#else
+      const bool skew = tc.skew;
+#endif
+      double pval = 0.0;
+      int poff = kRecB;
+      auto emit = [&](int off, double val) {
+        lds_add_rec(rec + (skew ? poff : off), skew ? pval : val);
+        pval = val; poff = off;
+      };
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         double ga = 0.0, ha = 0.0;
@@ -717,10 +736,10 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
         for (int r = 0; r < 4; ++r) { ga += L.Jc[6 * r + a] * L.rs[r]; ha += L.Jc[6 * r + a] * L.Jc[6 * r + a]; }
         const double fu = F[4 * a] * u[0] + F[4 * a + 1] * u[1] + F[4 * a + 2] * u[2] + F[4 * a + 3] * u[3];
         if (!same_point) {
-          lds_add_rec(&rec[kRecG + a], ga);
-          lds_add_rec(&rec[kRecH + a], ha);
+          emit(kRecG + a, ga);
+          emit(kRecH + a, ha);
         }
-        lds_add_rec(&rec[kRecB + a], ga - fu);
+        emit(kRecB + a, ga - fu);
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
           double v = 0.0;
@@ -728,9 +747,10 @@ __global__ __launch_bounds__(64) void k_linearise_schur(BatchPtrs p, Policy pol)
           for (int r = 0; r < 4; ++r) v += L.Jc[6 * r + a] * L.Jc[6 * r + b];
 #pragma unroll
           for (int m = 0; m < 4; ++m) v -= F[4 * a + m] * F[4 * b + m];
-          lds_add_rec(&rec[tri_index(a, b)], v);
+          emit(tri_index(a, b), v);
         }
       }
+      if (skew) lds_add_rec(rec + poff, pval);             // the marked lanes' last entry
     }
 
     // ---- off-diagonal camera pairs of the tile, balanced over the lanes

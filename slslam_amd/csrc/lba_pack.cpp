@@ -214,12 +214,21 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
       Tile t;
       t.line_begin = s; t.item_off = (int)((item_w - P.items.data()) / 2);
       for (int q = 0; q < 64; ++q) map[q] = (uint16_t)0x00FF;
+      unsigned char row_cam_seen[4][kMaxFreeCams] = {};
       int lane = 0, nl = 0, min_lanes = 64, max_run = 1, multi = 0;
       for (int ri = tile_ptr[ti]; ri < tile_ptr[ti + 1]; ++ri) {
         lane = (lane + 15) & ~15;                            // every row entry starts a row
         for (int l = rows[tile_rows[ri]].head; l >= 0; l = next[l], ++s, ++nl) {
           const int k = P.line_ptr[s + 1] - P.line_ptr[s], run = std::max(k, 1);
           for (int j = 0; j < run; ++j) map[lane + j] = (uint16_t)(nl | (j << 8));
+          // skew flag (bit 15): every second lane of this 16-lane row that holds an observation of the same free camera adds its
+          // camera-record entries one step late (lba_kernels.h, diagonal block) - no two of them meet on one LDS address
+          for (int j = 0; j < k && j < 64; ++j) {
+            const int cf = P.cam_cf[P.ob_cam[P.line_ptr[s] + j]];
+            if (cf < 0) continue;
+            const int row = (lane + j) >> 4;
+            if (row_cam_seen[row][cf]++ & 1) map[lane + j] |= (uint16_t)0x8000;
+          }
           min_lanes = std::min(min_lanes, run);
           max_run = std::max(max_run, std::min(run, 16));
           if (run > 16) multi = 1;

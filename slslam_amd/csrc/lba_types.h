@@ -44,8 +44,8 @@ struct WinDesc {
 // max(k, 1) consecutive lanes (k = its observations), lane j of the run handles observation
 // line_ptr[l] + j.  Runs are bin-packed into the four 16-lane rows of the wave so that a run only
 // crosses a row boundary when it starts on one (lines with more than 16 observations), which keeps the
-// per-line reductions on row-local DPP shifts.  lane_map[64 t + lane] = slot | j << 8 with slot = line - line_begin
-// (0xFF: idle lane).
+// per-line reductions on row-local DPP shifts.  lane_map[64 t + lane] = slot | j << 8 | skew << 15 with slot = line - line_begin
+// (0xFF: idle lane), j < 64 the position in the run, skew: see the diagonal block of the elimination sweep.
 enum { kTileMultiRow = 1 };             // Tile.flags bit 0: some line of the tile spans several rows
 struct Tile {
   int line_begin;         // global sorted line index of the first line

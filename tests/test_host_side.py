@@ -103,7 +103,7 @@ def test_mfma_elimination_index_maps_replay_a_window(host_math):
     nmfma = 0
     for t, (lb, nl, flags, ni) in enumerate(P["tiles"]):
         panel = np.full(4 * 400 + 64, np.nan)
-        lane_slot, lane_pos = P["lane_map"][t] & 0xFF, P["lane_map"][t] >> 8
+        lane_slot, lane_pos = P["lane_map"][t] & 0xFF, (P["lane_map"][t] >> 8) & 0x3F
         F = {}
         for lane in range(64):
             if lane_slot[lane] == 0xFF:
@@ -264,7 +264,7 @@ def _check_tiles(P, w, L):
     for t, (lb, nl, flags, ni) in enumerate(P["tiles"]):
         assert lb == covered and 1 <= nl <= 64
         m = P["lane_map"][t]
-        slot, pos = m & 0xFF, m >> 8
+        slot, pos = m & 0xFF, (m >> 8) & 0x3F
         want, min_run, max_run, multi = set(), 64, 1, 0
         for q in range(nl):
             s = lb + q
