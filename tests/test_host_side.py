@@ -281,6 +281,25 @@ def _check_tiles(P, w, L):
             if not np.any(np.asarray(w["fixed_index"]).reshape(-1, 2)[sel, 1]):
                 want |= {(lanes[0] + i, lanes[0] + j) for i in range(kf) for j in range(i + 1, kf)}
         assert np.all(slot[slot != 0xFF] < nl)
+        # skew flag (bit 15): inside a 16-lane row the lanes that hold observations of one free camera alternate 0, 1, 0, ...
+        skew = (m >> 15) & 1
+        for row in range(4):
+            seen = {}
+            for lane in range(16 * row, 16 * row + 16):
+                if slot[lane] == 0xFF:
+                    assert skew[lane] == 0
+                    continue
+                sl = lb + int(slot[lane])
+                kk = int(P["line_ptr"][sl + 1] - P["line_ptr"][sl])
+                if pos[lane] >= kk:
+                    assert skew[lane] == 0
+                    continue
+                cf = int(P["cam_cf"][P["ob_cam"][P["line_ptr"][sl] + int(pos[lane])]])
+                if cf < 0:
+                    assert skew[lane] == 0
+                    continue
+                assert skew[lane] == seen.get(cf, 0) % 2
+                seen[cf] = seen.get(cf, 0) + 1
         assert (flags & 1) == int(multi) and (flags >> 3) & 31 == max_run
         assert 1 << ((flags >> 1) & 3) == (1 if min_run >= 4 else 2 if min_run >= 2 else 4)
         got = [tuple(int(v) for v in x) for x in P["items"][it:it + ni]]
