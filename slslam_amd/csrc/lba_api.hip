@@ -612,6 +612,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if (b->lds_lin > 48 * 1024 && !b->big_mode) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
     HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_linearise_schur<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_lin));
   }
   if (b->elim_mode == 1 && b->lds_elim > 48 * 1024) {
     if (b->lds_elim > 160 * 1024) return SLSLAM_ERR_UNSUPPORTED;
@@ -759,7 +761,9 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
         else LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<1, true>), g_chunk, blk64, b->lds_elim, s, p, pol));
       } else if (b->elim_mode == 1 && b->elim_waves == 2) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<2, false>), g_chunk, dim3(128), b->lds_elim, s, p, pol));
       else if (b->elim_mode == 1) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<1, false>), g_chunk, blk64, b->lds_elim, s, p, pol));
-      else LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_linearise_schur<false>, g_chunk, blk64, b->lds_lin, s, p, pol));
+      // the first sweep of a solve doubles as Ceres' initial evaluation (every window fresh) unless the separate pass above ran
+      else if (it == 0 && !(pol.max_num_iterations <= 0 || pol.store_f)) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_linearise_schur<false, 1>), g_chunk, blk64, b->lds_lin, s, p, pol));
+      else LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_linearise_schur<false, 0>), g_chunk, blk64, b->lds_lin, s, p, pol));
     }
     if (b->slab_sum_stride)
       LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)B, (unsigned)((b->slab_sum_stride + 255) / 256)), blk256, 0, s, p));   // windows on grid.x (no 65535 limit)

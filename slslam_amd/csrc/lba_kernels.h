@@ -564,7 +564,10 @@ __host__ __device__ inline int lds_doubles_linearise(int C, int n) {
 // no elimination, unit scaling, writes the per-line scale.
 // (two waves per SIMD - 256 registers, arch + accumulation VGPRs together - is the occupancy the sweep is tuned for; without the
 // bound the allocator parks a few values in AGPRs and the kernel drops to one wave per SIMD)
-template <bool INIT>
+// FRESH: 1 = the first sweep of a solve (it is also Ceres' initial evaluation: every window of the launch is fresh), 0 = any later
+// sweep (none is), -1 = read LMState.fresh.  The host knows which launch is which; the two compile-time forms keep the first
+// sweep's extras (unit scales, line Jacobi scale, fixed cost, |x|) out of the steady sweep's registers.
+template <bool INIT, int FRESH = -1>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearise_schur(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double* camscale = camtab + wd.C * kCamTab;
   double* S = camscale + (n > 0 ? n : 6);
   signed char* camcf = (signed char*)(S + nsys);
-  const bool fresh = !INIT && st->fresh != 0;              // this sweep is also the initial evaluation: see below
+  const bool fresh = !INIT && (FRESH < 0 ? st->fresh != 0 : FRESH == 1);   // this sweep is also the initial evaluation: see below
   load_cam_table<true>(p, wd, cur, lane, camtab, camscale, camcf, INIT || fresh);
   for (int q = lane; q < nsys; q += 64) S[q] = 0.0;
   __syncthreads();
@@ -717,6 +720,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       // such lanes one after the other.  The packer marks every second of them (TileCtx.skew): a marked lane adds each entry ONE
       // step later than its neighbours - in any one ds_add_f64 the two then name different entries of the record.  The
       // delayed value waits in two registers; selects and address arithmetic are VALU work, which this sweep has to spare.
+      // (Three levels - the third same-camera lane of a row two steps late - measured slower: 1.26 -> 1.52 ms.)
       double* rec = S + L.cf * kCamAcc;
 #if defined(SLSLAM_NO_SKEW)
       const bool skew = false;

@@ -549,7 +549,8 @@ def test_sweep_kernels_keep_their_occupancy(tmp_path):
         hits = [v for k, v in stats.items() if fragment in k]
         assert len(hits) == 1, (fragment, [k for k in stats if fragment in k])
         return hits[0]
-    for frag in ("17k_linearise_schurILb0E", "9k_backsubE"):
+    # the elimination sweep's three forms: first sweep of a solve (FRESH = 1), steady (0), run-time flag (-1)
+    for frag in ("17k_linearise_schurILb0ELi1E", "17k_linearise_schurILb0ELi0E", "17k_linearise_schurILb0ELin1E", "9k_backsubE"):
         st = find(frag)
         assert st["Occupancy"] == 2 and st["ScratchSize"] == 0 and st["TotalNumVgprs"] <= 256, (frag, st)
     assert find("15k_reduced_solveE")["Occupancy"] >= 4          # four workgroups per CU: the whole bench batch resident in one round
