@@ -8,8 +8,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "_lib")
 LIB = os.path.join(LIB_DIR, "libslslam_hip.so")
 SOURCES = ["lba_api.hip", "lba_pack.cpp", "po_api.hip", "ransac_api.hip"]
-HEADERS = ["lba_kernels.h", "lba_math.h", "lba_types.h", "lba_pack.h", "lba_gram.h", "lba_eliminate_mfma.h", "lba_eliminate_mfma_maps.h", "po_kernels.h", "lba_motion_only.h", "device_cache.h", "dense_tile.h", "lba_big.h",
-           os.path.join("..", "..", "include", "slslam_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "slslam_hip.h")]   # every header: a new one must not leave a stale library behind
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 import os as _os
 FLAGS += _os.environ.get("SLSLAM_EXTRA_FLAGS", "").split()

@@ -52,8 +52,8 @@ __device__ __forceinline__ void diag_tile_steps(T (&a)[16], T (&e)[4], T& ipown,
 }
 
 // The whole tile: D points at its (0, 0) element in LDS (leading dimension ld, LOWER triangle valid on entry).  On exit the
-// lower triangle holds L; the inverse goes where `put_inverse(row, col, value)` sends it (col <= row).  One full wave.
-template <typename T, typename PutInv>
+// lower triangle holds L (STORE_L; a caller that only needs the inverse skips it); the inverse goes where `put_inverse(row, col, value)` sends it (col <= row).  One full wave.
+template <typename T, bool STORE_L = true, typename PutInv>
 __device__ __forceinline__ void diag_tile_factor(T* D, int ld, int lane, int& fail, PutInv put_inverse) {
   const int r = lane & 15, g = lane >> 4;
   T a[16], e[4], ipown = T(1);
@@ -62,14 +62,17 @@ __device__ __forceinline__ void diag_tile_factor(T* D, int ld, int lane, int& fa
 #pragma unroll
   for (int k = 0; k < 4; ++k) e[k] = (r == 4 * g + k) ? T(1) : T(0);
   diag_tile_steps<0, T>(a, e, ipown, r, fail);
+  // (a[] is indexed with compile-time constants only: one masked store per column - a select chain over the row group is
+  // turned into an indexed load from a stack copy of a[] by the compiler)
+  if (STORE_L) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (g == (c >> 2) && c <= r) D[r * ld + c] = a[c];
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = 4 * g + k;
-    T av = a[k];                                                          // a[] is indexed with compile-time constants only
-    if (g == 1) av = a[4 + k];
-    if (g == 2) av = a[8 + k];
-    if (g == 3) av = a[12 + k];
-    if (c <= r) { D[r * ld + c] = av; put_inverse(r, c, e[k] * ipown); }
+    if (c <= r) put_inverse(r, c, e[k] * ipown);
   }
 }
 

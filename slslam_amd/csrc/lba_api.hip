@@ -16,6 +16,7 @@
 #define SLSLAM_PO_FACTOR_ONLY
 #include "po_kernels.h"
 #include "lba_big.h"
+#include "lba_big_solve.h"
 #include "device_cache.h"
 #include "lba_motion_only.h"
 #include "lba_pack.h"
@@ -688,6 +689,10 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     const dim3 g_obs128((unsigned)((g.nobs + 127) / 128)), g_obs256((unsigned)((g.nobs + 255) / 256)), g_line128((unsigned)((b->nline + 127) / 128)), g_linew((unsigned)((b->nline + 3) / 4)),
         g_cam((unsigned)((b->ncam + 255) / 256)), g_pair((unsigned)std::max<long long>(1, g.npairs)), g_camwg((unsigned)std::max(1, b->ncam));
     const int iters = std::max(1, pol.max_num_iterations);      // (max_num_iterations = 0: the first sweep's initial evaluation only)
+    // reduced systems of at most 256 unknowns (the reference's W = 40: 240) are factorised and solved by one workgroup in one
+    // launch, from registers (lba_big_solve.h): nothing dirties the system in memory, which every sweep rebuilds by stores
+    bool one_launch_solve = !(pol.debug_flags & 2048);
+    for (int wi = 0; wi < B; ++wi) if (b->h_wins[wi].n > kBsvMaxN) one_launch_solve = false;
     for (int it = 0; it < iters; ++it) {
       if (!capturing && it > 0 && (it % 16) == 0) {
         unsigned int active = 0;
@@ -698,8 +703,10 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       if (!capturing && ((it + 1) % 16) == 0) HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
       // (the reduced system is rebuilt by stores: only what the factorisation leaves behind - its upper triangle - and the
       // failure flags need clearing; the per-line / per-observation outputs are overwritten)
-      HIP_TRY(hipMemsetAsync(b->d_big_sys.p, 0, b->d_big_sys.n * sizeof(double), s));
-      HIP_TRY(hipMemsetAsync(b->d_big_flags.p, 0, b->d_big_flags.n * sizeof(int), s));
+      if (!one_launch_solve) {
+        HIP_TRY(hipMemsetAsync(b->d_big_sys.p, 0, b->d_big_sys.n * sizeof(double), s));
+        HIP_TRY(hipMemsetAsync(b->d_big_flags.p, 0, b->d_big_flags.n * sizeof(int), s));
+      }
       LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_cameras, g_cam, blk256, 0, s, p, g, 0));
       if (g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_linearise, g_obs128, blk128, 0, s, p, g, pol));
       if (b->nline > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_line, g_linew, blk256, 0, s, p, g, pol));
@@ -709,7 +716,8 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       if (g.npairs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_pairs, g_pair, blk256, 0, s, p, g));
       LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_prepare, g_win, blk256, 0, s, p, g, pol));
       if (pol.max_num_iterations <= 0) break;
-      for (int wi = 0; wi < B; ++wi) {
+      if (one_launch_solve) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_solve, g_win, dim3(64 * kBsvWaves), 0, s, p, g, pol));
+      for (int wi = 0; wi < B && !one_launch_solve; ++wi) {
         const int n = b->h_wins[wi].n;
         if (n <= 0) continue;
         PoPtrs pp;
@@ -728,13 +736,12 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
         }
         LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(1024), 0, s, pp, (const double*)pp.H, (const double*)linv));
       }
-      LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_finish, g_win, blk64, 0, s, p, g));
+      if (!one_launch_solve) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_finish, g_win, blk64, 0, s, p, g));
       if (it == 0 && g.nobs > 0) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_rescale_cameras, g_obs256, blk256, 0, s, p, g));
-      LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_cameras, g_cam, blk256, 0, s, p, g, 1));
+      if (!one_launch_solve) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_cameras, g_cam, blk256, 0, s, p, g, 1));
       if (b->nline > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_backsub_line, g_linew, blk256, 0, s, p, g));
       if (g.nobs > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_cost, g_obs128, blk128, 0, s, p, g, pol));
-      LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_reduce, g_win, blk256, 0, s, p, g));
-      LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_lm_update, g_upd, blk64, 0, s, p, pol));
+      LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_big_reduce, g_win, blk256, 0, s, p, g, pol));
     }
     HIP_TRY(hipGetLastError());
     return SLSLAM_OK;

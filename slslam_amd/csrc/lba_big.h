@@ -12,7 +12,7 @@
 //
 // One LM iteration:  k_big_cameras(0) -> k_big_linearise -> k_big_line -> k_big_rescale -> k_big_F -> k_big_cam -> k_big_pairs ->
 // k_big_prepare -> [potrf / panel updates / trisolve per window] -> k_big_finish -> k_big_cameras(1) -> k_big_backsub_line ->
-// k_big_cost -> k_big_reduce -> k_lm_update.
+// k_big_cost -> k_big_reduce (with the trust-region bookkeeping).
 #ifndef SLSLAM_LBA_BIG_H_
 #define SLSLAM_LBA_BIG_H_
 
@@ -70,18 +70,20 @@ __device__ __forceinline__ double block_max_256(double v, double* red) {
 }
 
 // thread <-> camera: rotation, SO(3) left Jacobian and translation of the accepted (which = 0) or candidate (1) pose
-__global__ __launch_bounds__(256) void k_big_cameras(BatchPtrs p, BigPtrs bg, int which) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.ncam) return;
-  const LMState* st = p.state + bg.cam_win[i];
-  if (st->status != kRunning) return;
-  const int buf = which ? 1 - st->cur : st->cur;
+__device__ __forceinline__ void big_camera_entry(const BatchPtrs& p, const BigPtrs& bg, const int i, const int buf, const int which) {
   const double* x = p.cam_x + ((long long)i * 2 + buf) * kCamRec;
   double w[3] = { x[0], x[1], x[2] }, R[9], JL[9];
   cam_prepare<double>(w, R, JL);
   double* ct = bg.camtab + ((long long)i * 2 + which) * kBigCam;
   for (int q = 0; q < 9; ++q) { ct[q] = R[q]; ct[9 + q] = JL[q]; }
   ct[18] = x[3]; ct[19] = x[4]; ct[20] = x[5];
+}
+__global__ __launch_bounds__(256) void k_big_cameras(BatchPtrs p, BigPtrs bg, int which) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.ncam) return;
+  const LMState* st = p.state + bg.cam_win[i];
+  if (st->status != kRunning) return;
+  big_camera_entry(p, bg, i, which ? 1 - st->cur : st->cur, which);
 }
 
 // thread <-> observation: residual, Jacobians, Huber, scaling, kept per observation.  At the first sweep of a solve (fresh)
@@ -514,12 +516,11 @@ __global__ __launch_bounds__(256) void k_big_rescale_cameras(BatchPtrs p, BigPtr
     for (int m = 0; m < 4; ++m) F[4 * a + m] *= cs[a];
 }
 
-// after the factorisation and the triangular solves: step statistics of the camera block, candidate camera poses
-__global__ __launch_bounds__(64) void k_big_finish(BatchPtrs p, BigPtrs bg) {
-  const int w = blockIdx.x, lane = threadIdx.x;
+// after the factorisation and the triangular solves: step statistics of the camera block, candidate camera poses.  One wave;
+// factor_failed: the factorisation met a non-positive pivot.
+__device__ __forceinline__ void big_finish(const BatchPtrs& p, const BigPtrs& bg, const int w, const int lane, const int factor_failed) {
   const WinDesc wd = p.wins[w];
   LMState* st = p.state + w;
-  if (st->status != kRunning) return;
   const int n = wd.n, ld = big_ld(n), cur = st->cur;
   const double* S = bg.sys + bg.sys_off[w];
   const double* gvec = S + (long long)n * ld + n;
@@ -552,8 +553,13 @@ __global__ __launch_bounds__(64) void k_big_finish(BatchPtrs p, BigPtrs bg) {
   const int any_bad = __any(bad);
   if (lane == 0) {
     st->cam_model = model; st->cam_dn2 = dn2; st->cam_xn2 = xn2;
-    st->solve_failed = (any_bad || bg.flags[2 * w] != 0 || bg.scal[(long long)w * kBgScal + kBgFail] != 0.0) ? 1 : 0;
+    st->solve_failed = (any_bad || factor_failed || bg.scal[(long long)w * kBgScal + kBgFail] != 0.0) ? 1 : 0;
   }
+}
+__global__ __launch_bounds__(64) void k_big_finish(BatchPtrs p, BigPtrs bg) {
+  const int w = blockIdx.x;
+  if (p.state[w].status != kRunning) return;
+  big_finish(p, bg, w, threadIdx.x, bg.flags[2 * w] != 0);
 }
 
 // wave <-> line: w = sum_i F_i^T y_c,i over the line's observations (lane <-> observation, fixed butterfly), y_l = K^T (u - w),
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(128) void k_big_cost(BatchPtrs p, BigPtrs bg, Polic
 }
 
 // one workgroup per window: the candidate cost and the lines' step statistics summed in a fixed order, for k_lm_update
-__global__ __launch_bounds__(256) void k_big_reduce(BatchPtrs p, BigPtrs bg) {
+__global__ __launch_bounds__(256) void k_big_reduce(BatchPtrs p, BigPtrs bg, Policy pol) {
   __shared__ double red4[4];
   const int w = blockIdx.x, tid = threadIdx.x;
   const WinDesc wd = p.wins[w];
@@ -652,10 +658,10 @@ __global__ __launch_bounds__(256) void k_big_reduce(BatchPtrs p, BigPtrs bg) {
     m += la[kBlModel]; d += la[kBlDn2]; x += la[kBlXn2New];
   }
   cs = block_sum_256(cs, red4); m = block_sum_256(m, red4); d = block_sum_256(d, red4); x = block_sum_256(x, red4);
+  // ... and the trust-region bookkeeping of the step (what k_lm_update does for the tiled path)
   if (tid == 0) {
-    double* bp = p.bs_part + (long long)wd.chunk_off * kBsStride;
-    bp[kBsModel] = m; bp[kBsDn2] = d; bp[kBsXn2] = x;
-    p.cost_part[wd.chunk_off] = cs;
+    LMState* st = p.state + w;
+    lm_step(p, pol, w, st, cs, st->cam_model + m, st->cam_dn2 + d, st->cam_xn2 + x);
   }
 }
 
