@@ -17,19 +17,26 @@
 
 namespace slslam {
 
-// lane J of every 16-lane row -> all lanes of the row
+// lane J of every 16-lane row -> all lanes of the row.  fp64: ONE v_mov_b64_dpp (row_newbcast is the control the DP ALU's DPP
+// accepts); the clang builtin only takes 32-bit values, the LLVM intrinsic is reached by its name.
+extern "C" __device__ double slslam_update_dpp_f64(double old, double src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+    __asm("llvm.amdgcn.update.dpp.f64");
 template <int J>
 __device__ __forceinline__ double tile_bcast(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + J, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + J, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
+  return slslam_update_dpp_f64(0.0, v, 0x150 + J, 0xF, 0xF, true);
 }
 template <int J>
 __device__ __forceinline__ float tile_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + J, 0xF, 0xF, true));
 }
-__device__ __forceinline__ double tile_rsqrt(double x) { return rsqrt(x); }      // v_rsq_f64 + refinement: no sqrt, no divide on the chain
+// 1 / sqrt(x) of a positive, finite x (the caller has tested the pivot): v_rsq_f64 and the one refinement step the device
+// library's rsqrt() applies - the same values - without its handling of 0 / inf / nan, which sits on the dependent chain of the
+// sixteen pivots.  No sqrt, no divide on that chain.
+__device__ __forceinline__ double tile_rsqrt(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y0, y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
 __device__ __forceinline__ float tile_rsqrt(float x) { return rsqrtf(x); }
 
 template <int JC, typename T>
@@ -38,15 +45,15 @@ __device__ __forceinline__ void diag_tile_steps(T (&a)[16], T (&e)[4], T& ipown,
     const T piv = tile_bcast<JC>(a[JC]);
     const bool okp = piv > T(0) && isfinite(piv);
     if (!okp) fail = 1;
-    const T ip = okp ? tile_rsqrt(piv) : T(1);
-    T m = a[JC] * (ip * ip);
+    const T ip = tile_rsqrt(okp ? piv : T(1));
+    const T below = (r > JC) ? a[JC] : T(0);                             // (off the pivot chain: ready before ip is)
+    const T nm = below * (ip * -ip);                                     // -a[JC] / piv for the rows below the pivot, 0 elsewhere
     a[JC] *= ip;                                                         // L[r][JC] for r >= JC
-    m = (r > JC) ? m : T(0);
     ipown = (r == JC) ? ip : ipown;
 #pragma unroll
-    for (int c = JC + 1; c < 16; ++c) a[c] = fma(-m, tile_bcast<JC>(a[c]), a[c]);
+    for (int c = JC + 1; c < 16; ++c) a[c] = fma(nm, tile_bcast<JC>(a[c]), a[c]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e[k] = fma(-m, tile_bcast<JC>(e[k]), e[k]);
+    for (int k = 0; k < 4; ++k) e[k] = fma(nm, tile_bcast<JC>(e[k]), e[k]);
     diag_tile_steps<JC + 1, T>(a, e, ipown, r, fail);
   }
 }
