@@ -692,7 +692,9 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     // reduced systems of at most 256 unknowns (the reference's W = 40: 240) are factorised and solved by one workgroup in one
     // launch, from registers (lba_big_solve.h): nothing dirties the system in memory, which every sweep rebuilds by stores
     bool one_launch_solve = !(pol.debug_flags & 2048);
-    for (int wi = 0; wi < B; ++wi) if (b->h_wins[wi].n > kBsvMaxN) one_launch_solve = false;
+    int max_n = 0;
+    for (int wi = 0; wi < B; ++wi) max_n = std::max(max_n, b->h_wins[wi].n);
+    if (max_n > kBsvMaxN) one_launch_solve = false;
     for (int it = 0; it < iters; ++it) {
       if (!capturing && it > 0 && (it % 16) == 0) {
         unsigned int active = 0;
@@ -714,9 +716,12 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       if (g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_F, g_obs128, blk128, 0, s, p, g));
       if (b->ncam > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_cam, g_camwg, blk256, 0, s, p, g));
       if (g.npairs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_pairs, g_pair, blk256, 0, s, p, g));
-      LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_prepare, g_win, blk256, 0, s, p, g, pol));
+      LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_prepare, g_win, blk256, 0, s, p, g, pol, one_launch_solve ? 1 : 0));
       if (pol.max_num_iterations <= 0) break;
-      if (one_launch_solve) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_solve, g_win, dim3(64 * kBsvWaves), 0, s, p, g, pol));
+      if (one_launch_solve) {
+        if (max_n <= 240) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_solve<15>, g_win, dim3(64 * kBsvWaves), 0, s, p, g, pol));
+        else LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_solve<kBsvSlots>, g_win, dim3(64 * kBsvWaves), 0, s, p, g, pol));
+      }
       for (int wi = 0; wi < B && !one_launch_solve; ++wi) {
         const int n = b->h_wins[wi].n;
         if (n <= 0) continue;

@@ -36,7 +36,7 @@ struct BigPtrs {
                                // per-window sums stream them)
   double* camtab;              // [ncam][2][kBigCam]
   double* line_acc;            // [nline][kBigLine]
-  double* sys;                 // per window: S [n x ld] | b [n] | g [n] | h [n] | y [n]
+  double* sys;                 // per window: S [n x ld] | b [n] | g [n] | h [n] | y [n] | Jacobi scale of the unknowns [n]
   const long long* sys_off;    // [nwin]
   // gather lists, built on the host: every sum of the path is formed by ONE thread group walking a list in a fixed order - no
   // atomics, results bitwise reproducible
@@ -51,7 +51,7 @@ struct BigPtrs {
   long long npairs, nobs;
 };
 __host__ __device__ inline int big_ld(int n) { return ((n + 7) / 8) * 8 + 8; }
-__host__ __device__ inline long long big_sys_doubles(int n) { return (long long)(n > 0 ? n : 1) * big_ld(n) + 4LL * (n > 0 ? n : 1); }
+__host__ __device__ inline long long big_sys_doubles(int n) { return (long long)(n > 0 ? n : 1) * big_ld(n) + 5LL * (n > 0 ? n : 1); }
 
 // Sum of one value per thread over a 256-thread workgroup in a fixed order (the same tree every run); red: 4 doubles of LDS.
 __device__ __forceinline__ double block_sum_256(double v, double* red) {
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void k_big_pairs(BatchPtrs p, BigPtrs bg) {
 // one workgroup per window: Ceres' initial bookkeeping on the first sweep (cost, gradient norm, |x|, Jacobi scale of the
 // camera columns, trace record 0, the tests that end a solve before its first step) and the congruence to scaled
 // coordinates; gradient test after an accepted step; LM damping; right-hand side.  (k_reduced_solve steps 1b - 3.)
-__global__ __launch_bounds__(256) void k_big_prepare(BatchPtrs p, BigPtrs bg, Policy pol) {
+__global__ __launch_bounds__(256) void k_big_prepare(BatchPtrs p, BigPtrs bg, Policy pol, int solver_scales) {
   __shared__ double red[8], red4[4];
   const int w = blockIdx.x, tid = threadIdx.x;
   const WinDesc wd = p.wins[w];
@@ -415,21 +415,23 @@ __global__ __launch_bounds__(256) void k_big_prepare(BatchPtrs p, BigPtrs bg, Po
   }
   __syncthreads();
   if (fresh) {
-    if (tid == 0) {
-      double cost = cost_sum, fixed = fixed_sum, xn2 = xn2_line, gmax = gmax_line;
-      for (int c = 0; c < wd.C; ++c) {
-        const int cf = p.cam_cf[wd.cam_off + c];
-        for (int a = 0; a < 6; ++a) {
-          double s = 1.0;
-          if (cf >= 0) {
-            const double x = p.cam_x[((long long)(wd.cam_off + c) * 2 + cur) * kCamRec + a];
-            gmax = fmax(gmax, fabs(gvec[6 * cf + a]));
-            xn2 += x * x;
-            if (pol.jacobi_scaling) s = 1.0 / (1.0 + sqrt(hvec[6 * cf + a]));
-          }
-          p.cam_scale[(long long)(wd.cam_off + c) * 6 + a] = s;
-        }
+    // camera entries: thread <-> (camera, component), sums in the fixed order of the workgroup's tree
+    double gm_c = 0.0, xs_c = 0.0;
+    for (int q = tid; q < 6 * wd.C; q += 256) {
+      const int c = q / 6, a = q - 6 * c, cf = p.cam_cf[wd.cam_off + c];
+      double s = 1.0;
+      if (cf >= 0) {
+        const double x = p.cam_x[((long long)(wd.cam_off + c) * 2 + cur) * kCamRec + a];
+        gm_c = fmax(gm_c, fabs(gvec[6 * cf + a]));
+        xs_c += x * x;
+        if (pol.jacobi_scaling) s = 1.0 / (1.0 + sqrt(hvec[6 * cf + a]));
       }
+      p.cam_scale[(long long)(wd.cam_off + c) * 6 + a] = s;
+    }
+    gm_c = block_max_256(gm_c, red4);
+    xs_c = block_sum_256(xs_c, red4);
+    if (tid == 0) {
+      const double cost = cost_sum, fixed = fixed_sum, xn2 = xn2_line + xs_c, gmax = fmax(gmax_line, gm_c);
       st->cost = cost; st->fixed_cost = fixed; st->initial_cost = cost + fixed; st->min_cost = cost + fixed;
       st->x_norm = sqrt(xn2);
       st->grad_max = gmax;
@@ -462,11 +464,14 @@ __global__ __launch_bounds__(256) void k_big_prepare(BatchPtrs p, BigPtrs bg, Po
         for (int a = 0; a < 6; ++a) yvec[6 * cf + a] = p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
     }
     __syncthreads();
-    for (long long q = tid; q < (long long)n * n; q += 256) {
-      const int r = (int)(q / n), c = (int)(q - (long long)r * n);
-      if (c <= r) S[(long long)r * ld + c] *= yvec[r] * yvec[c];
-    }
-    for (int q = tid; q < n; q += 256) { const double s = yvec[q]; bvec[q] *= s; gvec[q] *= s; hvec[q] *= s * s; }
+    // (solver_scales: k_big_solve applies the congruence and the damping to the copy of S it factorises - the matrix in
+    // memory is only ever written by the sweeps that build it)
+    if (!solver_scales)
+      for (long long q = tid; q < (long long)n * n; q += 256) {
+        const int r = (int)(q / n), c = (int)(q - (long long)r * n);
+        if (c <= r) S[(long long)r * ld + c] *= yvec[r] * yvec[c];
+      }
+    for (int q = tid; q < n; q += 256) { const double s = yvec[q]; bvec[q] *= s; gvec[q] *= s; hvec[q] *= s * s; yvec[n + q] = s; }
     __syncthreads();
   } else if (need_grad) {
     double gm = 0.0;
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(256) void k_big_prepare(BatchPtrs p, BigPtrs bg, Po
   for (int q = tid; q < n; q += 256) {
     const double d2 = fmin(fmax(hvec[q], pol.min_lm_diagonal), pol.max_lm_diagonal) / radius;
     hvec[q] = d2;
-    S[(long long)q * ld + q] += d2;
+    if (!solver_scales) S[(long long)q * ld + q] += d2;
     yvec[q] = bvec[q];
   }
 }

@@ -25,13 +25,18 @@
 
 namespace slslam {
 
-enum { kBsvMaxN = 256, kBsvWaves = 8, kBsvSlots = 17, kBsvLd = 17 };   // 136 blocks of 16 over 8 waves; LDS tiles: 34-dword rows
+enum { kBsvMaxN = 256, kBsvWaves = 8, kBsvSlots = 17, kBsvLd = 17, kBsvPark = 0 };   // 136 blocks of 16 over 8 waves; LDS tiles: 34-dword rows
 
+// SLOTS: blocks per wave - 15 for n <= 240 (120 blocks: the reference's W = 40), 17 for n <= 256; the kernel sits at the
+// register limit of two waves per SIMD and the two slots less keep the tile factorisation out of scratch
+template <int SLOTS>
 __global__ __launch_bounds__(64 * kBsvWaves) void k_big_solve(BatchPtrs p, BigPtrs bg, Policy pol) {
-  __shared__ double Pan[16][16 * kBsvLd];      // block column k of the factor, one tile per block row
+  __shared__ double Pan[2][16][16 * kBsvLd];   // block column k of the factor (buffer k & 1), one tile per block row
   __shared__ double Xs[16][16 * kBsvLd];       // inverses of the diagonal tiles
   __shared__ double Dt[16 * kBsvLd];           // the diagonal tile being factored
   __shared__ double yv[kBsvMaxN];              // right-hand side -> y -> solution
+  __shared__ double dv[kBsvMaxN], sv[kBsvMaxN]; // LM damping of the diagonal, Jacobi scale of the first sweep (else 1)
+  __shared__ v4f64 park[(kBsvPark > 0 ? kBsvPark : 1) * 64];        // blocks of the factoring wave, out of its registers for the duration
   __shared__ int failed;
   const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const WinDesc wd = p.wins[w];
@@ -44,15 +49,22 @@ __global__ __launch_bounds__(64 * kBsvWaves) void k_big_solve(BatchPtrs p, BigPt
   unsigned long long tlast_ = timing ? solve_clock() : 0ull;
   const int am = lane & 15, ak = lane >> 4;            // MFMA operand coordinates (row / k) and result column; result rows ak + 4 q
   // (LDS set up before the loads of S are issued: the first diagonal tile is factored while the rest of them are in flight)
-  if (tid < kBsvMaxN) yv[tid] = tid < n ? yvec[tid] : 0.0;
+  // the first sweep of a solve built S in unscaled camera coordinates: the congruence with the Jacobi scale k_big_prepare derived
+  // is applied to the copy in the registers, and so is the LM damping (every iteration) - k_big_prepare leaves S alone
+  const bool rescale = bg.scal[(long long)w * kBgScal + kBgWasFresh] != 0.0;
+  if (tid < kBsvMaxN) {
+    yv[tid] = tid < n ? yvec[tid] : 0.0;
+    dv[tid] = tid < n ? yvec[tid - n] : 0.0;                               // h: the damping term of the diagonal
+    sv[tid] = (tid < n && rescale) ? yvec[n + tid] : 1.0;
+  }
   if (tid == 0) failed = 0;
   for (int q = tid; q < 16 * 16 * kBsvLd; q += 64 * kBsvWaves) (&Xs[0][0])[q] = 0.0;      // (upper triangles stay zero)
   __syncthreads();
   // the blocks of this wave
-  v4f64 acc[kBsvSlots];
-  int bi[kBsvSlots], bj[kBsvSlots];
+  v4f64 acc[SLOTS];
+  int bi[SLOTS], bj[SLOTS];
 #pragma unroll
-  for (int s = 0; s < kBsvSlots; ++s) {
+  for (int s = 0; s < SLOTS; ++s) {
     const int b = s * kBsvWaves + wave;
     int i = 0;
     while (((i + 1) * (i + 2)) / 2 <= b) ++i;             // (wave-uniform: scalar code)
@@ -69,8 +81,17 @@ __global__ __launch_bounds__(64 * kBsvWaves) void k_big_solve(BatchPtrs p, BigPt
         const int r = r0 + 4 * q;
         const bool in = i < NB && r < n && c <= r;
         const double v = S[in ? off0 + 4 * q * ld : 0];
-        acc[s][q] = in ? v : (r == c) ? 1.0 : 0.0;     // rows beyond n: identity
+        acc[s][q] = in ? v : (r == c) ? 1.0 : 0.0;     // rows beyond n: identity (scale 1, damping 0 there)
       }
+    }
+    if (rescale) {
+      const double sc = sv[c];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[s][q] *= sv[r0 + 4 * q] * sc;
+    }
+    if (i == j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (r0 + 4 * q == c) acc[s][q] += dv[c];
     }
   }
 
@@ -93,18 +114,18 @@ __global__ __launch_bounds__(64 * kBsvWaves) void k_big_solve(BatchPtrs p, BigPt
     if (timing && lane == 0) p.dbg_cycles[(long long)w * 16 + 5] += solve_clock() - tf0;
   };
   SLS_SOLVE_STAMP(0);
-  if (wave == 0 && NB > 0) factor_diag(0, acc[0]);
-  __syncthreads();
-  SLS_SOLVE_STAMP(1);
 
-  for (int k = 0; k < NB; ++k) {
+  // (k = -1: only the first diagonal tile is factored - one copy of that code in the kernel, which is larger than the
+  // instruction cache as it is)
+  int deferred = -1;
+  for (int k = -1; k < NB; ++k) {
     // ---- panel below the diagonal tile: L_ik = A_ik X_kk^T; forward substitution b_i -= L_ik y_k
 #pragma unroll
-    for (int s = 0; s < kBsvSlots; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
       if (bj[s] != k || bi[s] <= k) continue;
       int ib = bi[s];
       asm volatile("" : "+s"(ib));                       // (opaque: the slot's LDS addresses are formed here, not hoisted out of the k loop for all slots at once)
-      double* P = Pan[ib];
+      double* P = Pan[k & 1][ib];
       const double* X = Xs[k];
 #pragma unroll
       for (int q = 0; q < 4; ++q) P[(ak + 4 * q) * kBsvLd + am] = acc[s][q];
@@ -122,37 +143,48 @@ __global__ __launch_bounds__(64 * kBsvWaves) void k_big_solve(BatchPtrs p, BigPt
         if (am == 0) yv[16 * ib + ak + 4 * q] -= t;
       }
     }
-    __syncthreads();
+    if (k >= 0) __syncthreads();
     SLS_SOLVE_STAMP(2);
     // ---- trailing update A_ij -= L_ik L_jk^T.  Look-ahead: the wave that holds the next diagonal tile updates it first and
-    // factors it while the other waves work through their blocks - the 16 sequential pivots of a tile are the long pole of a step.
-    // (Tried: that wave putting off its other blocks to the next phase behind a double-buffered panel - the extra unrolled
-    // slot loops cost registers, the factorisation spilled and the kernel went from 136 to 180 us.)
-    auto update = [&](v4f64& c, int ib, int jb) {
+    // factors it while the other waves work through their blocks - the 16 sequential pivots of a tile are the long pole of a
+    // step - and of its other blocks it only brings the next panel's up to date: the rest of this step's updates wait for the
+    // next phase (the panel is double-buffered), when another wave is the one factoring.
+    auto update = [&](v4f64& c, const int kk, int ib, int jb) {
       asm volatile("" : "+s"(ib), "+s"(jb));
-      const double* Pi = Pan[ib];
-      const double* Pj = Pan[jb];
+      const double* Pi = Pan[kk & 1][ib];
+      const double* Pj = Pan[kk & 1][jb];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)
         c = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pi[am * kBsvLd + 4 * s4 + ak], Pj[am * kBsvLd + 4 * s4 + ak], c, 0, 0, 0);
     };
     const int bd = ((k + 1) * (k + 2)) / 2 + k + 1;
-    if (k + 1 < NB && wave == (bd & (kBsvWaves - 1))) {
+    const int pend = deferred;                                   // -1, or k - 1: that step is still missing on this wave's blocks with j > k
+    const bool factoring = k + 1 < NB && wave == (bd & (kBsvWaves - 1));
+    if (factoring) {
       v4f64 d = acc[0];
 #pragma unroll
-      for (int s = 0; s < kBsvSlots; ++s)
-        if (s == bd / kBsvWaves) { update(acc[s], k + 1, k + 1); d = acc[s]; }
+      for (int s = 0; s < SLOTS; ++s)
+        if (s == bd / kBsvWaves) {
+          if (pend >= 0) update(acc[s], pend, k + 1, k + 1);
+          if (k >= 0) update(acc[s], k, k + 1, k + 1);
+          d = acc[s];
+        }
       factor_diag(k + 1, d);
     }
+    // the blocks of this wave: a pending older step first (its panel buffer is the one the next panel is written to), then this
+    // step - which the factoring wave only applies to the next panel's blocks (j = k + 1) and leaves pending on the others
+    const int jhi = factoring ? k + 1 : NB;
 #pragma unroll
-    for (int s = 0; s < kBsvSlots; ++s) {
-      if (bj[s] <= k || bi[s] < 0 || (bi[s] == k + 1 && bj[s] == k + 1)) continue;
-      update(acc[s], bi[s], bj[s]);
+    for (int s = 0; s < SLOTS; ++s) {
+      if (k < 0 || bj[s] <= k || bi[s] < 0 || (bi[s] == k + 1 && bj[s] == k + 1)) continue;
+      if (pend >= 0) update(acc[s], pend, bi[s], bj[s]);
+      if (bj[s] <= jhi) update(acc[s], k, bi[s], bj[s]);
     }
+    deferred = (factoring && k >= 0) ? k : -1;
     __syncthreads();
     SLS_SOLVE_STAMP(3);
-    // (factor_diag(k + 1) wrote Dt, Xs[k + 1], y_(k+1): nothing the trailing update reads; the next panel's stores to Pan
-    // come after this barrier)
+    // (factor_diag(k + 1) wrote Dt, Xs[k + 1], y_(k+1): nothing the trailing update reads; the next panel's stores go to the
+    // buffer of step k - 1, whose pending updates every wave has applied by now)
   }
   // ---- backward substitution
   for (int i = NB - 1; i >= 0; --i) {
@@ -168,7 +200,7 @@ __global__ __launch_bounds__(64 * kBsvWaves) void k_big_solve(BatchPtrs p, BigPt
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kBsvSlots; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
       if (bi[s] != i || bj[s] >= i) continue;
       int jb = bj[s];
       asm volatile("" : "+s"(jb));
