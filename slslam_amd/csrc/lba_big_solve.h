@@ -7,15 +7,27 @@
 // chooses the solver; what it does to a window is restated in oracle/lba_oracle.c: lba_solve_reduced).
 //
 // Layout: the lower triangle of S as 16 x 16 blocks, at most 136 of them, lives in the REGISTERS of the workgroup's eight waves
-// (block b = i (i + 1) / 2 + j belongs to wave b % 8, slot b / 8: 17 slots of four doubles per lane, the result layout of
-// v_mfma_f64_16x16x4_f64) from the one pass that reads S until the solution is written - nothing of the factor goes back to
-// memory.  Right-looking, one block column k at a time:
-//   1. the wave that holds (k, k) factors it (dense_tile.h: row per lane, DPP broadcasts, the tile's inverse X_kk from the same
-//      sweep) and forms y_k = X_kk b_k of the forward substitution;
-//   2. the waves that hold (i, k), i > k: L_ik = A_ik X_kk^T on the MFMA (operands staged through LDS), b_i -= L_ik y_k;
-//   3. every wave: A_ij -= L_ik L_jk^T for its blocks with i >= j > k, operands from the panel in LDS.
-// Then the backward substitution x_i = X_ii^T y_i, y_k -= L_ik^T x_i (k < i), block row by block row from the registers.
-// Two workgroup barriers per step, no atomics: every sum has one owner and a fixed order (bitwise reproducible).
+// (block b = i (i + 1) / 2 + j belongs to wave b % 8, slot b / 8: 15 or 17 slots of four doubles per lane, the result layout of
+// v_mfma_f64_16x16x4_f64) from the one pass that reads S - applying the Jacobi congruence of a first sweep and the LM damping
+// on the way, so nothing but the sweeps that build S ever writes it - until the solution is written: nothing of the factor
+// goes back to memory.  Right-looking, one block column k at a time, two workgroup barriers per step:
+//   panel     the waves that hold (i, k), i > k: L_ik = A_ik X_kk^T on the MFMA (operands staged through LDS), b_i -= L_ik y_k;
+//   trailing  every wave: A_ij -= L_ik L_jk^T for its blocks with i >= j > k, operands from the panel in LDS.  LOOK-AHEAD: the
+//             wave that holds (k + 1, k + 1) updates that tile first and factors it meanwhile (dense_tile.h: row per lane, DPP
+//             broadcasts, the tile's inverse X from the same sweep; y = X b of the forward substitution) - the sixteen
+//             sequential pivots of a tile are the long pole of a step - and puts off its other blocks' updates of this step
+//             to the next phase (the panel is double-buffered; only the next panel's blocks are brought up to date at once).
+// Then the backward substitution x_i = X_ii^T y_i, y_k -= L_ik^T x_i (k < i), block row by block row from the registers, the
+// step statistics of the camera block, the candidate poses and their rotation tables.  No atomics: every sum has one owner
+// and a fixed order (bitwise reproducible).
+//
+// Measured (house-sized W = 40 window, n = 240, tools/big_solve_phases.py): 113 us per launch against 205 us for the launch
+// chain; by phase: load 7 %, panels 25 %, trailing with the look-ahead factorisation 55 % (the tiles themselves 29 %),
+// backward 13 %.  A phase between two barriers costs ~0.5 us even when nearly empty (the unrolled slot loops are scalar branch
+// chains and the kernel is larger than the instruction cache), so what is left is mostly the 60 phases.  Tried and dropped:
+// blocks kept transposed so the panel solve multiplies straight from registers (panel phase -19 %, but the strided first read
+// of S, the row-wise backward sums and the rest cost more: +7 % overall); two blocks per round of LDS reads in the trailing
+// loop (no gain: the MFMA issue rate, not its latency, bounds that loop); four waves with 34 slots (accumulators spill).
 #ifndef SLSLAM_LBA_BIG_SOLVE_H_
 #define SLSLAM_LBA_BIG_SOLVE_H_
 

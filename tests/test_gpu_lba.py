@@ -130,7 +130,9 @@ def test_windows_beyond_the_tiled_sweeps(hip, oracle):
     (Lines observed by more than 64 keyframes: tests/test_house_study.py, W = 40.)"""
     ws = [synth.make_window(31, num_lines=100, num_kf=80, num_free=40, mean_track=30.0),
           synth.make_window(33, num_lines=80, num_kf=70, num_free=12, mean_track=20.0),        # > 64 cameras only
-          synth.make_window(34, num_lines=50, num_kf=30, num_free=24, mean_track=10.0)]        # > 20 free cameras only
+          synth.make_window(34, num_lines=50, num_kf=30, num_free=24, mean_track=10.0),        # > 20 free cameras only
+          synth.make_window(36, num_lines=60, num_kf=50, num_free=42, mean_track=25.0),        # 252 unknowns: the 17-slot form of k_big_solve
+          synth.make_window(37, num_lines=60, num_kf=50, num_free=44, mean_track=25.0)]        # 264 unknowns: the launch chain of the pose-graph Cholesky
     for w in ws:
         x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
         x1, s1, t1 = hip.lba_solve(w)

@@ -5,7 +5,7 @@ os.environ["SLSLAM_DEBUG_ABLATE"] = "512"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from slslam_amd import capi, synth
-names = ["load", "first diagonal tile", "panels", "trailing + look-ahead factor", "backward", "(diagonal tiles, inside)"]
+names = ["load", "-", "panels", "trailing + look-ahead factor", "backward", "(diagonal tiles, inside)"]
 w = synth.make_window(5, num_lines=74, num_kf=80, num_free=40, mean_track=61.0)
 b = capi.LBABatch(); b.add(w); b.finalize(use_graph=0)
 def read():
