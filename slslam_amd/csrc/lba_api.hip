@@ -659,6 +659,14 @@ struct Launcher {
   }
 };
 
+// windows beyond the tiled sweeps whose reduced systems all fit k_big_solve (lba_big_solve.h): no memsets, no per-window launch
+// loop - the solve is a fixed sequence of launches like the tiled path's, and can be captured
+bool big_one_launch(const slslam_lba_batch* b) {
+  if (!b->big_mode || (b->pol.debug_flags & 2048)) return false;
+  for (const WinDesc& wd : b->h_wins) if (wd.n > kBsvMaxN) return false;
+  return true;
+}
+
 int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing = false) {
   const BatchPtrs& p = b->ptrs;
   const Policy& pol = b->pol;
@@ -691,10 +699,9 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     const int iters = std::max(1, pol.max_num_iterations);      // (max_num_iterations = 0: the first sweep's initial evaluation only)
     // reduced systems of at most 256 unknowns (the reference's W = 40: 240) are factorised and solved by one workgroup in one
     // launch, from registers (lba_big_solve.h): nothing dirties the system in memory, which every sweep rebuilds by stores
-    bool one_launch_solve = !(pol.debug_flags & 2048);
     int max_n = 0;
     for (int wi = 0; wi < B; ++wi) max_n = std::max(max_n, b->h_wins[wi].n);
-    if (max_n > kBsvMaxN) one_launch_solve = false;
+    const bool one_launch_solve = big_one_launch(b);
     for (int it = 0; it < iters; ++it) {
       if (!capturing && it > 0 && (it % 16) == 0) {
         unsigned int active = 0;
@@ -709,11 +716,19 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
         HIP_TRY(hipMemsetAsync(b->d_big_sys.p, 0, b->d_big_sys.n * sizeof(double), s));
         HIP_TRY(hipMemsetAsync(b->d_big_flags.p, 0, b->d_big_flags.n * sizeof(int), s));
       }
-      LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_cameras, g_cam, blk256, 0, s, p, g, 0));
-      if (g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_linearise, g_obs128, blk128, 0, s, p, g, pol));
-      if (b->nline > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_line, g_linew, blk256, 0, s, p, g, pol));
-      if (it == 0 && g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_rescale, g_obs256, blk256, 0, s, p, g));
-      if (g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_F, g_obs128, blk128, 0, s, p, g));
+      // (the launch-chain variant keeps the round-2 sequence of one kernel per stage; the default folds the stages a wave can
+      // do for its own line into k_big_line / k_big_backsub_line and the table refresh into k_big_reduce: every kernel of this
+      // path runs for a few microseconds and the launches are what an iteration is made of)
+      const bool fold = one_launch_solve;
+      if (it == 0 || !fold) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_cameras, g_cam, blk256, 0, s, p, g, 0));
+      if (fold) {
+        if (b->nline > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_line<true>, g_linew, blk256, 0, s, p, g, pol));
+      } else {
+        if (g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_linearise, g_obs128, blk128, 0, s, p, g, pol));
+        if (b->nline > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_line<false>, g_linew, blk256, 0, s, p, g, pol));
+        if (it == 0 && g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_rescale, g_obs256, blk256, 0, s, p, g));
+        if (g.nobs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_F, g_obs128, blk128, 0, s, p, g));
+      }
       if (b->ncam > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_cam, g_camwg, blk256, 0, s, p, g));
       if (g.npairs > 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_big_pairs, g_pair, blk256, 0, s, p, g));
       LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_prepare, g_win, blk256, 0, s, p, g, pol, one_launch_solve ? 1 : 0));
@@ -744,9 +759,13 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       if (!one_launch_solve) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_finish, g_win, blk64, 0, s, p, g));
       if (it == 0 && g.nobs > 0) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_big_rescale_cameras, g_obs256, blk256, 0, s, p, g));
       if (!one_launch_solve) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_cameras, g_cam, blk256, 0, s, p, g, 1));
-      if (b->nline > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_backsub_line, g_linew, blk256, 0, s, p, g));
-      if (g.nobs > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_cost, g_obs128, blk128, 0, s, p, g, pol));
-      LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_big_reduce, g_win, blk256, 0, s, p, g, pol));
+      if (fold) {
+        if (b->nline > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_backsub_line<true>, g_linew, blk256, 0, s, p, g, pol));
+      } else {
+        if (b->nline > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_backsub_line<false>, g_linew, blk256, 0, s, p, g, pol));
+        if (g.nobs > 0) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_big_cost, g_obs128, blk128, 0, s, p, g, pol));
+      }
+      LAUNCH(FAM_UPDATE, hipLaunchKernelGGL(k_big_reduce, g_win, blk256, 0, s, p, g, pol, fold ? 1 : 0));
     }
     HIP_TRY(hipGetLastError());
     return SLSLAM_OK;
@@ -808,7 +827,7 @@ extern "C" int slslam_lba_batch_solve(slslam_lba_batch* b, void* stream) {
     if (b->ev_next > 16384) b->harvest_events();        // long profiled runs: bounded pool (costs one synchronisation)
     return enqueue_solve(b, s, true);
   }
-  if (!b->opt.use_graph || b->opt.max_num_iterations > 16 || b->big_mode) return enqueue_solve(b, s, false);
+  if (!b->opt.use_graph || b->opt.max_num_iterations > 16 || (b->big_mode && !big_one_launch(b))) return enqueue_solve(b, s, false);
   if (!b->graph_exec) {
     // capture the whole solve (1 + 4 * max_iter launches) once; replay costs one host call
     HIP_TRY(hipStreamCreateWithFlags(&b->capture_stream, hipStreamNonBlocking));

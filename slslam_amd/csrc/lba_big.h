@@ -88,15 +88,8 @@ __global__ __launch_bounds__(256) void k_big_cameras(BatchPtrs p, BigPtrs bg, in
 
 // thread <-> observation: residual, Jacobians, Huber, scaling, kept per observation.  At the first sweep of a solve (fresh)
 // all scales are 1 (see k_big_line / k_big_prepare).
-__global__ __launch_bounds__(128) void k_big_linearise(BatchPtrs p, BigPtrs bg, Policy pol) {
-  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= bg.nobs) return;
-  const int ls = bg.ob_line[o], w = p.line_win[ls];
-  const WinDesc wd = p.wins[w];
-  const LMState* st = p.state + w;
-  if (st->status != kRunning) return;
-  const int cur = st->cur;
-  const bool fresh = st->fresh != 0;
+__device__ __forceinline__ void big_linearise_obs(const BatchPtrs& p, const BigPtrs& bg, const Policy& pol, const long long o, const int ls,
+                                                  const WinDesc& wd, const int cur, const bool fresh) {
   const int cam = wd.cam_off + p.ob_cam[o], cf = p.cam_cf[cam];
   const double* ct = bg.camtab + (long long)cam * 2 * kBigCam;
   double R[9], JL[9], t[3], trig[7], ob[8];
@@ -124,10 +117,48 @@ __global__ __launch_bounds__(128) void k_big_linearise(BatchPtrs p, BigPtrs bg, 
   J[44] = cost;
   bg.cost[o] = cost;
 }
+__global__ __launch_bounds__(128) void k_big_linearise(BatchPtrs p, BigPtrs bg, Policy pol) {
+  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= bg.nobs) return;
+  const int ls = bg.ob_line[o], w = p.line_win[ls];
+  const LMState* st = p.state + w;
+  if (st->status != kRunning) return;
+  big_linearise_obs(p, bg, pol, o, ls, p.wins[w], st->cur, st->fresh != 0);
+}
+
+// the line Jacobian of one observation to scaled coordinates (first sweep: the scale comes out of the line's block)
+__device__ __forceinline__ void big_rescale_obs(const BigPtrs& bg, const long long o, const double* lsc) {
+  double* Jl = bg.J + o * kBigObs + 24;
+  for (int q = 0; q < 4; ++q)
+    for (int a = 0; a < 4; ++a) Jl[4 * q + a] *= lsc[a];
+}
+// F = (Jc^T Jl) K^T of one observation coupling a free camera to a free line (zero otherwise); K: the line's chol^-1 (10)
+__device__ __forceinline__ void big_F_obs(const BatchPtrs& p, const BigPtrs& bg, const long long o, const int ls, const WinDesc& wd,
+                                          const double* K) {
+  double* F = bg.F + o * kBigF;
+  if (p.cam_cf[wd.cam_off + p.ob_cam[o]] < 0 || (p.line_flags[ls] & 1)) { for (int q = 0; q < kBigF; ++q) F[q] = 0.0; return; }
+  const double* J = bg.J + o * kBigObs;
+  for (int a = 0; a < 6; ++a) {
+    double h[4];
+    for (int b = 0; b < 4; ++b) {
+      double s = 0.0;
+      for (int r = 0; r < 4; ++r) s += J[6 * r + a] * J[24 + 4 * r + b];
+      h[b] = s;
+    }
+    F[4 * a + 0] = h[0] * K[0];
+    F[4 * a + 1] = h[0] * K[1] + h[1] * K[2];
+    F[4 * a + 2] = h[0] * K[3] + h[1] * K[4] + h[2] * K[5];
+    F[4 * a + 3] = h[0] * K[6] + h[1] * K[7] + h[2] * K[8] + h[3] * K[9];
+  }
+}
 
 // wave <-> line: the line's normal-equation block summed over its observations (lane <-> observation, 64 at a time in order,
 // fixed butterfly); Jacobi scale (first sweep), LM damping, 4x4 Cholesky, K = chol^-1, u = K g; kept for the Schur products and
 // the back-substitution (line_elim)
+// ALL: the same wave also linearises the line's observations first (k_big_linearise) and forms their F blocks afterwards
+// (k_big_rescale, k_big_F): one launch instead of four on a path whose kernels each run for a few microseconds.  A lane reads
+// back only what it wrote itself (lane <-> observation, the same chunks of 64 in every pass).
+template <bool ALL>
 __global__ __launch_bounds__(256) void k_big_line(BatchPtrs p, BigPtrs bg, Policy pol) {
   const int ls = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (ls >= p.nline) return;
@@ -138,6 +169,11 @@ __global__ __launch_bounds__(256) void k_big_line(BatchPtrs p, BigPtrs bg, Polic
   const int cur = st->cur;
   const int o0 = p.line_ptr[ls], k = p.line_ptr[ls + 1] - o0;
   const bool line_active = !(p.line_flags[ls] & 1) && k > 0;
+  if (ALL) {
+    const WinDesc wd = p.wins[w];
+    for (int base = 0; base < k; base += 64)
+      if (base + lane < k) big_linearise_obs(p, bg, pol, o0 + base + lane, ls, wd, cur, fresh);
+  }
   double* la = bg.line_acc + (long long)ls * kBigLine;
   double H[10], g[4], D2[4], K[10], u[4] = { 0, 0, 0, 0 };
 #pragma unroll
@@ -201,6 +237,15 @@ __global__ __launch_bounds__(256) void k_big_line(BatchPtrs p, BigPtrs bg, Polic
     if (st->need_grad_check)
       for (int a = 0; a < 4; ++a) gm = fmax(gm, fabs(g[a] / sl[a]));
   }
+  if (ALL) {
+    const WinDesc wd = p.wins[w];
+    for (int base = 0; base < k; base += 64) {
+      if (base + lane >= k) continue;
+      const long long o = o0 + base + lane;
+      if (fresh) big_rescale_obs(bg, o, sl);
+      big_F_obs(p, bg, o, ls, wd, K);
+    }
+  }
   if (lane != 0) return;                                  // every lane holds the same values; one writes
   if (fresh) for (int a = 0; a < 4; ++a) lsc[a] = sl[a];
   la[kBlGmax] = gm; la[kBlXn2] = xn2; la[kBlFail] = ok ? 0.0 : 1.0;
@@ -216,10 +261,7 @@ __global__ __launch_bounds__(256) void k_big_rescale(BatchPtrs p, BigPtrs bg) {
   const int ls = bg.ob_line[o];
   const LMState* st = p.state + p.line_win[ls];
   if (st->status != kRunning || !st->fresh) return;
-  double* Jl = bg.J + o * kBigObs + 24;
-  const double* lsc = p.line_scale + (long long)ls * 4;
-  for (int q = 0; q < 4; ++q)
-    for (int a = 0; a < 4; ++a) Jl[4 * q + a] *= lsc[a];
+  big_rescale_obs(bg, o, p.line_scale + (long long)ls * 4);
 }
 
 // thread <-> observation coupling a free camera to a free line: F = (Jc^T Jl) K^T, kept for the camera blocks, the pair
@@ -228,24 +270,8 @@ __global__ __launch_bounds__(128) void k_big_F(BatchPtrs p, BigPtrs bg) {
   const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= bg.nobs) return;
   const int ls = bg.ob_line[o], w = p.line_win[ls];
-  const WinDesc wd = p.wins[w];
   if (p.state[w].status != kRunning) return;
-  double* F = bg.F + o * kBigF;
-  if (p.cam_cf[wd.cam_off + p.ob_cam[o]] < 0 || (p.line_flags[ls] & 1)) { for (int q = 0; q < kBigF; ++q) F[q] = 0.0; return; }
-  const double* J = bg.J + o * kBigObs;
-  const double* K = p.line_elim + (long long)ls * p.line_elim_stride;
-  for (int a = 0; a < 6; ++a) {
-    double h[4];
-    for (int b = 0; b < 4; ++b) {
-      double s = 0.0;
-      for (int r = 0; r < 4; ++r) s += J[6 * r + a] * J[24 + 4 * r + b];
-      h[b] = s;
-    }
-    F[4 * a + 0] = h[0] * K[0];
-    F[4 * a + 1] = h[0] * K[1] + h[1] * K[2];
-    F[4 * a + 2] = h[0] * K[3] + h[1] * K[4] + h[2] * K[5];
-    F[4 * a + 3] = h[0] * K[6] + h[1] * K[7] + h[2] * K[8] + h[3] * K[9];
-  }
+  big_F_obs(p, bg, o, ls, p.wins[w], p.line_elim + (long long)ls * p.line_elim_stride);
 }
 
 // One workgroup (4 waves) per free camera: its record of the reduced system - diagonal block Jc^T Jc - F F^T (21), b = Jc^T r - F u
@@ -567,9 +593,44 @@ __global__ __launch_bounds__(64) void k_big_finish(BatchPtrs p, BigPtrs bg) {
   big_finish(p, bg, w, threadIdx.x, bg.flags[2 * w] != 0);
 }
 
+// cost of one observation at the candidate point (candidate camera table; trig: sin / cos table of the candidate line)
+__device__ __forceinline__ void big_cost_obs(const BatchPtrs& p, const BigPtrs& bg, const Policy& pol, const long long o, const int ls,
+                                             const WinDesc& wd, const double* trig) {
+  const int cam = wd.cam_off + p.ob_cam[o], cf = p.cam_cf[cam];
+  double c = 0.0;
+  if (!(cf < 0 && (p.line_flags[ls] & 1))) {                            // in the reduced program
+    const double* ct = bg.camtab + ((long long)cam * 2 + 1) * kBigCam;
+    double R[9], t[3] = { ct[18], ct[19], ct[20] }, ob[8], cp[3], dv[3], r[4];
+    for (int q = 0; q < 9; ++q) R[q] = ct[q];
+    for (int q = 0; q < 4; ++q) {
+      const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
+      ob[2 * q] = e.x; ob[2 * q + 1] = e.y;
+    }
+    line_points<double>(trig, cp, dv);
+    obs_residual<double>(R, t, cp, dv, ob, pol.baseline, r);
+    huber_scale<double>(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], pol.huber_delta, &c);
+  }
+  bg.cost[bg.nobs + o] = c;
+}
+// thread <-> observation: cost at the candidate point, kept per observation
+__global__ __launch_bounds__(128) void k_big_cost(BatchPtrs p, BigPtrs bg, Policy pol) {
+  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= bg.nobs) return;
+  const int ls = bg.ob_line[o], w = p.line_win[ls];
+  const LMState* st = p.state + w;
+  if (st->status != kRunning) return;
+  const double* lrec = p.line_x + line_rec(p, ls, (1 - st->cur));
+  double trig[7];
+  for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
+  big_cost_obs(p, bg, pol, o, ls, p.wins[w], trig);
+}
+
 // wave <-> line: w = sum_i F_i^T y_c,i over the line's observations (lane <-> observation, fixed butterfly), y_l = K^T (u - w),
 // candidate parameters and their sin/cos table, the line's part of the step statistics (summed per window by k_big_reduce)
-__global__ __launch_bounds__(256) void k_big_backsub_line(BatchPtrs p, BigPtrs bg) {
+// COST: the same wave then evaluates the cost of the line's observations at the candidate point (k_big_cost; the candidate
+// camera table is there since the reduced solve) - one launch less.
+template <bool COST>
+__global__ __launch_bounds__(256) void k_big_backsub_line(BatchPtrs p, BigPtrs bg, Policy pol) {
   const int ls = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (ls >= p.nline) return;
   const int w = p.line_win[ls];
@@ -614,45 +675,22 @@ __global__ __launch_bounds__(256) void k_big_backsub_line(BatchPtrs p, BigPtrs b
       xn[a] = v;
     }
   }
+  double trig[7];
+  line_trig<double>(xn, trig);                            // (every lane holds the same candidate)
+  if (COST)
+    for (int base = 0; base < k; base += 64)
+      if (base + lane < k) big_cost_obs(p, bg, pol, o0 + base + lane, ls, wd, trig);
   if (lane != 0) return;
   double* la = bg.line_acc + (long long)ls * kBigLine;
   la[kBlModel] = model; la[kBlDn2] = dn2; la[kBlXn2New] = xn2;
-  double trig[7];
-  line_trig<double>(xn, trig);
   for (int a = 0; a < 4; ++a) xc[a] = xn[a];
   for (int a = 0; a < 7; ++a) xc[4 + a] = trig[a];
 }
 
-// thread <-> observation: cost at the candidate point, kept per observation
-__global__ __launch_bounds__(128) void k_big_cost(BatchPtrs p, BigPtrs bg, Policy pol) {
-  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= bg.nobs) return;
-  const int ls = bg.ob_line[o], w = p.line_win[ls];
-  const WinDesc wd = p.wins[w];
-  const LMState* st = p.state + w;
-  if (st->status != kRunning) return;
-  const int cam = wd.cam_off + p.ob_cam[o], cf = p.cam_cf[cam];
-  double c = 0.0;
-  if (!(cf < 0 && (p.line_flags[ls] & 1))) {                            // in the reduced program
-    const double* ct = bg.camtab + ((long long)cam * 2 + 1) * kBigCam;
-    const double* lrec = p.line_x + line_rec(p, ls, (1 - st->cur));
-    double R[9], t[3] = { ct[18], ct[19], ct[20] }, trig[7], ob[8], cp[3], dv[3], r[4];
-    for (int q = 0; q < 9; ++q) R[q] = ct[q];
-    for (int q = 0; q < 7; ++q) trig[q] = lrec[4 + q];
-    for (int q = 0; q < 4; ++q) {
-      const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
-      ob[2 * q] = e.x; ob[2 * q + 1] = e.y;
-    }
-    line_points<double>(trig, cp, dv);
-    obs_residual<double>(R, t, cp, dv, ob, pol.baseline, r);
-    huber_scale<double>(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], pol.huber_delta, &c);
-  }
-  bg.cost[bg.nobs + o] = c;
-}
-
 // one workgroup per window: the candidate cost and the lines' step statistics summed in a fixed order, for k_lm_update
-__global__ __launch_bounds__(256) void k_big_reduce(BatchPtrs p, BigPtrs bg, Policy pol) {
+__global__ __launch_bounds__(256) void k_big_reduce(BatchPtrs p, BigPtrs bg, Policy pol, int refresh_cameras) {
   __shared__ double red4[4];
+  __shared__ int cur_now;
   const int w = blockIdx.x, tid = threadIdx.x;
   const WinDesc wd = p.wins[w];
   if (p.state[w].status != kRunning) return;
@@ -667,6 +705,14 @@ __global__ __launch_bounds__(256) void k_big_reduce(BatchPtrs p, BigPtrs bg, Pol
   if (tid == 0) {
     LMState* st = p.state + w;
     lm_step(p, pol, w, st, cs, st->cam_model + m, st->cam_dn2 + d, st->cam_xn2 + x);
+    cur_now = st->cur;                                     // (through LDS: the other threads must not read a stale copy)
+  }
+  // rotation / Jacobian table of the cameras at the point the next sweep linearises at (what k_big_cameras(0) does at the
+  // start of an iteration)
+  if (refresh_cameras) {
+    __syncthreads();
+    const int cur = cur_now;
+    for (int c = tid; c < wd.C; c += 256) big_camera_entry(p, bg, wd.cam_off + c, cur, 0);
   }
 }
 

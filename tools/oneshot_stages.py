@@ -1,11 +1,11 @@
-"""Where the time of a one-shot slslam_lba_solve goes for windows of the reference's study sizes (house scene: 74 lines, W = 5 / 10 / 20):
+"""Where the time of a one-shot slslam_lba_solve goes for windows of the reference's study sizes (house scene: 74 lines, W = 5 / 10 / 20 / 40):
 host stages (pack, build + upload, enqueue, GPU + download) of the batch API, the one-shot call, and the resident graph replay."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slslam_amd import capi, synth
 
-for (kf, free, mt, label) in ((10, 5, 8.4, "W=5"), (20, 10, 16.5, "W=10"), (40, 20, 32.0, "W=20")):
+for (kf, free, mt, label) in ((10, 5, 8.4, "W=5"), (20, 10, 16.5, "W=10"), (40, 20, 32.0, "W=20"), (80, 40, 61.0, "W=40")):
     w = synth.make_window(5, num_lines=74, num_kf=kf, num_free=free, mean_track=mt)
     def stages():
         t = [time.perf_counter()]
