@@ -25,4 +25,12 @@ timeout 600 rocprofv3 --pmc $C2 -d gpurun_out/${TAG}_pl -o p -- $ONE > gpurun_ou
 python tools/rocpd_pmc.py $(ls gpurun_out/${TAG}_pl/*.db | head -1) > gpurun_out/${TAG}_pmc_lds.txt 2>&1
 rm -rf gpurun_out/${TAG}_pl
 bash tools/gpu_two_ranks_shared.sh > gpurun_out/${TAG}_two_ranks_shared.log 2>&1
+# windows beyond the tiled sweeps (lba_big.h / lba_big_solve.h) and single-window latency at the reference's study sizes
+python tools/big_window_prof.py 3 > gpurun_out/${TAG}_big_window.txt 2>&1
+python tools/big_solve_phases.py >> gpurun_out/${TAG}_big_window.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_bigkt -o t -- python tools/big_window_prof.py 1 > gpurun_out/${TAG}_bigkt.log 2>&1
+python tools/rocpd_summary.py $(ls gpurun_out/${TAG}_bigkt/*.db | head -1) >> gpurun_out/${TAG}_big_window.txt 2>&1
+rm -rf gpurun_out/${TAG}_bigkt
+python tools/oneshot_stages.py > gpurun_out/${TAG}_latency.txt 2>&1
+python tools/latency_families.py >> gpurun_out/${TAG}_latency.txt 2>&1
 tail -3 gpurun_out/${TAG}_gputests.log; head -12 gpurun_out/${TAG}_kernel_trace.txt; grep -A1 "k_linearise_schur\|k_backsub" gpurun_out/${TAG}_pmc.txt; cut -c1-300 gpurun_out/${TAG}_bench.json
