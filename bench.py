@@ -250,11 +250,11 @@ def time_batch(windows, device, steps, warmup, **opt):
     return its / dt, 1e3 * dt / steps
 
 
-def single_window_latency(lines, device):
+def single_window_latency(lines, device, **shape):
     """The reference's call protocol (slam.cpp:924-944: one window per keyframe, each built from the result of the one
     before): ms per 10-iteration solve of ONE window resident in HBM (hipGraph replay) and through slslam_lba_solve
     (host buffers: pack + upload + solve + download)."""
-    w = synth.make_window(5, num_lines=lines)
+    w = synth.make_window(5, num_lines=lines, **shape)
     _, resident = time_batch([w], device, 30, 3)
     capi.lba_solve(w)
     t0 = time.perf_counter()
@@ -594,6 +594,11 @@ def main():
                 c2["cpu_oracle_lm_iterations_per_s"] = (so["num_successful_steps"] + so["num_unsuccessful_steps"]) / dt
             out["config2_window_500_lines"] = c2
             out["latency_single_window"] = single_window_latency(args.lines, local_rank)
+            # the window sizes of the reference's own study (house scene: 74 lines; W free + W fixed keyframes).  W = 40 is
+            # beyond the tiled sweeps and takes the global-memory path (lba_big.h, lba_big_solve.h)
+            out["latency_study_windows"] = {
+                "W=%d" % W: single_window_latency(74, local_rank, num_kf=2 * W, num_free=W, mean_track=mt)
+                for W, mt in ((5, 8.4), (10, 16.5), (20, 32.0), (40, 61.0))}
             if not args.no_cpu_baseline:
                 out["config5_pose_graph"] = pose_graph_block()
         print(json.dumps(out))

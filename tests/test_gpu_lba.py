@@ -172,6 +172,35 @@ def test_windows_beyond_the_tiled_sweeps(hip, oracle):
     assert abs(s1["initial_cost"] - s0["initial_cost"]) <= 1e-12 * s0["initial_cost"] and np.array_equal(x1, ws[0]["parameters"])
 
 
+def test_oversize_window_sizes_and_batches(hip, oracle):
+    """The one-launch reduced solve of the global-memory path (lba_big_solve.h: blocks of 16 in registers, look-ahead, updates
+    deferred behind a double-buffered panel) over system sizes that end inside a block, on a block edge, in the 15- and the
+    17-slot form; and a batch of oversize windows of different sizes solved twice (graph replay)."""
+    for seed, free, kf, lines, mt in ((101, 21, 42, 40, 20.0), (103, 30, 66, 50, 28.0), (104, 33, 80, 74, 50.0), (105, 37, 74, 90, 33.0),
+                                      (106, 40, 85, 74, 61.0), (107, 41, 82, 64, 40.0), (109, 22, 30, 35, 9.0)):
+        w = synth.make_window(seed, num_lines=lines, num_kf=kf, num_free=free, mean_track=mt)
+        x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+        x1, s1, t1 = hip.lba_solve(w)
+        _assert_trace_parity(t0, t1, n=4, tight=True)
+        _assert_summary_parity(s0, s1)
+        _assert_params_parity(w, x0, x1)
+    ws = [synth.make_window(200 + i, num_lines=40 + 7 * i, num_kf=50 + 5 * i, num_free=24 + 3 * i, mean_track=20.0 + i) for i in range(6)]
+    b = hip.LBABatch()
+    for w in ws:
+        b.add(w)
+    b.finalize(); b.solve(); b.download()
+    assert b.path() == 2
+    first = [b.parameters(i).copy() for i in range(len(ws))]
+    b.reset(); b.solve(); b.download()
+    for i, w in enumerate(ws):
+        x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+        assert np.array_equal(first[i], b.parameters(i))
+        _assert_params_parity(w, x0, first[i])
+        _assert_summary_parity(s0, b.summary(i))
+        _assert_trace_parity(t0, b.trace(i), n=4, tight=True)
+    b.close()
+
+
 def test_one_iteration_is_roundoff_exact(hip, oracle):
     w = synth.make_window(11, num_lines=300)
     x0, s0, t0 = oracle.lba_solve(w, linear_solver=0, max_num_iterations=1)      # dense normal equations
