@@ -180,7 +180,7 @@ int  slslam_lba_batch_counts(const slslam_lba_batch* b, long long* num_windows, 
                              long long* num_free_cameras, long long* num_lines, long long* num_observations);
 /* After finalize: which device path the batch takes.  One window beyond the tiled sweeps (more than 20 free / 64 cameras, a line
  * with more than 64 observations: the reference's W = 40 study) sends the WHOLE batch down the global-memory path, which is
- * several times slower per observation for the ordinary windows in it - callers that mix sizes should batch them apart. */
+ * built for single large windows, not for batch throughput - callers that mix sizes should batch them apart. */
 enum { SLSLAM_PATH_TILED = 0, SLSLAM_PATH_FUSED_MOTION_ONLY = 1, SLSLAM_PATH_GLOBAL_MEMORY = 2 };
 int  slslam_lba_batch_path(const slslam_lba_batch* b, int* path);
 /* After finalize: the number of chunks (waves cooperating on the window's observation sweeps) window `index` was cut into.  A
