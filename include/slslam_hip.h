@@ -179,9 +179,11 @@ int  slslam_lba_batch_export_device(slslam_lba_batch* b, double* device_out, voi
 int  slslam_lba_batch_counts(const slslam_lba_batch* b, long long* num_windows, long long* num_cameras,
                              long long* num_free_cameras, long long* num_lines, long long* num_observations);
 /* After finalize: which device path the batch takes.  One window beyond the tiled sweeps (more than 20 free / 64 cameras, a line
- * with more than 64 observations: the reference's W = 40 study) sends the WHOLE batch down the global-memory path, which is
- * built for single large windows, not for batch throughput - callers that mix sizes should batch them apart. */
-enum { SLSLAM_PATH_TILED = 0, SLSLAM_PATH_FUSED_MOTION_ONLY = 1, SLSLAM_PATH_GLOBAL_MEMORY = 2 };
+ * with more than 64 observations: the reference's W = 40 study) takes the global-memory path (built for single large windows,
+ * not for batch throughput).  A batch that mixes such windows with ordinary ones is solved as two batches side by side - the
+ * ordinary windows on the tiled sweeps, the oversize ones on the global-memory path on a stream of the batch's own, joined to
+ * the caller's before the call returns control of it: SLSLAM_PATH_MIXED. */
+enum { SLSLAM_PATH_TILED = 0, SLSLAM_PATH_FUSED_MOTION_ONLY = 1, SLSLAM_PATH_GLOBAL_MEMORY = 2, SLSLAM_PATH_MIXED = 3 };
 int  slslam_lba_batch_path(const slslam_lba_batch* b, int* path);
 /* After finalize: the number of chunks (waves cooperating on the window's observation sweeps) window `index` was cut into.  A
  * window's result is a function of its inputs, the options and this number only (the chunk partials are summed in chunk order):

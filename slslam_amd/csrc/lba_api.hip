@@ -214,6 +214,16 @@ struct slslam_lba_batch {
   // graph
   hipGraphExec_t graph_exec = nullptr;
   hipStream_t capture_stream = nullptr;
+  // A batch that mixes oversize windows with ordinary ones is solved as TWO batches side by side: part[0] holds the ordinary
+  // windows (tiled sweeps), part[1] the oversize ones (lba_big.h), the second on a stream of its own between a fork and a join on
+  // the caller's.  This object then only routes: window i of the caller is window route[i].second of part[route[i].first].
+  slslam_lba_batch* part[2] = { nullptr, nullptr };
+  std::vector<std::pair<int, int>> route;
+  std::vector<long long> part_param_off[2];  // per window of a part: where its parameters go in the caller's export layout
+  hipStream_t part_stream = nullptr;
+  hipEvent_t part_fork = nullptr, part_join = nullptr;
+  DevBuf<double> d_part_out[2];
+  int num_windows() const { return part[0] ? (int)route.size() : (int)wins.size(); }
   // profiling
   bool profiling = false;
   double fam_ms[FAM_N] = { 0 };
@@ -269,6 +279,10 @@ extern "C" int slslam_lba_batch_create(int device, slslam_lba_batch** out) {
 extern "C" void slslam_lba_batch_destroy(slslam_lba_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
+  for (int h = 0; h < 2; ++h) if (b->part[h]) { slslam_lba_batch_destroy(b->part[h]); b->part[h] = nullptr; b->d_part_out[h].release(); }
+  if (b->part_stream) { (void)hipStreamSynchronize(b->part_stream); (void)hipStreamDestroy(b->part_stream); }
+  if (b->part_fork) (void)hipEventDestroy(b->part_fork);
+  if (b->part_join) (void)hipEventDestroy(b->part_join);
   b->release();
   delete b;
 }
@@ -283,6 +297,46 @@ extern "C" int slslam_lba_batch_add(slslam_lba_batch* b, const slslam_lba_window
   b->wins.push_back(std::move(pw));
   return SLSLAM_OK;
 }
+
+namespace {
+// A mixed batch: the ordinary windows and the oversize ones become two batches of their own (same device, same options).
+int finalize_mixed(slslam_lba_batch* b) {
+  int rc;
+  for (int h = 0; h < 2; ++h)
+    if ((rc = slslam_lba_batch_create(b->device, &b->part[h])) != SLSLAM_OK) return rc;
+  long long off = 0;
+  b->route.clear();
+  for (PackedWindow& P : b->wins) {
+    const int h = P.big ? 1 : 0;
+    b->route.push_back({ h, (int)b->part[h]->wins.size() });
+    b->part_param_off[h].push_back(off);
+    off += 6LL * P.C + 4LL * P.L;
+    b->part[h]->wins.push_back(std::move(P));
+  }
+  b->total_params = off;
+  b->wins.clear();
+  for (int h = 0; h < 2; ++h) {
+    if ((rc = slslam_lba_batch_finalize(b->part[h], &b->opt)) != SLSLAM_OK) return rc;
+    if ((rc = b->d_part_out[h].alloc((size_t)std::max<long long>(1, b->part[h]->total_params))) != SLSLAM_OK) return rc;
+  }
+  HIP_TRY(hipStreamCreateWithFlags(&b->part_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&b->part_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&b->part_join, hipEventDisableTiming));
+  b->finalized = true;
+  return SLSLAM_OK;
+}
+// the oversize part runs on the batch's own stream, between a fork from and a join to the caller's
+template <typename Fn>
+int on_both_parts(slslam_lba_batch* b, hipStream_t s, Fn fn) {
+  HIP_TRY(hipEventRecord(b->part_fork, s));
+  HIP_TRY(hipStreamWaitEvent(b->part_stream, b->part_fork, 0));
+  int rc = fn(b->part[1], (void*)b->part_stream);
+  if (rc == SLSLAM_OK) rc = fn(b->part[0], (void*)s);
+  HIP_TRY(hipEventRecord(b->part_join, b->part_stream));
+  HIP_TRY(hipStreamWaitEvent(s, b->part_join, 0));
+  return rc;
+}
+}  // namespace
 
 extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solver_options* opt) {
   if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
@@ -309,7 +363,9 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     // issues a v_mfma_f64_16x16x4_f64 every 64 cycles, tools/micro/mfma_f64_bench.hip) but because of its operand path through
     // LDS and its front end
     b->big_mode = false;
-    for (const PackedWindow& P : b->wins) if (P.big) b->big_mode = true;       // one oversize window sends the batch down lba_big.h
+    int nbig = 0;
+    for (const PackedWindow& P : b->wins) if (P.big) { b->big_mode = true; ++nbig; }
+    if (nbig > 0 && nbig < B && !b->opt.reuse_elimination) return finalize_mixed(b);       // oversize windows apart (see `part`)
     if (b->big_mode) { mfma_ok = false; if (b->opt.reuse_elimination) return SLSLAM_ERR_UNSUPPORTED; }
     b->elim_mode = (want >= 2 && mfma_ok) ? 1 : 0;
     b->elim_waves = b->elim_mode == 0 ? 1 : (want == 2 ? 1 : 2);
@@ -823,6 +879,7 @@ extern "C" int slslam_lba_batch_solve(slslam_lba_batch* b, void* stream) {
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
   b->downloaded = false;
+  if (b->part[0]) return on_both_parts(b, s, [](slslam_lba_batch* pb, void* st) { return slslam_lba_batch_solve(pb, st); });
   if (b->profiling) {                                   // times accumulate until set_profiling()
     if (b->ev_next > 16384) b->harvest_events();        // long profiled runs: bounded pool (costs one synchronisation)
     return enqueue_solve(b, s, true);
@@ -855,6 +912,7 @@ extern "C" int slslam_lba_batch_reset(slslam_lba_batch* b, void* stream) {
   if (!b->finalized) return SLSLAM_ERR_STATE;
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
+  if (b->part[0]) { b->downloaded = false; return on_both_parts(b, s, [](slslam_lba_batch* pb, void* st) { return slslam_lba_batch_reset(pb, st); }); }
   const long long total = 6LL * b->ncam + 4LL * b->nline + b->ptrs.nwin;      // one thread per parameter / per window state
   if (total > 0)
     hipLaunchKernelGGL(k_reset, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b->ptrs, b->pol);
@@ -868,6 +926,13 @@ extern "C" int slslam_lba_batch_iterations(slslam_lba_batch* b, void* stream, lo
   if (!b->finalized) return SLSLAM_ERR_STATE;
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
+  if (b->part[0]) {
+    long long a = 0, c = 0;
+    int rc = slslam_lba_batch_iterations(b->part[0], stream, &a, clear);
+    if (rc == SLSLAM_OK) rc = slslam_lba_batch_iterations(b->part[1], stream, &c, clear);
+    *iterations = a + c;
+    return rc;
+  }
   unsigned long long v = 0;
   HIP_TRY(hipMemcpyAsync(&v, b->d_iter_counter.p, sizeof(v), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -881,6 +946,18 @@ extern "C" int slslam_lba_batch_export_device(slslam_lba_batch* b, double* devic
   if (!b->finalized) return SLSLAM_ERR_STATE;
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
+  if (b->part[0]) {                                     // each part exports its windows, which are then put where the caller's order has them
+    for (int h = 0; h < 2; ++h) {
+      const slslam_lba_batch* pb = b->part[h];
+      int rc = slslam_lba_batch_export_device(b->part[h], b->d_part_out[h].p, stream);
+      if (rc != SLSLAM_OK) return rc;
+      for (size_t i = 0; i < pb->h_param_off.size(); ++i) {
+        const long long n = (i + 1 < pb->h_param_off.size() ? pb->h_param_off[i + 1] : pb->total_params) - pb->h_param_off[i];
+        if (n > 0) HIP_TRY(hipMemcpyAsync(device_out + b->part_param_off[h][i], b->d_part_out[h].p + pb->h_param_off[i], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+      }
+    }
+    return SLSLAM_OK;
+  }
   const int total = b->ncam + b->nline;
   if (total > 0)
     hipLaunchKernelGGL(k_export, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b->ptrs,
@@ -894,6 +971,12 @@ extern "C" int slslam_lba_batch_download(slslam_lba_batch* b, void* stream) {
   if (!b->finalized) return SLSLAM_ERR_STATE;
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
+  if (b->part[0]) {
+    int rc0 = slslam_lba_batch_download(b->part[0], stream);
+    if (rc0 == SLSLAM_OK) rc0 = slslam_lba_batch_download(b->part[1], stream);
+    b->downloaded = rc0 == SLSLAM_OK;
+    return rc0;
+  }
   int rc = slslam_lba_batch_export_device(b, b->d_params_out.p, stream);
   if (rc) return rc;
   if (!b->h_params.empty())
@@ -909,7 +992,8 @@ extern "C" int slslam_lba_batch_download(slslam_lba_batch* b, void* stream) {
 }
 
 extern "C" int slslam_lba_batch_get_parameters(const slslam_lba_batch* b, int index, double* parameters) {
-  if (!b || !parameters || index < 0 || index >= (int)b->wins.size()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b || !parameters || index < 0 || index >= b->num_windows()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (b->part[0]) return slslam_lba_batch_get_parameters(b->part[b->route[index].first], b->route[index].second, parameters);
   if (!b->downloaded) return SLSLAM_ERR_STATE;
   const PackedWindow& P = b->wins[index];
   const size_t n = (size_t)6 * P.C + (size_t)4 * P.L;
@@ -920,7 +1004,8 @@ extern "C" int slslam_lba_batch_get_parameters(const slslam_lba_batch* b, int in
 }
 
 extern "C" int slslam_lba_batch_get_summary(const slslam_lba_batch* b, int index, slslam_summary* s) {
-  if (!b || !s || index < 0 || index >= (int)b->wins.size()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b || !s || index < 0 || index >= b->num_windows()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (b->part[0]) return slslam_lba_batch_get_summary(b->part[b->route[index].first], b->route[index].second, s);
   if (!b->downloaded) return SLSLAM_ERR_STATE;
   const LMState& st = b->h_state[index];
   s->num_successful_steps = st.n_success;
@@ -935,7 +1020,8 @@ extern "C" int slslam_lba_batch_get_summary(const slslam_lba_batch* b, int index
 }
 
 extern "C" int slslam_lba_batch_get_trace(const slslam_lba_batch* b, int index, slslam_iteration* trace, int cap, int* len) {
-  if (!b || index < 0 || index >= (int)b->wins.size()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b || index < 0 || index >= b->num_windows()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (b->part[0]) return slslam_lba_batch_get_trace(b->part[b->route[index].first], b->route[index].second, trace, cap, len);
   if (!b->downloaded) return SLSLAM_ERR_STATE;
   const int n = std::min<int>(b->h_state[index].ntrace, kMaxTrace);
   if (len) *len = n;
@@ -954,6 +1040,8 @@ extern "C" int slslam_lba_batch_counts(const slslam_lba_batch* b, long long* nw,
                                        long long* nl, long long* no) {
   if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
   long long w = 0, c = 0, fc = 0, l = 0, o = 0;
+  for (int h = 0; h < 2; ++h)
+    if (b->part[h]) for (const PackedWindow& P : b->part[h]->wins) { ++w; c += P.C; fc += P.Cf; l += P.L; o += P.M; }
   for (const PackedWindow& P : b->wins) { ++w; c += P.C; fc += P.Cf; l += P.L; o += P.M; }
   if (nw) *nw = w; if (nc) *nc = c; if (nfc) *nfc = fc; if (nl) *nl = l; if (no) *no = o;
   return SLSLAM_OK;
@@ -961,12 +1049,14 @@ extern "C" int slslam_lba_batch_counts(const slslam_lba_batch* b, long long* nw,
 
 extern "C" int slslam_lba_batch_path(const slslam_lba_batch* b, int* path) {
   if (!b || !path || !b->finalized) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (b->part[0]) { *path = SLSLAM_PATH_MIXED; return SLSLAM_OK; }
   *path = b->big_mode ? SLSLAM_PATH_GLOBAL_MEMORY : b->fused_motion_only ? SLSLAM_PATH_FUSED_MOTION_ONLY : SLSLAM_PATH_TILED;
   return SLSLAM_OK;
 }
 
 extern "C" int slslam_lba_batch_window_chunks(const slslam_lba_batch* b, int index, int* num_chunks) {
-  if (!b || !num_chunks || !b->finalized || index < 0 || index >= (int)b->h_wins.size()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b || !num_chunks || !b->finalized || index < 0 || index >= b->num_windows()) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (b->part[0]) return slslam_lba_batch_window_chunks(b->part[b->route[index].first], b->route[index].second, num_chunks);
   *num_chunks = b->h_wins[index].nchunks;
   return SLSLAM_OK;
 }
@@ -975,6 +1065,7 @@ extern "C" int slslam_lba_batch_window_chunks(const slslam_lba_batch* b, int ind
 // matrix-core sweep, summed over all waves; out[16].
 extern "C" int slslam_debug_phase_cycles(slslam_lba_batch* b, double* out) {
   if (!b || !out || !b->finalized) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (b->part[0]) return slslam_debug_phase_cycles(b->part[0], out);
   const size_t n = std::max((size_t)32 * std::max(1, b->nchunk), (size_t)16 * std::max<size_t>(1, b->wins.size()));
   if (!b->pol.debug_flags) return SLSLAM_ERR_STATE;
   std::vector<unsigned long long> h(n);
@@ -988,6 +1079,7 @@ extern "C" int slslam_debug_phase_cycles(slslam_lba_batch* b, double* out) {
 
 extern "C" int slslam_lba_batch_set_profiling(slslam_lba_batch* b, int enable) {
   if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
+  for (int h = 0; h < 2; ++h) if (b->part[h]) (void)slslam_lba_batch_set_profiling(b->part[h], enable);
   b->profiling = enable != 0;
   b->ev_used.clear(); b->ev_next = 0;                   // the events themselves are kept for reuse
   for (int f = 0; f < FAM_N; ++f) { b->fam_ms[f] = 0.0; b->fam_launches[f] = 0; }
@@ -997,13 +1089,16 @@ extern "C" int slslam_lba_batch_set_profiling(slslam_lba_batch* b, int enable) {
 extern "C" int slslam_lba_batch_kernel_times(const slslam_lba_batch* b, double ms[8], int launches[8]) {
   if (!b || !ms || !launches) return SLSLAM_ERR_INVALID_ARGUMENT;
   for (int f = 0; f < FAM_N; ++f) { ms[f] = b->fam_ms[f]; launches[f] = b->fam_launches[f]; }
+  for (int h = 0; h < 2; ++h)
+    if (b->part[h]) for (int f = 0; f < FAM_N; ++f) { ms[f] += b->part[h]->fam_ms[f]; launches[f] += b->part[h]->fam_launches[f]; }
   return SLSLAM_OK;
 }
 
 extern "C" int slslam_lba_batch_linearise(slslam_lba_batch* b, int index, double* residuals, double* j_cam,
                                           double* j_line, double* cost) {
-  if (!b || index < 0 || index >= (int)b->wins.size() || !residuals || !j_cam || !j_line || !cost) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b || index < 0 || index >= b->num_windows() || !residuals || !j_cam || !j_line || !cost) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (!b->finalized) return SLSLAM_ERR_STATE;
+  if (b->part[0]) return slslam_lba_batch_linearise(b->part[b->route[index].first], b->route[index].second, residuals, j_cam, j_line, cost);
   HIP_TRY(hipSetDevice(b->device));
   const PackedWindow& P = b->wins[index];
   const size_t M = (size_t)P.M;

@@ -895,7 +895,9 @@ __device__ __forceinline__ unsigned long long solve_clock() {
 __global__ __launch_bounds__(256) void k_slab_reduce(BatchPtrs p) {
   const int w = blockIdx.x;
   const WinDesc wd = p.wins[w];
-  if (p.state[w].status != kRunning || wd.nchunks <= 0) return;
+  // (a window of at most 8 chunks is summed by its reduced solve itself, as in a batch without this launch: what a window's
+  // result depends on is its own chunk count, not the company it keeps)
+  if (p.state[w].status != kRunning || wd.nchunks <= 8) return;
   const int nsys = p.elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n);
   const long long sstride = (long long)nsys + kSlabScalars;
   const int q = blockIdx.y * 256 + threadIdx.x;
@@ -944,7 +946,7 @@ __global__ __launch_bounds__(256, 4) void k_reduced_solve(BatchPtrs p, Policy po
   // ---- 1. ordered reduction over the window's chunk partials (uniform stride between consecutive slabs)
   const bool mfma_slab = p.elim_mode == 1;          // slab layout of lba_eliminate_mfma.h
   const int nsys_slab = mfma_slab ? kMfmaTiles * 256 + ncf * kMfmaRec : nsys;
-  const bool presummed = p.slab_sum != nullptr && wd.nchunks > 0;       // k_slab_reduce ran: one partial per window
+  const bool presummed = p.slab_sum != nullptr && wd.nchunks > 8;       // k_slab_reduce ran for this window: one partial
   const double* slab_base = presummed ? p.slab_sum : p.slab;
   const long long slab0 = presummed ? (long long)w * p.slab_sum_stride : (wd.nchunks > 0 ? p.chunks[wd.chunk_off].slab_off : 0);
   const long long sstride = (long long)nsys_slab + kSlabScalars;
@@ -1895,6 +1897,18 @@ __global__ __launch_bounds__(64) void k_lm_update_wave(BatchPtrs p, Policy pol) 
   const WinDesc wd = p.wins[w];
   LMState* st = p.state + w;
   if (st->status != kRunning) return;
+  if (wd.nchunks <= 8) {                                  // the sums of k_lm_update, in its order (see k_slab_reduce)
+    if (lane == 0) {
+      double new_cost = 0.0, model = st->cam_model, dn2 = st->cam_dn2, xn2 = st->cam_xn2;
+      for (int c = 0; c < wd.nchunks; ++c) {
+        new_cost += p.cost_part[wd.chunk_off + c];
+        const double* bp = p.bs_part + (long long)(wd.chunk_off + c) * kBsStride;
+        model += bp[kBsModel]; dn2 += bp[kBsDn2]; xn2 += bp[kBsXn2];
+      }
+      lm_step(p, pol, w, st, new_cost, model, dn2, xn2);
+    }
+    return;
+  }
   double new_cost = 0.0, model = 0.0, dn2 = 0.0, xn2 = 0.0;
   for (int c = lane; c < wd.nchunks; c += 64) {
     new_cost += p.cost_part[wd.chunk_off + c];

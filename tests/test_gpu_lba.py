@@ -141,14 +141,39 @@ def test_windows_beyond_the_tiled_sweeps(hip, oracle):
         _assert_params_parity(w, x0, x1)
         x2, s2, t2 = hip.lba_solve(w)                       # gather sums in list order: bitwise reproducible (round 2: atomics)
         assert np.array_equal(x1, x2) and s1 == s2 and t1 == t2
-    # a batch that mixes an oversize window with ordinary ones goes down the same path as a whole - and says so
+    # a batch that mixes oversize windows with ordinary ones is solved as two batches side by side - the ordinary windows keep the
+    # tiled sweeps - and says so; every window's result is what it is in a batch of its own, bit for bit
     b = hip.LBABatch()
-    mix = [ws[0], synth.make_window(35, num_lines=120), synth.make_motion_only(6, num_lines=30)]
+    mix = [ws[0], synth.make_window(35, num_lines=120), synth.make_motion_only(6, num_lines=30), ws[2], synth.make_window(38, num_lines=300)]
     for w in mix:
         b.add(w)
     b.finalize(); b.solve(); b.download()
-    assert b.path() == 2                                     # SLSLAM_PATH_GLOBAL_MEMORY
+    assert b.path() == 3                                     # SLSLAM_PATH_MIXED
     first = [b.parameters(i).copy() for i in range(len(mix))]
+    # (device buffer through the HIP runtime the library itself is linked to)
+    import ctypes
+    rt = ctypes.CDLL("libamdhip64.so")
+    nbytes = 8 * b.total_parameters()
+    dptr = ctypes.c_void_p()
+    assert rt.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(nbytes)) == 0
+    b.export_device(dptr.value)
+    flat = np.zeros(b.total_parameters())
+    assert rt.hipDeviceSynchronize() == 0
+    assert rt.hipMemcpy(flat.ctypes.data_as(ctypes.c_void_p), dptr, ctypes.c_size_t(nbytes), 2) == 0      # hipMemcpyDeviceToHost
+    assert rt.hipFree(dptr) == 0
+    off = 0
+    for i, w in enumerate(mix):
+        n = len(w["parameters"])
+        assert np.array_equal(flat[off:off + n], first[i])       # the device export keeps the caller's order
+        off += n
+        alone = hip.LBABatch(); alone.add(w); alone.finalize(chunks_per_window=b.window_chunks(i)); alone.solve(); alone.download()
+        if alone.path() == 1:                                   # a motion-only problem alone takes its one-launch kernel: other sums
+            assert np.abs(alone.parameters(0) - first[i]).max() < 1e-9, i
+        else:
+            assert np.array_equal(alone.parameters(0), first[i]), i
+            assert alone.summary(0) == b.summary(i) and alone.trace(0) == b.trace(i), i
+        alone.close()
+    assert b.counts()["windows"] == len(mix)
     for i, w in enumerate(mix):
         xo, so, to = oracle.lba_solve(w, linear_solver=1)
         _assert_params_parity(w, xo, first[i])
