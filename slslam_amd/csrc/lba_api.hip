@@ -679,8 +679,10 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
   }
-  if (b->lds_solve > 48 * 1024 && !b->big_mode)
-    HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
+  if (b->lds_solve > 48 * 1024 && !b->big_mode) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
+  }
   b->h_state.assign(B, LMState());
   b->h_trace.assign((size_t)B * kMaxTrace, IterRec());
   b->h_params.assign((size_t)param_off, 0.0);
@@ -854,7 +856,8 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     }
     if (b->slab_sum_stride)
       LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)B, (unsigned)((b->slab_sum_stride + 255) / 256)), blk256, 0, s, p));   // windows on grid.x (no 65535 limit)
-    LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve, g_win, blk256, b->lds_solve, s, p, pol));
+    if (B <= b->num_cus) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve<1>, g_win, blk256, b->lds_solve, s, p, pol));
+    else LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve<4>, g_win, blk256, b->lds_solve, s, p, pol));
     if (b->nchunk > 0) {
       if (pol.store_f) LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub_stream, g_chunk, blk64, b->lds_bs_stream, s, p, pol));
       else LAUNCH(FAM_BACKSUB, hipLaunchKernelGGL(k_backsub, g_chunk, dim3(64 * b->elim_waves), b->lds_bs, s, p, pol));

@@ -915,8 +915,11 @@ __global__ __launch_bounds__(256) void k_slab_reduce(BatchPtrs p) {
   p.slab_sum[(long long)w * p.slab_sum_stride + q] = s;
 }
 
-// (four workgroups per CU - the LDS limit - need <= 128 registers: the whole 1024-window batch is resident in one round)
-__global__ __launch_bounds__(256, 4) void k_reduced_solve(BatchPtrs p, Policy pol) {
+// RESIDENT = 4: four workgroups per CU - the LDS limit - need <= 128 registers: the whole 1024-window batch is resident in one
+// round.  RESIDENT = 1: a batch of at most one window per CU (the reference's call protocol: one window) has the CU to itself and
+// the tile factorisation on its critical path gets the registers it wants (no scratch).
+template <int RESIDENT>
+__global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = blockIdx.x;
@@ -1250,8 +1253,8 @@ __global__ __launch_bounds__(256, 4) void k_reduced_solve(BatchPtrs p, Policy po
     double* D = A + (16 * kb) * ld + 16 * kb;   // diagonal tile
     // (a)+(b) diagonal tile in the registers of wave 0 (dense_tile.h): L into the tile's lower triangle, L^-1 strictly
     // lower part transposed into the tile's upper triangle, its diagonal into ivec
-    if (wave == 0)
-      diag_tile_factor<double>(D, ld, lane, fail, [&](int r, int c, double v) {
+    if (wave == 0)                                // (L of the diagonal tile itself is never read again: only its inverse is kept)
+      diag_tile_factor<double, false>(D, ld, lane, fail, [&](int r, int c, double v) {
         if (c < r) D[c * ld + r] = v; else ivec[16 * kb + r] = v;
       });
     __syncthreads();
@@ -1306,11 +1309,14 @@ __global__ __launch_bounds__(256, 4) void k_reduced_solve(BatchPtrs p, Policy po
       if (ec == 0) tvec[er] = bvec[16 * kb + er] - sacc;
     }
     __syncthreads();
-    if (tid < 16) {
+    {
+      // y = Linv t, one product per thread (row er, column ec), summed over the 16 lanes of the row (was: 16 threads walking
+      // their rows one element after the other)
       const double* Dk = A + (16 * kb) * ld + 16 * kb;
-      double sacc = ivec[16 * kb + tid] * tvec[tid];
-      for (int k = 0; k < tid; ++k) sacc += Dk[k * ld + tid] * tvec[k];          // Linv[tid][k]
-      yvec[16 * kb + tid] = sacc;
+      const double li = ec < er ? Dk[ec * ld + er] : (ec == er ? ivec[16 * kb + er] : 0.0);      // Linv[er][ec]
+      double sacc = li * tvec[ec];
+      sacc += dpp_move<0xB1>(sacc); sacc += dpp_move<0x4E>(sacc); sacc += dpp_move<0x141>(sacc); sacc += dpp_move<0x140>(sacc);
+      if (ec == 0) yvec[16 * kb + er] = sacc;
     }
     __syncthreads();
   }
@@ -1324,11 +1330,12 @@ __global__ __launch_bounds__(256, 4) void k_reduced_solve(BatchPtrs p, Policy po
       if (ec == 0) tvec[er] = yvec[16 * kb + er] - sacc;
     }
     __syncthreads();
-    if (tid < 16) {
-      const double* Dk = A + (16 * kb) * ld + 16 * kb;
-      double sacc = ivec[16 * kb + tid] * tvec[tid];
-      for (int k = tid + 1; k < 16; ++k) sacc += Dk[tid * ld + k] * tvec[k];     // Linv[k][tid]
-      yvec[16 * kb + tid] = sacc;
+    {
+      const double* Dk = A + (16 * kb) * ld + 16 * kb;                                            // x = Linv^T t: Linv[ec][er]
+      const double li = ec > er ? Dk[er * ld + ec] : (ec == er ? ivec[16 * kb + er] : 0.0);
+      double sacc = li * tvec[ec];
+      sacc += dpp_move<0xB1>(sacc); sacc += dpp_move<0x4E>(sacc); sacc += dpp_move<0x141>(sacc); sacc += dpp_move<0x140>(sacc);
+      if (ec == 0) yvec[16 * kb + er] = sacc;
     }
     __syncthreads();
   }

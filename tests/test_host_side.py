@@ -553,4 +553,5 @@ def test_sweep_kernels_keep_their_occupancy(tmp_path):
     for frag in ("17k_linearise_schurILb0ELi1E", "17k_linearise_schurILb0ELi0E", "17k_linearise_schurILb0ELin1E", "9k_backsubE"):
         st = find(frag)
         assert st["Occupancy"] == 2 and st["ScratchSize"] == 0 and st["TotalNumVgprs"] <= 256, (frag, st)
-    assert find("15k_reduced_solveE")["Occupancy"] >= 4          # four workgroups per CU: the whole bench batch resident in one round
+    assert find("15k_reduced_solveILi4E")["Occupancy"] >= 4      # four workgroups per CU: the whole bench batch resident in one round
+    assert find("15k_reduced_solveILi1E")["ScratchSize"] == 0    # the one-window-per-CU form: the tile factorisation stays in registers
