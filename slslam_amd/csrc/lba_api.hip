@@ -201,6 +201,7 @@ struct slslam_lba_batch {
   DevBuf<long long> d_big_sys_off;
   DevBuf<double> d_slab_sum;
   long long slab_sum_stride = 0;           // > 0: k_slab_reduce runs ahead of the reduced solve
+  bool slab_sum_image = false;             // ... and writes the LDS image of the reduced solve (BatchPtrs.slab_sum_image)
   int line_elim_stride = kLineElim;
   DevBuf<double> d_slab, d_bs_part, d_cost_part, d_ysys, d_params_out, d_fstore, d_line_elim;
   DevBuf<LMState> d_state; DevBuf<IterRec> d_trace; DevBuf<long long> d_param_off;
@@ -524,6 +525,15 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
       max_sys = std::max(max_sys, b->elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n));
     }
     b->slab_sum_stride = (max_chunks > 8 && !b->opt.reuse_elimination && !b->big_mode) ? (long long)max_sys + kSlabScalars : 0;
+    // default sweeps: the sums go straight into the LDS image of the reduced solve (zeros where nothing is mapped: written
+    // once, here)
+    b->slab_sum_image = b->slab_sum_stride && b->elim_mode == 0;
+    if (b->slab_sum_image) {
+      long long ext = 0;
+      for (const WinDesc& wd : b->h_wins) { const int N = solve_pad(wd.n); ext = std::max<long long>(ext, (long long)N * solve_stride(wd.n) + 6LL * N); }
+      b->slab_sum_stride = ((ext + kSlabScalars + 1) / 2) * 2;
+      ar.zeroed(b->d_slab_sum, (size_t)b->slab_sum_stride * (size_t)B);
+    } else
     ar.scratch(b->d_slab_sum, b->slab_sum_stride ? (size_t)b->slab_sum_stride * (size_t)B : 1);
   }
   ar.scratch(b->d_bs_part, std::max<size_t>(1, (size_t)b->nchunk * kBsStride));
@@ -638,7 +648,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.line_x = b->d_line_x.p; p.line_scale = b->d_line_scale.p; p.line_ptr = b->d_line_ptr.p;
   p.line_flags = b->d_line_flags.p; p.line_win = b->d_line_win.p;
   p.ob = b->d_ob.p; p.ob_cam = b->d_ob_cam.p; p.ob_stride = std::max<long long>(1, nobs);
-  p.slab_sum = b->slab_sum_stride ? b->d_slab_sum.p : nullptr; p.slab_sum_stride = b->slab_sum_stride;
+  p.slab_sum = b->slab_sum_stride ? b->d_slab_sum.p : nullptr; p.slab_sum_stride = b->slab_sum_stride; p.slab_sum_image = b->slab_sum_image ? 1 : 0;
   p.slab = b->d_slab.p; p.bs_part = b->d_bs_part.p; p.cost_part = b->d_cost_part.p; p.ysys = b->d_ysys.p;
   p.fstore = b->d_fstore.p; p.line_elim = b->d_line_elim.p; p.line_elim_stride = b->line_elim_stride;
   p.state = b->d_state.p; p.trace = b->d_trace.p;

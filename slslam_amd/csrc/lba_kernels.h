@@ -912,6 +912,18 @@ __global__ __launch_bounds__(256) void k_slab_reduce(BatchPtrs p) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) s = is_max ? fmax(s, v[u]) : s + v[u];
   }
+  if (p.slab_sum_image) {
+    // straight into the layout the reduced solve keeps in LDS: its first phase was a chain of dependent global reads (partials,
+    // then the map, then the scalars: ~2 us each for a window alone on the chip) and is now one sweep of independent loads
+    const int N = solve_pad(wd.n), ext = N * solve_stride(wd.n) + 6 * N;
+    double* img = p.slab_sum + (long long)w * p.slab_sum_stride;
+    if (q >= nsys) img[ext + (q - nsys)] = s;
+    else {
+      const unsigned off = (p.sys_map + wd.map_off)[q];
+      if (off != 0xFFFFu) img[off] = s;
+    }
+    return;
+  }
   p.slab_sum[(long long)w * p.slab_sum_stride + q] = s;
 }
 
@@ -943,15 +955,22 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
   const bool timing = (pol.debug_flags & 512) && p.dbg_cycles;
   unsigned long long tlast_ = timing ? solve_clock() : 0ull;
 
-  for (int q = tid; q < N * ld; q += 256) A[q] = 0.0;
-  for (int q = tid; q < 6 * N; q += 256) bvec[q] = 0.0;
-  __syncthreads();
   // ---- 1. ordered reduction over the window's chunk partials (uniform stride between consecutive slabs)
   const bool mfma_slab = p.elim_mode == 1;          // slab layout of lba_eliminate_mfma.h
-  const int nsys_slab = mfma_slab ? kMfmaTiles * 256 + ncf * kMfmaRec : nsys;
   const bool presummed = p.slab_sum != nullptr && wd.nchunks > 8;       // k_slab_reduce ran for this window: one partial
+  const bool image = presummed && p.slab_sum_image;                      // ... already in the layout of this kernel's LDS
+  const int nsys_slab = mfma_slab ? kMfmaTiles * 256 + ncf * kMfmaRec : image ? N * ld + 6 * N : nsys;
   const double* slab_base = presummed ? p.slab_sum : p.slab;
   const long long slab0 = presummed ? (long long)w * p.slab_sum_stride : (wd.nchunks > 0 ? p.chunks[wd.chunk_off].slab_off : 0);
+  if (image) {
+    const double2* src = reinterpret_cast<const double2*>(slab_base + slab0);
+    double2* dst = reinterpret_cast<double2*>(smem);
+    for (int q = tid; q < (N * ld + 6 * N) / 2; q += 256) dst[q] = src[q];
+  } else {
+    for (int q = tid; q < N * ld; q += 256) A[q] = 0.0;
+    for (int q = tid; q < 6 * N; q += 256) bvec[q] = 0.0;
+  }
+  __syncthreads();
   const long long sstride = (long long)nsys_slab + kSlabScalars;
   const int nchunks = presummed ? 1 : wd.nchunks;
   const unsigned short* smap = p.sys_map + wd.map_off;
@@ -1080,7 +1099,7 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
         bvec[q] *= sc; gvec[q] *= sc; hvec[q] *= sc * sc;
       }
     }
-  } else {
+  } else if (!image) {
   // eight entries of this thread at a time: the loads of an entry's partials (up to 8 chunks per round) of all eight are
   // in flight together; per entry the partials are added in chunk order, so the result does not depend on the grouping
   for (int q0 = tid; q0 < nsys; q0 += 8 * 256) {

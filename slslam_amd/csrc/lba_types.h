@@ -132,6 +132,7 @@ struct BatchPtrs {
   double* slab;               // linearise/Schur partials
   double* slab_sum;           // [nwin][slab_sum_stride] per-window sum of the chunk partials (k_slab_reduce), nullptr when unused
   long long slab_sum_stride;
+  int slab_sum_image;         // 1: slab_sum holds, per window, the LDS image of the reduced solve (A | b | g | hdiag scattered by sys_map, zeros elsewhere, the scalars behind it) - the solve copies it in one sweep of loads (default sweeps); 0: the slab layout
   const unsigned short* sys_map;   // per distinct n: chunk-partial entry -> place in the reduced solve's LDS image (WinDesc.map_off)
   double* bs_part;            // [nchunk][kBsStride]
   double* cost_part;          // [nchunk]
