@@ -567,10 +567,21 @@ __host__ __device__ inline int lds_doubles_linearise(int C, int n) {
 // FRESH: 1 = the first sweep of a solve (it is also Ceres' initial evaluation: every window of the launch is fresh), 0 = any later
 // sweep (none is), -1 = read LMState.fresh.  The host knows which launch is which; the two compile-time forms keep the first
 // sweep's extras (unit scales, line Jacobi scale, fixed cost, |x|) out of the steady sweep's registers.
+// Timing experiment (build with -DSLSLAM_K1_TIMING=1 and run with SLSLAM_DEBUG_ABLATE != 0: tools/k1_phases.py): shader-clock stamps
+// of one chunk's sweep, summed over chunks into dbg_cycles[chunk * 32 + i]
+#if defined(SLSLAM_K1_TIMING) && SLSLAM_K1_TIMING
+#define SLS_K1_STAMP(i) do { unsigned long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+    if (lane == 0 && p.dbg_cycles) p.dbg_cycles[(long long)blockIdx.x * 32 + (i)] += now_ - k1_t_; k1_t_ = now_; } while (0)
+#define SLS_K1_STAMP_INIT unsigned long long k1_t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(k1_t_) :: "memory")
+#else
+#define SLS_K1_STAMP(i) do { } while (0)
+#define SLS_K1_STAMP_INIT do { } while (0)
+#endif
 template <bool INIT, int FRESH = -1>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearise_schur(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
+  SLS_K1_STAMP_INIT;
   const Chunk ck = p.chunks[blockIdx.x];
   const WinDesc wd = p.wins[ck.win];
   const LMState* st = p.state + ck.win;
@@ -589,12 +600,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   load_cam_table<true>(p, wd, cur, lane, camtab, camscale, camcf, INIT || fresh);
   for (int q = lane; q < nsys; q += 64) S[q] = 0.0;
   __syncthreads();
+  SLS_K1_STAMP(0);
 
   double acc_cost = 0.0, acc_fixed = 0.0, acc_gmax = 0.0, acc_xn2 = 0.0;
   int fail = 0;
   TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
   ObsPref pfn;
   prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
+#if defined(SLSLAM_K1_TIMING) && SLSLAM_K1_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  SLS_K1_STAMP(1);
   for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
     SLS_PHASE("tile_head");
     const TileCtx tc = nxt;
@@ -801,22 +817,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
   }
   SLS_PHASE("epilogue");
+  SLS_K1_STAMP(2);
 
   __syncthreads();
   double* slab = p.slab + ck.slab_off;
-  for (int q = lane; q < nsys; q += 64) {
-    // after a rejected step the gradient / column-norm entries of the camera records were not accumulated: keep the slab's
-    if (same_point && q < ncf * kCamAcc && (q % kCamAcc) >= kRecG) continue;
-    slab[q] = S[q];
+  // (four entries per lane and round: the LDS reads of a round are in flight together; the test for the entries a rejected step
+  // must not overwrite is taken out of the common case - it was most of the instructions of this loop, 2.5 us of a window's 20 us
+  // sweep when its chunk is one tile)
+  if (!same_point) {
+    for (int q0 = lane; q0 < nsys; q0 += 256) {
+      double v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = S[q0 + 64 * e < nsys ? q0 + 64 * e : 0];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (q0 + 64 * e < nsys) slab[q0 + 64 * e] = v[e];
+    }
+  } else {
+    for (int q = lane; q < nsys; q += 64) {
+      // after a rejected step the gradient / column-norm entries of the camera records were not accumulated: keep the slab's
+      if (q < ncf * kCamAcc && (q % kCamAcc) >= kRecG) continue;
+      slab[q] = S[q];
+    }
   }
+  SLS_K1_STAMP(3);
   const double c_sum = wave_sum(acc_cost), f_sum = wave_sum(acc_fixed), x_sum = wave_sum(acc_xn2);
   const double g_max = wave_max(acc_gmax);
   const int any_fail = __any(fail);
+  SLS_K1_STAMP(4);
   if (lane == 0) {
     double* sc = slab + nsys;
     sc[kScCost] = c_sum; sc[kScFixedCost] = f_sum; sc[kScGradMaxLine] = g_max; sc[kScXn2Line] = x_sum;
     sc[kScFail] = any_fail ? 1.0 : 0.0;
   }
+  SLS_K1_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------
