@@ -597,7 +597,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double* S = camscale + (n > 0 ? n : 6);
   signed char* camcf = (signed char*)(S + nsys);
   const bool fresh = !INIT && (FRESH < 0 ? st->fresh != 0 : FRESH == 1);   // this sweep is also the initial evaluation: see below
+  SLS_K1_STAMP(6);
   load_cam_table<true>(p, wd, cur, lane, camtab, camscale, camcf, INIT || fresh);
+  SLS_K1_STAMP(7);
   for (int q = lane; q < nsys; q += 64) S[q] = 0.0;
   __syncthreads();
   SLS_K1_STAMP(0);
@@ -1517,6 +1519,7 @@ __device__ __forceinline__ void line_trig_step(const double trig0[7], const doub
 __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  SLS_K1_STAMP_INIT;
   const Chunk ck = p.chunks[blockIdx.x];
   const WinDesc wd = p.wins[ck.win];
   const LMState* st = p.state + ck.win;
@@ -1557,11 +1560,16 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     ct[9] = xc[3]; ct[10] = xc[4]; ct[11] = xc[5];
   }
   __syncthreads();
+  SLS_K1_STAMP(8);
 
   double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0, acc_cost = 0.0;
   TileCtx nxt = fetch_tile(p, ck.tile_begin + wave, ck.tile_end, lane);
   ObsPref pfn;
   prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
+#if defined(SLSLAM_K1_TIMING) && SLSLAM_K1_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  SLS_K1_STAMP(9);
   for (int t = ck.tile_begin + wave; t < ck.tile_end; t += nw) {
     SLS_PHASE("bs_tile_head");
     const TileCtx tc = nxt;
@@ -1658,6 +1666,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     }
   }
   SLS_PHASE("epilogue");
+  SLS_K1_STAMP(10);
   const double m = wave_sum(acc_model), d = wave_sum(acc_dn2), x = wave_sum(acc_xn2), cs = wave_sum(acc_cost);
   if (nw > 1) {
     if (lane == 0) { red[4 * wave] = m; red[4 * wave + 1] = d; red[4 * wave + 2] = x; red[4 * wave + 3] = cs; }
@@ -1672,6 +1681,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     bp[kBsModel] = m; bp[kBsDn2] = d; bp[kBsXn2] = x;
     p.cost_part[blockIdx.x] = cs;
   }
+  SLS_K1_STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------
