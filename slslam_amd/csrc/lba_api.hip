@@ -189,7 +189,7 @@ struct slslam_lba_batch {
   size_t lds_elim = 0;
   DevBuf<unsigned long long> d_iter_counter;
   DevBuf<unsigned int> d_active;
-  DevBuf<double> d_cam_x, d_cam_x0, d_cam_scale; DevBuf<int> d_cam_cf, d_cam_win;
+  DevBuf<double> d_cam_x, d_cam_x0, d_cam_scale, d_cam_tab; DevBuf<int> d_cam_cf, d_cam_win;
   DevBuf<double> d_line_x, d_line_x0, d_line_scale; DevBuf<int> d_line_ptr, d_line_flags, d_line_win, d_line_orig;
   DevBuf<double> d_ob; DevBuf<int> d_ob_cam, d_ob_orig;
   // windows beyond the tiled sweeps (lba_big.h)
@@ -245,7 +245,7 @@ struct slslam_lba_batch {
 
   void release() {
     d_sys_map.release(); d_wins.release(); d_tiles.release(); d_chunks.release(); d_items.release(); d_lane_map.release(); d_line_desc.release(); d_dbg_cycles.release();
-    d_cam_x.release(); d_cam_x0.release(); d_cam_scale.release(); d_cam_cf.release(); d_cam_win.release();
+    d_cam_x.release(); d_cam_x0.release(); d_cam_scale.release(); d_cam_tab.release(); d_cam_cf.release(); d_cam_win.release();
     d_line_x.release(); d_line_x0.release(); d_line_scale.release(); d_line_ptr.release(); d_line_flags.release();
     d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release();
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
@@ -491,6 +491,10 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if (cam_x0.empty()) cam_x0.assign(6, 0.0);
   ar.upload(b->d_cam_x0, cam_x0);
   ar.zeroed(b->d_cam_scale, std::max<size_t>(6, (size_t)6 * ncam));
+  // rotation / Jacobian tables of both pose buffers, shared by the chunks of a window (BatchPtrs.cam_tab); the default sweeps only:
+  // the other paths (reuse_elimination, streamed F, matrix-core sweep) keep building their tables per sweep
+  const bool share_cam_tab = !b->big_mode && !b->fused_motion_only && b->elim_mode == 0 && !b->opt.reuse_elimination && !b->pol.store_f && b->opt.max_num_iterations > 0 && !(b->pol.debug_flags & 16384);
+  ar.zeroed(b->d_cam_tab, share_cam_tab ? std::max<size_t>(1, (size_t)2 * kCamTab * ncam) : 1);
   if (cam_cf.empty()) { cam_cf.push_back(-1); cam_win.push_back(0); }
   ar.upload(b->d_cam_cf, cam_cf);
   ar.upload(b->d_cam_win, cam_win);
@@ -645,6 +649,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   BatchPtrs& p = b->ptrs;
   p.wins = b->d_wins.p; p.tiles = b->d_tiles.p; p.chunks = b->d_chunks.p; p.items = b->d_items.p; p.lane_map = b->d_lane_map.p;
   p.cam_x = b->d_cam_x.p; p.cam_scale = b->d_cam_scale.p; p.cam_cf = b->d_cam_cf.p;
+  p.cam_tab = share_cam_tab ? b->d_cam_tab.p : nullptr;
   p.line_x = b->d_line_x.p; p.line_scale = b->d_line_scale.p; p.line_ptr = b->d_line_ptr.p;
   p.line_flags = b->d_line_flags.p; p.line_win = b->d_line_win.p;
   p.ob = b->d_ob.p; p.ob_cam = b->d_ob_cam.p; p.ob_stride = std::max<long long>(1, nobs);

@@ -535,17 +535,27 @@ __device__ __forceinline__ void lane_F(const LaneLin& L, const double K[10], dou
 }
 
 // Camera table of one window in LDS.  WITH_JAC: R and JL at buffer `buf`; else R only.
+// mode 0: built here (three trig calls per camera).  With BatchPtrs.cam_tab: mode 1 builds it and leaves a copy in memory (the
+// first sweep of a solve), mode 2 reads the copy (every later sweep: the reduced solve left the candidate point's table in the
+// other buffer, which the accepted point is if the step was taken) - for a window alone on the chip, whose chunks are one tile
+// each, building the tables was 12 k of an iteration's 155 k cycles.
 template <bool WITH_JAC>
 __device__ __forceinline__ void load_cam_table(const BatchPtrs& p, const WinDesc& wd, int buf, int lane,
-                                               double* camtab, double* camscale, signed char* camcf, bool unit_scale) {
+                                               double* camtab, double* camscale, signed char* camcf, bool unit_scale, int mode = 0) {
   for (int c = lane; c < wd.C; c += 64) {
-    const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + buf) * kCamRec;
-    double w[3] = { x[0], x[1], x[2] }, R[9], JL[9];
-    if (WITH_JAC) cam_prepare<double>(w, R, JL);
-    else { cam_rotation<double>(w, R); for (int q = 0; q < 9; ++q) JL[q] = 0.0; }
     double* ct = camtab + c * kCamTab;
-    for (int q = 0; q < 9; ++q) { ct[q] = R[q]; ct[9 + q] = JL[q]; }
-    ct[18] = x[3]; ct[19] = x[4]; ct[20] = x[5];
+    double* gt = mode ? p.cam_tab + ((long long)(wd.cam_off + c) * 2 + buf) * kCamTab : nullptr;
+    if (mode == 2) {
+      for (int q = 0; q < kCamTab; ++q) ct[q] = gt[q];
+    } else {
+      const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + buf) * kCamRec;
+      double w[3] = { x[0], x[1], x[2] }, R[9], JL[9];
+      if (WITH_JAC) cam_prepare<double>(w, R, JL);
+      else { cam_rotation<double>(w, R); for (int q = 0; q < 9; ++q) JL[q] = 0.0; }
+      for (int q = 0; q < 9; ++q) { ct[q] = R[q]; ct[9 + q] = JL[q]; }
+      ct[18] = x[3]; ct[19] = x[4]; ct[20] = x[5];
+      if (mode == 1) for (int q = 0; q < kCamTab; ++q) gt[q] = ct[q];
+    }
     const int cf = p.cam_cf[wd.cam_off + c];
     if (cf >= 0)
       for (int a = 0; a < 6; ++a) camscale[6 * cf + a] = unit_scale ? 1.0 : p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   signed char* camcf = (signed char*)(S + nsys);
   const bool fresh = !INIT && (FRESH < 0 ? st->fresh != 0 : FRESH == 1);   // this sweep is also the initial evaluation: see below
   SLS_K1_STAMP(6);
-  load_cam_table<true>(p, wd, cur, lane, camtab, camscale, camcf, INIT || fresh);
+  load_cam_table<true>(p, wd, cur, lane, camtab, camscale, camcf, INIT || fresh, p.cam_tab ? ((INIT || fresh) ? 1 : 2) : 0);
   SLS_K1_STAMP(7);
   for (int q = lane; q < nsys; q += 64) S[q] = 0.0;
   __syncthreads();
@@ -1395,7 +1405,29 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
   }
 
   SLS_SOLVE_STAMP(7);
-  // ---- 5. step statistics of the camera block and candidate camera poses (wave 0)
+  // ---- 5. step statistics of the camera block and candidate camera poses (wave 0); next to it, wave 1: the candidate poses'
+  // rotation / Jacobian table for the sweeps that follow (BatchPtrs.cam_tab)
+  if (wave == 1 && p.cam_tab) {
+    for (int c = lane; c < wd.C; c += 64) {
+      const int cf = p.cam_cf[wd.cam_off + c];
+      const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + cur) * kCamRec;
+      double xc[6];
+      for (int a = 0; a < 6; ++a) {
+        double v = x[a];
+        if (cf >= 0) {                                      // (the candidate pose, statement for statement as wave 0 forms it)
+          const double d = -yvec[6 * cf + a] * p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
+          const double xn = v + d;
+          v = xn;
+        }
+        xc[a] = v;
+      }
+      double R[9], JL[9];
+      cam_prepare<double>(xc, R, JL);
+      double* gt = p.cam_tab + ((long long)(wd.cam_off + c) * 2 + (1 - cur)) * kCamTab;
+      for (int q = 0; q < 9; ++q) { gt[q] = R[q]; gt[9 + q] = JL[q]; }
+      gt[18] = xc[3]; gt[19] = xc[4]; gt[20] = xc[5];
+    }
+  }
   if (wave != 0) return;
   double model = 0.0, dn2 = 0.0, xn2 = 0.0;
   int bad = 0;
@@ -1536,11 +1568,23 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     // candidate pose (written by k_reduced_solve): R, t for the cost at the candidate point
     const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + cur) * kCamRec;
     const double* xc = p.cam_x + ((long long)(wd.cam_off + c) * 2 + (1 - cur)) * kCamRec;
-    double w[3] = { x[0], x[1], x[2] }, R[9], JL[9];
-    cam_prepare<double>(w, R, JL);
+    double R[9], JL[9], tacc[3], Rc[9], tc[3];
+    if (p.cam_tab) {                                     // both points' tables are in memory (load_cam_table, k_reduced_solve)
+      const double* ga = p.cam_tab + ((long long)(wd.cam_off + c) * 2 + cur) * kCamTab;
+      const double* gc = p.cam_tab + ((long long)(wd.cam_off + c) * 2 + (1 - cur)) * kCamTab;
+      for (int q = 0; q < 9; ++q) { R[q] = ga[q]; JL[q] = ga[9 + q]; Rc[q] = gc[q]; }
+      for (int q = 0; q < 3; ++q) { tacc[q] = ga[18 + q]; tc[q] = gc[18 + q]; }
+    } else {
+      double w[3] = { x[0], x[1], x[2] };
+      cam_prepare<double>(w, R, JL);
+      tacc[0] = x[3]; tacc[1] = x[4]; tacc[2] = x[5];
+      double wc[3] = { xc[0], xc[1], xc[2] };
+      cam_rotation<double>(wc, Rc);
+      tc[0] = xc[3]; tc[1] = xc[4]; tc[2] = xc[5];
+    }
     double* bt = bstab + c * kBsTab;
     for (int q = 0; q < 9; ++q) bt[q] = R[q];
-    bt[9] = x[3]; bt[10] = x[4]; bt[11] = x[5];
+    bt[9] = tacc[0]; bt[10] = tacc[1]; bt[11] = tacc[2];
     const int cf = p.cam_cf[wd.cam_off + c];
     double yw[3] = { 0, 0, 0 }, yt[3] = { 0, 0, 0 };
     if (cf >= 0) {
@@ -1553,11 +1597,9 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
       bt[15 + i] = yt[i];
     }
     camcf[c] = (signed char)cf;
-    double wc[3] = { xc[0], xc[1], xc[2] }, Rc[9];
-    cam_rotation<double>(wc, Rc);
     double* ct = candtab + c * kCandTab;
     for (int q = 0; q < 9; ++q) ct[q] = Rc[q];
-    ct[9] = xc[3]; ct[10] = xc[4]; ct[11] = xc[5];
+    ct[9] = tc[0]; ct[10] = tc[1]; ct[11] = tc[2];
   }
   __syncthreads();
   SLS_K1_STAMP(8);

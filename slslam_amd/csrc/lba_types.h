@@ -117,6 +117,7 @@ struct BatchPtrs {
   // cameras
   double* cam_x;              // [ncam][2][6]
   double* cam_scale;          // [ncam][6]
+  double* cam_tab;            // [ncam][2][kCamTab] R | JL | t of the pose in cam_x[.][buf]: built once per point (first sweep of a solve; the reduced solve for the candidate) and read by the sweeps of every chunk instead of being rebuilt by each of them; nullptr: every sweep builds its own
   const int* cam_cf;          // [ncam] index among the window's free cameras, or -1
   // lines (sorted order)
   double* line_x;             // [2][nline][12]: buffer-major, so that a sweep reading one buffer of consecutive lines streams dense memory
