@@ -1313,16 +1313,36 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
 
   SLS_SOLVE_STAMP(2);
   const int er = tid >> 4, ec = tid & 15;       // this thread's element of a 16x16 tile
+  // (a)+(b) a diagonal tile in the registers of wave 0 (dense_tile.h): L^-1 strictly lower part transposed into the tile's upper
+  // triangle, its diagonal into ivec (L of the diagonal tile itself is never read again: only its inverse is kept)
+  auto factor_tile = [&](const int kb) {
+    double* D = A + (16 * kb) * ld + 16 * kb;
+    diag_tile_factor<double, false>(D, ld, lane, fail, [&](int r, int c, double v) {
+      if (c < r) D[c * ld + r] = v; else ivec[16 * kb + r] = v;
+    });
+  };
+  // A(i,j) -= L(i,kb) L(j,kb)^T, one tile by one wave
+  auto update_tile = [&](const int kb, const int i, const int jt) {
+    double* C = A + (16 * i) * ld + 16 * jt;
+    const double* Pi = A + (16 * i) * ld + 16 * kb;
+    const double* Pj = A + (16 * jt) * ld + 16 * kb;
+    solve_acc_t acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = C[((lane >> 4) + 4 * q) * ld + (lane & 15)];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const double a = -Pi[(lane & 15) * ld + 4 * s4 + (lane >> 4)];
+      const double b = Pj[(lane & 15) * ld + 4 * s4 + (lane >> 4)];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) C[((lane >> 4) + 4 * q) * ld + (lane & 15)] = acc[q];
+  };
+  if (wave == 0) factor_tile(0);
+  __syncthreads();
+  SLS_SOLVE_STAMP(3);
   for (int kb = 0; kb < nt; ++kb) {
-    double* D = A + (16 * kb) * ld + 16 * kb;   // diagonal tile
-    // (a)+(b) diagonal tile in the registers of wave 0 (dense_tile.h): L into the tile's lower triangle, L^-1 strictly
-    // lower part transposed into the tile's upper triangle, its diagonal into ivec
-    if (wave == 0)                                // (L of the diagonal tile itself is never read again: only its inverse is kept)
-      diag_tile_factor<double, false>(D, ld, lane, fail, [&](int r, int c, double v) {
-        if (c < r) D[c * ld + r] = v; else ivec[16 * kb + r] = v;
-      });
-    __syncthreads();
-    SLS_SOLVE_STAMP(3);
+    const double* D = A + (16 * kb) * ld + 16 * kb;   // diagonal tile: its inverse
     // (c) panel: L(i,kb) = A(i,kb) Linv^T, one tile per wave at a time
     for (int i = kb + 1 + wave; i < nt; i += 4) {
       double* T = A + (16 * i) * ld + 16 * kb;
@@ -1339,26 +1359,22 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
     }
     __syncthreads();
     SLS_SOLVE_STAMP(4);
-    // (d) trailing update: A(i,j) -= L(i,kb) L(j,kb)^T for kb < j <= i, tiles dealt round-robin to the waves
-    int tile = 0;
-    for (int i = kb + 1; i < nt; ++i)
-      for (int jt = kb + 1; jt <= i; ++jt, ++tile) {
-        if ((tile & 3) != wave) continue;
-        double* C = A + (16 * i) * ld + 16 * jt;
-        const double* Pi = A + (16 * i) * ld + 16 * kb;
-        const double* Pj = A + (16 * jt) * ld + 16 * kb;
-        solve_acc_t acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = C[((lane >> 4) + 4 * q) * ld + (lane & 15)];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const double a = -Pi[(lane & 15) * ld + 4 * s4 + (lane >> 4)];
-          const double b = Pj[(lane & 15) * ld + 4 * s4 + (lane >> 4)];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) C[((lane >> 4) + 4 * q) * ld + (lane & 15)] = acc[q];
+    // (d) trailing update: A(i,j) -= L(i,kb) L(j,kb)^T for kb < j <= i.  LOOK-AHEAD: wave 0 brings the next diagonal tile up to
+    // date and factors it - the sixteen sequential pivots of a tile are the long pole of a step - while the other three waves
+    // share the rest of the tiles round-robin (every tile by one wave, the same arithmetic as before)
+    if (kb + 1 < nt) {
+      if (wave == 0) {
+        update_tile(kb, kb + 1, kb + 1);
+        factor_tile(kb + 1);
+      } else {
+        int tile = 0;
+        for (int i = kb + 1; i < nt; ++i)
+          for (int jt = kb + 1; jt <= i; ++jt) {
+            if (i == kb + 1) continue;                  // (kb + 1, kb + 1): wave 0's
+            if ((tile++ % 3) + 1 == wave) update_tile(kb, i, jt);
+          }
       }
+    }
     __syncthreads();
     SLS_SOLVE_STAMP(9);
   }
