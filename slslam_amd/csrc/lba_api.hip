@@ -492,8 +492,10 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.upload(b->d_cam_x0, cam_x0);
   ar.zeroed(b->d_cam_scale, std::max<size_t>(6, (size_t)6 * ncam));
   // rotation / Jacobian tables of both pose buffers, shared by the chunks of a window (BatchPtrs.cam_tab); the default sweeps only:
-  // the other paths (reuse_elimination, streamed F, matrix-core sweep) keep building their tables per sweep
-  const bool share_cam_tab = !b->big_mode && !b->fused_motion_only && b->elim_mode == 0 && !b->opt.reuse_elimination && !b->pol.store_f && b->opt.max_num_iterations > 0 && !(b->pol.debug_flags & 16384);
+  // the other paths (reuse_elimination, streamed F, matrix-core sweep) keep building their tables per sweep.  Small batches only:
+  // there a chunk is a tile or two and the tables are a tenth of a sweep; in a batch that fills the chip a chunk is ~33 tiles, the
+  // tables are nothing, and reading them would add 30 MB to a sweep's traffic
+  const bool share_cam_tab = B <= b->num_cus && !b->big_mode && !b->fused_motion_only && b->elim_mode == 0 && !b->opt.reuse_elimination && !b->pol.store_f && b->opt.max_num_iterations > 0 && !(b->pol.debug_flags & 16384);
   ar.zeroed(b->d_cam_tab, share_cam_tab ? std::max<size_t>(1, (size_t)2 * kCamTab * ncam) : 1);
   if (cam_cf.empty()) { cam_cf.push_back(-1); cam_win.push_back(0); }
   ar.upload(b->d_cam_cf, cam_cf);
