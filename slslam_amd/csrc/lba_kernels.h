@@ -545,6 +545,11 @@ __device__ __forceinline__ void load_cam_table(const BatchPtrs& p, const WinDesc
   for (int c = lane; c < wd.C; c += 64) {
     double* ct = camtab + c * kCamTab;
     double* gt = mode ? p.cam_tab + ((long long)(wd.cam_off + c) * 2 + buf) * kCamTab : nullptr;
+    // (free index and Jacobi scale are requested with the table, not after it: one memory round trip for the lot)
+    const int cf = p.cam_cf[wd.cam_off + c];
+    double sc6[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) sc6[a] = unit_scale ? 1.0 : p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
     if (mode == 2) {
       for (int q = 0; q < kCamTab; ++q) ct[q] = gt[q];
     } else {
@@ -556,9 +561,8 @@ __device__ __forceinline__ void load_cam_table(const BatchPtrs& p, const WinDesc
       ct[18] = x[3]; ct[19] = x[4]; ct[20] = x[5];
       if (mode == 1) for (int q = 0; q < kCamTab; ++q) gt[q] = ct[q];
     }
-    const int cf = p.cam_cf[wd.cam_off + c];
     if (cf >= 0)
-      for (int a = 0; a < 6; ++a) camscale[6 * cf + a] = unit_scale ? 1.0 : p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
+      for (int a = 0; a < 6; ++a) camscale[6 * cf + a] = sc6[a];
     camcf[c] = (signed char)cf;
   }
 }
