@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
 #pragma unroll
     for (int q = 0; q < 4; ++q) C[((lane >> 4) + 4 * q) * ld + (lane & 15)] = acc[q];
   };
-  if (wave == 0) factor_tile(0);
+  if (wave == 0 && nt > 0) factor_tile(0);
   __syncthreads();
   SLS_SOLVE_STAMP(3);
   for (int kb = 0; kb < nt; ++kb) {

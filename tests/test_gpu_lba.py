@@ -226,6 +226,22 @@ def test_oversize_window_sizes_and_batches(hip, oracle):
     b.close()
 
 
+def test_every_camera_constant(hip, oracle):
+    """Lines free, every camera constant (fixed_index, lba_problem.cpp:81-90): the reduced camera system is empty, every line is
+    solved on its own."""
+    w = synth.make_window(11, num_lines=60)
+    fi = np.asarray(w["fixed_index"]).reshape(-1, 2).copy()
+    fi[:, 0] = 1
+    w = dict(w); w["fixed_index"] = fi.reshape(-1).astype(np.int32)
+    x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+    x1, s1, t1 = hip.lba_solve(w)
+    _assert_trace_parity(t0, t1, n=3)
+    _assert_summary_parity(s0, s1)
+    _assert_params_parity(w, x0, x1)
+    ncam = int(w["num_cameras"])
+    assert np.array_equal(x1[:6 * ncam], np.asarray(w["parameters"])[:6 * ncam])
+
+
 def test_one_iteration_is_roundoff_exact(hip, oracle):
     w = synth.make_window(11, num_lines=300)
     x0, s0, t0 = oracle.lba_solve(w, linear_solver=0, max_num_iterations=1)      # dense normal equations
