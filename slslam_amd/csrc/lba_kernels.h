@@ -226,7 +226,8 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 }
 // Timing experiments of the elimination sweep (SLSLAM_EXTRA_FLAGS=-DSLSLAM_ABLATE=<bits>, tools/gpu_variant_bench.sh; results are
 // WRONG when set): 1 pair-block atomics dropped (products still computed), 4 camera-record atomics dropped, 8 pair-block
-// atomics replaced by plain stores, 16 camera-record atomics replaced by stores.
+// atomics replaced by plain stores, 16 camera-record atomics replaced by stores, 64 back-substitution: every lane reads the first
+// line's factor record (are those loads waited for?).
 #if !defined(SLSLAM_ABLATE)
 #define SLSLAM_ABLATE 0
 #endif
@@ -1644,7 +1645,9 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     // D^2, g_l (the same values this sweep would recompute); every lane of the line's run reads the same record
     double K[10], D2[4], g[4];
     {
-      const double* le = p.line_elim + (long long)(tc.line_ok ? tc.ls : 0) * p.line_elim_stride;
+      // (timing experiment 64: the record read from the chunk's first line only - same instructions, L2 hits: is the sweep waiting
+      // for these loads?)
+      const double* le = p.line_elim + (long long)((SLSLAM_ABLATE & 64) ? 0 : (tc.line_ok ? tc.ls : 0)) * p.line_elim_stride;
 #pragma unroll
       for (int q = 0; q < 10; ++q) K[q] = le[q];
 #pragma unroll
