@@ -256,13 +256,17 @@ def single_window_latency(lines, device, **shape):
     (host buffers: pack + upload + solve + download)."""
     w = synth.make_window(5, num_lines=lines, **shape)
     _, resident = time_batch([w], device, 30, 3)
+    bt = capi.LBABatch(device=device); bt.add(w); bt.finalize(use_graph=1)
+    path = {0: "tiled sweeps", 1: "fused motion-only", 2: "global memory (lba_big.h)", 3: "mixed"}[bt.path()]
+    chunks = bt.window_chunks(0)
+    bt.close()
     capi.lba_solve(w)
     t0 = time.perf_counter()
     for _ in range(10):
         _, s, _ = capi.lba_solve(w)
     host = 1e3 * (time.perf_counter() - t0) / 10
     return {"lines": lines, "observations": len(w["camera_index"]), "resident_ms_per_solve": resident, "host_buffer_ms_per_solve": host,
-            "lm_iterations": s["num_successful_steps"] + s["num_unsuccessful_steps"]}
+            "lm_iterations": s["num_successful_steps"] + s["num_unsuccessful_steps"], "path": path, "chunks": chunks}
 
 
 def pose_graph_block():
