@@ -1,0 +1,63 @@
+"""Differential soak of the LBA path against the CPU oracle over random window shapes (tiled sweeps, global-memory path, mixed
+batches): every window alone against the oracle at the tolerances of the GPU tests, then all of them in ONE batch against their
+solo results, bit for bit (same chunk counts).  python tools/soak.py [count] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from slslam_amd import capi, synth
+from oracle import pyoracle
+import test_gpu_lba as T
+
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad, solo, ws, paths, drift = 0, [], [], {}, []
+t0 = time.time()
+for i in range(count):
+    kind = rng.integers(0, 10)
+    if kind == 0:
+        w = synth.make_motion_only(int(rng.integers(1, 10 ** 6)), num_lines=int(rng.integers(10, 120)))
+    else:
+        free = int(rng.integers(2, 21)) if kind < 8 else int(rng.integers(21, 43))
+        kf = free + int(rng.integers(0, free + 3)) if kind < 8 else free + int(rng.integers(10, 45))
+        lines = int(rng.integers(12, 400)) if kind < 8 else int(rng.integers(20, 90))
+        w = synth.make_window(int(rng.integers(1, 10 ** 6)), num_lines=lines, num_kf=max(kf, free), num_free=free, mean_track=float(rng.uniform(3.0, max(3.5, 0.8 * max(kf, free)))))
+    x0, s0, t0_ = pyoracle.lba_solve(w, linear_solver=1)
+    b = capi.LBABatch(); b.add(w); b.finalize(); b.solve(); b.download()
+    x1, s1, t1 = b.parameters(0).copy(), b.summary(0), b.trace(0)
+    paths[b.path()] = paths.get(b.path(), 0) + 1
+    chunks = b.window_chunks(0)
+    b.close()
+    # hard: the LM decisions (steps taken / rejected, termination) and the costs to 1e-5; soft (listed): the tolerances of the GPU tests
+    # (final cost 1e-7, cameras 3e-9, lines 2e-6, first iterations of the trace) - random windows with a handful of observations per
+    # line have flat directions along which round-off differences of 1e-16 grow to 1e-7 in the parameters at equal LM decisions
+    hard = [k for k in ("num_successful_steps", "num_unsuccessful_steps", "termination_type", "num_free_parameters", "num_residual_blocks") if s0[k] != s1[k]]
+    rel = abs(s0["final_cost"] - s1["final_cost"]) / max(abs(s0["final_cost"]), 1e-300)
+    dx = float(np.abs(x0 - x1).max())
+    if hard or rel > 1e-5 or dx > 1e-4:
+        bad += 1
+        print("FAIL window %d (cams %d lines %d obs %d): %s, final cost rel. diff %.2e, max |dx| %.2e" % (i, w["num_cameras"], w["num_lines"], len(w["camera_index"]), hard, rel, dx))
+    else:
+        try:
+            T._assert_summary_parity(s0, s1); T._assert_trace_parity(t0_, t1, n=3); T._assert_params_parity(w, x0, x1)
+        except AssertionError:
+            drift.append((i, int(w["num_cameras"]), int(w["num_lines"]), len(w["camera_index"]), rel, dx))
+    ws.append(w); solo.append((x1, s1, chunks))
+print("%d windows alone vs oracle: %d failures; paths %s; %.1f s" % (count, bad, paths, time.time() - t0))
+for d in drift:
+    print("  beyond the test tolerances at equal LM decisions: window %d (cams %d lines %d obs %d) final cost rel. diff %.1e, max |dx| %.1e" % d)
+# all in one batch (mixed sizes and paths); a window's result must not depend on its company - except that a motion-only problem
+# alone takes its one-launch kernel, and that the chunk count is part of the result (so only windows that keep theirs are compared)
+b = capi.LBABatch()
+for w in ws: b.add(w)
+b.finalize(); b.solve(); b.download()
+same = diff = skipped = 0
+for i, w in enumerate(ws):
+    x, s, ch = solo[i]
+    alone_motion = (np.asarray(w["fixed_index"]).reshape(-1, 2)[:, 1] == 1).all()
+    if b.window_chunks(i) != ch or alone_motion: skipped += 1; continue
+    if np.array_equal(b.parameters(i), x) and b.summary(i) == s: same += 1
+    else: diff += 1; print("DIFF window %d in the batch vs alone: max |dx| %.3e" % (i, np.abs(b.parameters(i) - x).max()))
+print("one batch of %d (path %d): %d identical to solo, %d differ, %d not comparable (chunk count / motion-only kernel)" % (count, b.path(), same, diff, skipped))
+b.close()
+sys.exit(1 if (bad or diff) else 0)
