@@ -1313,6 +1313,7 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
     } else {
       A[q * ld + q] = 1.0;
     }
+    yvec[q] = bvec[q];                          // right-hand side, turned into y = L^-1 b block row by block row during the factorisation
   }
   __syncthreads();
 
@@ -1343,11 +1344,35 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
 #pragma unroll
     for (int q = 0; q < 4; ++q) C[((lane >> 4) + 4 * q) * ld + (lane & 15)] = acc[q];
   };
+  // Forward substitution on the fly (one wave each): y_kb = Linv_kb r_kb once block row kb of the right-hand side carries the
+  // contributions of all block columns before it, and r_i -= L(i,kb) y_kb for a block row below - in the shadow of the tile
+  // factorisation, where three of the four waves would otherwise wait.  lane = (row lane & 15, columns 4 (lane >> 4) ..)
+  auto tile_y = [&](const int kb) {
+    const double* D = A + (16 * kb) * ld + 16 * kb;
+    const int r = lane & 15, g4 = 4 * (lane >> 4);
+    double sacc = 0.0;
+#pragma unroll
+    for (int c = g4; c < g4 + 4; ++c) sacc += (c < r ? D[c * ld + r] : (c == r ? ivec[16 * kb + r] : 0.0)) * yvec[16 * kb + c];
+    sacc += __shfl_xor(sacc, 16); sacc += __shfl_xor(sacc, 32);
+    if (lane < 16) yvec[16 * kb + r] = sacc;
+  };
+  auto rhs_update = [&](const int kb, const int i) {
+    const double* T = A + (16 * i) * ld + 16 * kb;
+    const int r = lane & 15, g4 = 4 * (lane >> 4);
+    double sacc = 0.0;
+#pragma unroll
+    for (int c = g4; c < g4 + 4; ++c) sacc += T[r * ld + c] * yvec[16 * kb + c];
+    sacc += __shfl_xor(sacc, 16); sacc += __shfl_xor(sacc, 32);
+    if (lane < 16) yvec[16 * i + r] -= sacc;
+  };
   if (wave == 0 && nt > 0) factor_tile(0);
   __syncthreads();
   SLS_SOLVE_STAMP(3);
   for (int kb = 0; kb < nt; ++kb) {
     const double* D = A + (16 * kb) * ld + 16 * kb;   // diagonal tile: its inverse
+    // y of this block row (its right-hand side is complete since the last phase, its tile's inverse too): by the wave with the
+    // fewest panel tiles, off wave 0's path
+    if (wave == 3) tile_y(kb);
     // (c) panel: L(i,kb) = A(i,kb) Linv^T, one tile per wave at a time
     for (int i = kb + 1 + wave; i < nt; i += 4) {
       double* T = A + (16 * i) * ld + 16 * kb;
@@ -1378,6 +1403,7 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
             if (i == kb + 1) continue;                  // (kb + 1, kb + 1): wave 0's
             if ((tile++ % 3) + 1 == wave) update_tile(kb, i, jt);
           }
+        for (int i = kb + 1 + (wave - 1); i < nt; i += 3) rhs_update(kb, i);
       }
     }
     __syncthreads();
@@ -1385,26 +1411,7 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
   }
 
   SLS_SOLVE_STAMP(5);
-  // ---- 4. block substitution.  forward: y_k = Linv_k (b_k - sum_{c < 16k} L[k,c] y_c)
-  for (int kb = 0; kb < nt; ++kb) {
-    {
-      double sacc = 0.0;
-      for (int c = ec; c < 16 * kb; c += 16) sacc += A[(16 * kb + er) * ld + c] * yvec[c];
-      sacc += dpp_move<0xB1>(sacc); sacc += dpp_move<0x4E>(sacc); sacc += dpp_move<0x141>(sacc); sacc += dpp_move<0x140>(sacc);
-      if (ec == 0) tvec[er] = bvec[16 * kb + er] - sacc;
-    }
-    __syncthreads();
-    {
-      // y = Linv t, one product per thread (row er, column ec), summed over the 16 lanes of the row (was: 16 threads walking
-      // their rows one element after the other)
-      const double* Dk = A + (16 * kb) * ld + 16 * kb;
-      const double li = ec < er ? Dk[ec * ld + er] : (ec == er ? ivec[16 * kb + er] : 0.0);      // Linv[er][ec]
-      double sacc = li * tvec[ec];
-      sacc += dpp_move<0xB1>(sacc); sacc += dpp_move<0x4E>(sacc); sacc += dpp_move<0x141>(sacc); sacc += dpp_move<0x140>(sacc);
-      if (ec == 0) yvec[16 * kb + er] = sacc;
-    }
-    __syncthreads();
-  }
+  // ---- 4. block substitution (forward: done above)
   SLS_SOLVE_STAMP(6);
   // backward: x_k = Linv_k^T (y_k - sum_{r >= 16(k+1)} L[r,k]^T x_r), in place in yvec
   for (int kb = nt - 1; kb >= 0; --kb) {
