@@ -1,9 +1,10 @@
 """Differential soak of the LBA path against the CPU oracle over random window shapes (tiled sweeps, global-memory path, mixed
 batches): every window alone against the oracle at the tolerances of the GPU tests, then all of them in ONE batch against their
-solo results, bit for bit (same chunk counts).  python tools/soak.py [count] [seed]"""
+solo results, bit for bit (same chunk counts).  python tests/tools/soak.py [count] [seed]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from slslam_amd import capi, synth
 from oracle import pyoracle
