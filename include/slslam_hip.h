@@ -87,7 +87,9 @@ typedef struct slslam_solver_options {
                                            (v_mfma_f64_16x16x4_f64, accumulator tiles in registers) with one / two waves per chunk
                                            workgroup - for windows with <= 10 free cameras and one observation per (line, free
                                            camera), else the default sweep runs.  Same results to round-off; slower on MI355X
-                                           (DESIGN.md section 7), kept as a measured alternative                                  */
+                                           (DESIGN.md section 7), kept as a measured alternative.  4 = matrix cores with GROUP-LOCAL
+                                           accumulators: the lines of a window are packed by their first free camera and the wave
+                                           keeps only the 48 x 48 sum of the current group in registers (same conditions)         */
 } slslam_solver_options;
 
 /* Fills every field with the configuration the reference runs (robust loss on, 10 iterations). */

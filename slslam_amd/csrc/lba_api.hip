@@ -13,6 +13,7 @@
 #include "../../include/slslam_hip.h"
 #include "lba_kernels.h"
 #include "lba_eliminate_mfma.h"
+#include "lba_eliminate_grouped.h"
 #define SLSLAM_PO_FACTOR_ONLY
 #include "po_kernels.h"
 #include "lba_big.h"
@@ -186,6 +187,7 @@ struct slslam_lba_batch {
   DevBuf<uint32_t> d_line_desc;
   DevBuf<unsigned long long> d_dbg_cycles;
   int elim_mode = 0, elim_waves = 1;     // see BatchPtrs
+  bool elim_grouped = false;             // elim_mode 1 with group-local accumulators (lba_eliminate_grouped.h); the windows are packed with grouping = 1
   size_t lds_elim = 0;
   DevBuf<unsigned long long> d_iter_counter;
   DevBuf<unsigned int> d_active;
@@ -359,7 +361,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     bool mfma_ok = !b->opt.reuse_elimination && b->opt.max_num_iterations > 0 && B > 0;
     for (const PackedWindow& P : b->wins) if (P.Cf > kMfmaMaxFree || P.dup_free_obs) mfma_ok = false;
     const int want = b->opt.lba_elimination;
-    if (want < 0 || want > 3) return SLSLAM_ERR_INVALID_ARGUMENT;
+    if (want < 0 || want > 4) return SLSLAM_ERR_INVALID_ARGUMENT;
     // automatic = the LDS-atomic sweep: the matrix-core sweep measures slower on MI355X - not because of the matrix pipe (a wave
     // issues a v_mfma_f64_16x16x4_f64 every 64 cycles, tools/micro/mfma_f64_bench.hip) but because of its operand path through
     // LDS and its front end
@@ -369,7 +371,19 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     if (nbig > 0 && nbig < B && !b->opt.reuse_elimination) return finalize_mixed(b);       // oversize windows apart (see `part`)
     if (b->big_mode) { mfma_ok = false; if (b->opt.reuse_elimination) return SLSLAM_ERR_UNSUPPORTED; }
     b->elim_mode = (want >= 2 && mfma_ok) ? 1 : 0;
-    b->elim_waves = b->elim_mode == 0 ? 1 : (want == 2 ? 1 : 2);
+    b->elim_waves = b->elim_mode == 0 ? 1 : (want == 3 ? 2 : 1);
+    b->elim_grouped = b->elim_mode == 1 && want == 4;
+    if (b->elim_grouped) {
+      // the grouped sweep wants the lines of a window in the order of their first free camera: pack again (the default packing
+      // deals rows to the tiles by pair-item count, which this sweep has no use for)
+      for (PackedWindow& P : b->wins) {
+        if (P.grouping == 1) continue;
+        PackedWindow Q;
+        const int rc = repack_window(P, 1, &Q);
+        if (rc != SLSLAM_OK) return rc;
+        P = std::move(Q);
+      }
+    }
   }
 
   // ---- global layout
@@ -670,7 +684,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     g.pair_col = b->d_big_pair_col.p; g.pair_desc = b->d_big_pair_desc.p; g.scal = b->d_big_scal.p; g.flags = b->d_big_flags.p; g.nobs = nobs;
   }
   p.line_desc = b->d_line_desc.p; p.elim_mode = b->elim_mode; p.elim_waves = b->elim_waves;
-  b->lds_elim = (size_t)lds_bytes_eliminate_mfma(maxC, maxn, b->elim_waves);
+  b->lds_elim = b->elim_grouped ? (size_t)lds_bytes_eliminate_grouped(maxC, maxn) : (size_t)lds_bytes_eliminate_mfma(maxC, maxn, b->elim_waves);
 
   b->lds_lin = sizeof(double) * (size_t)lds_doubles_linearise(maxC, maxn);
   b->lds_solve = sizeof(double) * (size_t)lds_doubles_solve(maxn);
@@ -695,6 +709,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_grouped<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_grouped<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
   }
   if (b->lds_solve > 48 * 1024 && !b->big_mode) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
@@ -862,7 +878,9 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     }
     if (!capturing && ((it + 1) % 16) == 0) HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
     if (b->nchunk > 0) {
-      if (b->elim_mode == 1 && pol.debug_flags) {          // timing experiments (SLSLAM_DEBUG_ABLATE)
+      if (b->elim_grouped && it == 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_eliminate_grouped<true>, g_chunk, blk64, b->lds_elim, s, p, pol));
+      else if (b->elim_grouped) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_eliminate_grouped<false>, g_chunk, blk64, b->lds_elim, s, p, pol));
+      else if (b->elim_mode == 1 && pol.debug_flags) {          // timing experiments (SLSLAM_DEBUG_ABLATE)
         if (b->elim_waves == 2) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<2, true>), g_chunk, dim3(128), b->lds_elim, s, p, pol));
         else LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<1, true>), g_chunk, blk64, b->lds_elim, s, p, pol));
       } else if (b->elim_mode == 1 && b->elim_waves == 2) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<2, false>), g_chunk, dim3(128), b->lds_elim, s, p, pol));

@@ -213,6 +213,82 @@ SLS_HD void obs_linearise(const T R[9], const T JL[9], const T t[3],
   }
 }
 
+template <typename T>
+SLS_HD T huber_scale(T s, T a, T* cost);      // (defined at the end of this header)
+
+// The same observation in RAW camera coordinates, robustified and with the line's Jacobi scale folded in:
+//   J_c' rows = [tau | gP] sqrt(rho')  - the SO(3) left Jacobian (d r / d w = tau^T JL(w)) and the Jacobi column scale of the camera
+//     are per-camera constants, which the reduced solve applies once per window as a congruence of the reduced system;
+//   J_l  rows = (gP^T Mp_j + gD^T Md_j) sl_j sqrt(rho'),  [Mp_j | Md_j] = R [d cp / d u_j | d dv / d u_j]: with the line's frame
+//     in camera coordinates E = R R_l = [e0 dc e2] (cp = -d col2, dv = col1) and r3 = R e_z:
+//       a: Mp = d dc          Md = e2           b: Mp = -d c1 e0      Md = s1 e0
+//       g: Mp = -d (r3 x e2)  Md = r3 x dc      t: Mp = (1 + d^2) e2  Md = 0
+//     - seven 3-vectors per observation instead of R and the 21 partials of line_points_jac, and no R^T gP / R^T gD per row.
+// The four rho come first, so that the Huber factor sqrt(rho') multiplies the two 1/s of the stereo pair (every entry of both
+// Jacobians is linear in the row gradient q, which is linear in 1/s) instead of the 44 entries one by one.  The rows of J_c' are
+// handed to `jc_row(row, jc[6])` as they are formed (the grouped elimination sweep parks them in LDS: lba_eliminate_grouped.h).
+template <typename T, typename Sink>
+SLS_HD void obs_linearise_raw(const T R[9], const T t[3], const T trig[7], const T sl[4], const T ob[8], T baseline, T huber_delta,
+                              T rs[4], T Jl[16], T* cost, Sink&& jc_row) {
+  const T s1 = trig[0], c1 = trig[1], s2 = trig[2], c2 = trig[3], s3 = trig[4], c3 = trig[5], d = trig[6];
+  const T col0[3] = { c2 * c3, c2 * s3, -s2 };
+  const T col1[3] = { s1 * s2 * c3 - c1 * s3, s1 * s2 * s3 + c1 * c3, s1 * c2 };
+  const T col2[3] = { c1 * s2 * c3 + s1 * s3, c1 * s2 * s3 - s1 * c3, c1 * c2 };
+  T e0[3], dc[3], e2[3], Q[3], P[3];
+  for (int i = 0; i < 3; ++i) {
+    e0[i] = R[3 * i] * col0[0] + R[3 * i + 1] * col0[1] + R[3 * i + 2] * col0[2];
+    dc[i] = R[3 * i] * col1[0] + R[3 * i + 1] * col1[1] + R[3 * i + 2] * col1[2];
+    e2[i] = R[3 * i] * col2[0] + R[3 * i + 1] * col2[1] + R[3 * i + 2] * col2[2];
+    Q[i] = -d * e2[i];
+    P[i] = Q[i] + t[i];
+  }
+  const T r3[3] = { R[2], R[5], R[8] };
+  T Mp[4][3], Md[3][3];
+  {
+    const T k0 = d * sl[0], k1p = -d * c1 * sl[1], k1d = s1 * sl[1], k2p = -d * sl[2], k3 = (T(1) + d * d) * sl[3];
+    const T x2[3] = { r3[1] * e2[2] - r3[2] * e2[1], r3[2] * e2[0] - r3[0] * e2[2], r3[0] * e2[1] - r3[1] * e2[0] };
+    const T x1[3] = { r3[1] * dc[2] - r3[2] * dc[1], r3[2] * dc[0] - r3[0] * dc[2], r3[0] * dc[1] - r3[1] * dc[0] };
+    for (int i = 0; i < 3; ++i) {
+      Mp[0][i] = k0 * dc[i];  Md[0][i] = sl[0] * e2[i];
+      Mp[1][i] = k1p * e0[i]; Md[1][i] = k1d * e0[i];
+      Mp[2][i] = k2p * x2[i]; Md[2][i] = sl[2] * x1[i];
+      Mp[3][i] = k3 * e2[i];
+    }
+  }
+  T m[2][2], is[2], rho[4], px[2] = { P[0], P[0] - baseline };
+  for (int k = 0; k < 2; ++k) {
+    const T n0 = P[1] * dc[2] - P[2] * dc[1];
+    const T n1 = P[2] * dc[0] - px[k] * dc[2];
+    const T n2 = px[k] * dc[1] - P[1] * dc[0];
+    is[k] = inv_sqrt<T>(n0 * n0 + n1 * n1);
+    m[k][0] = n0 * is[k]; m[k][1] = n1 * is[k];
+    const T m2 = n2 * is[k];
+    for (int e = 0; e < 2; ++e) rho[2 * k + e] = ob[4 * k + 2 * e] * m[k][0] + ob[4 * k + 2 * e + 1] * m[k][1] + m2;
+  }
+  const T sr = huber_scale<T>(rho[0] * rho[0] + rho[1] * rho[1] + rho[2] * rho[2] + rho[3] * rho[3], huber_delta, cost);
+  for (int k = 0; k < 2; ++k) {
+    const T iss = is[k] * sr;
+    for (int e = 0; e < 2; ++e) {
+      const int row = 2 * k + e;
+      const T x = ob[4 * k + 2 * e], y = ob[4 * k + 2 * e + 1];
+      rs[row] = -rho[row] * sr;
+      const T q0 = -(x - rho[row] * m[k][0]) * iss, q1 = -(y - rho[row] * m[k][1]) * iss, q2 = -iss;
+      const T gP[3] = { dc[1] * q2 - dc[2] * q1, dc[2] * q0 - dc[0] * q2, dc[0] * q1 - dc[1] * q0 };
+      const T gD[3] = { q1 * P[2] - q2 * P[1], q2 * px[k] - q0 * P[2], q0 * P[1] - q1 * px[k] };
+      T jc[6];
+      jc[0] = Q[1] * gP[2] - Q[2] * gP[1] + dc[1] * gD[2] - dc[2] * gD[1];
+      jc[1] = Q[2] * gP[0] - Q[0] * gP[2] + dc[2] * gD[0] - dc[0] * gD[2];
+      jc[2] = Q[0] * gP[1] - Q[1] * gP[0] + dc[0] * gD[1] - dc[1] * gD[0];
+      jc[3] = gP[0]; jc[4] = gP[1]; jc[5] = gP[2];
+      jc_row(row, jc);
+      T* jl = Jl + 4 * row;
+      for (int j = 0; j < 3; ++j)
+        jl[j] = gP[0] * Mp[j][0] + gP[1] * Mp[j][1] + gP[2] * Mp[j][2] + gD[0] * Md[j][0] + gD[1] * Md[j][1] + gD[2] * Md[j][2];
+      jl[3] = gP[0] * Mp[3][0] + gP[1] * Mp[3][1] + gP[2] * Mp[3][2];
+    }
+  }
+}
+
 // What the back-substitution needs of an observation, in one pass: the residual and  w = J_l^T (J_c y_c)  (4 values,
 // unscaled: the caller applies the Huber factor and the Jacobi scale of the line's columns).  Neither Jacobian is
 // formed: per residual row the gradients gP, gD w.r.t. the camera-frame point and direction give the row's

@@ -21,7 +21,7 @@ bool all_finite(const double* v, size_t n) {
 }
 }  // namespace
 
-int pack_window(const slslam_lba_window* w, PackedWindow* out) {
+int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping) {
   if (!w || !out) return SLSLAM_ERR_INVALID_ARGUMENT;
   const int C = w->num_cameras, L = w->num_lines, M = w->num_observations;
   if (C < 0 || L < 0 || M < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
@@ -30,7 +30,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   if ((C > 0 || L > 0) && !w->parameters) return SLSLAM_ERR_INVALID_ARGUMENT;
   PackedWindow& P = *out;
   P = PackedWindow();
-  P.C = C; P.L = L; P.M = M;
+  P.C = C; P.L = L; P.M = M; P.grouping = grouping ? 1 : 0;
   P.params0.assign(w->parameters, w->parameters + (size_t)6 * C + (size_t)4 * L);
   if (!all_finite(P.params0.data(), P.params0.size()) || (M > 0 && !all_finite(w->observations, (size_t)8 * M))) return SLSLAM_ERR_INVALID_ARGUMENT;
 
@@ -82,9 +82,12 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
   std::vector<int> tile_ptr(1, 0);
   if (!P.big) {
     std::vector<int> by_len[17];
+    bool carry_open = false;                         // grouping: the open rows survive from one call to the next
+    std::vector<int> open_keep[17];
     auto pack_rows = [&](int len_lo, int len_hi) {
       const int first = (int)rows.size();
-      std::vector<int> open_by_room[17];
+      std::vector<int> open_local[17];
+      std::vector<int>* open_by_room = carry_open ? open_keep : open_local;
       for (int len = len_hi; len >= len_lo; --len)
         for (int l : by_len[len]) {
           // the fullest open row that holds the line - and, among the rows of that fill, preferably one none of whose
@@ -120,6 +123,60 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
       }
       if (!tile_rows.empty()) tile_ptr.push_back((int)tile_rows.size());
     }
+    // grouping: key of a line = first free camera that sees it (x 2, + 1 unless its camera range spans more than 8 cameras, i.e. a
+    // fourth 16-row block of the reduced system counted from that camera); lines without elimination work (constant, or seen by
+    // no free camera) come last
+    auto group_key = [&](int l) -> int {
+      const unsigned m = line_const[l] ? 0u : (fmask[l] & 0xfffffu);
+      if (!m) return 1000;
+      const int a = __builtin_ctz(m), hi = 31 - __builtin_clz(m);
+      return 2 * a + ((hi - a + 1) > 8 ? 0 : 1);       // (the wide lines first: the lanes they leave free in their rows go to lines of their own group)
+    };
+    if (grouping) {
+      // the two length classes of the default packing are kept (lines with fewer than 4 lanes in tiles of their own: the
+      // back-substitution's sin/cos rounds), each of them group after group, the rows filling the tiles in that order
+      std::vector<int> lens[2][17];
+      for (int len = 1; len <= 16; ++len) { lens[len < 4 ? 1 : 0][len].swap(by_len[len]); }
+      for (int cls = 0; cls < 2; ++cls) {
+        std::vector<int> keys;
+        for (int len = 1; len <= 16; ++len) for (int l : lens[cls][len]) keys.push_back(group_key(l));
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        const size_t first_row = tile_rows.size();
+        const int row0 = (int)rows.size();
+        carry_open = true;                             // a group's lines may finish the open rows of the group before it
+        for (int q = 0; q <= 16; ++q) open_keep[q].clear();
+        int prev_first = row0;                         // first row the previous group opened
+        for (int key : keys) {
+          for (int len = 1; len <= 16; ++len) {
+            by_len[len].clear();
+            for (int l : lens[cls][len]) if (group_key(l) == key) by_len[len].push_back(l);
+          }
+          // (only the rows the previous group left open: an older row would put this group's line in the middle of another
+          // group's tiles, and the sweep adds its accumulators to memory whenever the group changes)
+          for (int q = 0; q <= 16; ++q) {
+            std::vector<int>& v = open_keep[q];
+            v.erase(std::remove_if(v.begin(), v.end(), [&](int r) { return r < prev_first; }), v.end());
+          }
+          prev_first = (int)rows.size();
+          pack_rows(1, 16);
+        }
+        carry_open = false;
+        {
+          // rows in the order of the group of their FIRST line; a row that another group finished sits last among them, at the
+          // seam between the two groups
+          std::vector<int> order((int)rows.size() - row0);
+          std::iota(order.begin(), order.end(), row0);
+          auto mixed = [&](int r) { const int k0 = group_key(rows[r].head); for (int l = rows[r].head; l >= 0; l = next[l]) if (group_key(l) != k0) return 1; return 0; };
+          std::vector<int> rk(rows.size(), 0);
+          for (int r : order) rk[r] = group_key(rows[r].head) * 2 + mixed(r);
+          std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rk[x] < rk[y]; });
+          for (int r : order) tile_rows.push_back(r);
+        }
+        for (size_t r = first_row; r < tile_rows.size(); ++r)
+          if ((r - first_row) % 4 == 3 || r + 1 == tile_rows.size()) tile_ptr.push_back((int)r + 1);
+      }
+    } else {
     {
       const std::pair<int, int> rr = pack_rows(4, 16);
       std::vector<int> order(rr.second - rr.first);
@@ -142,6 +199,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
         tile_rows.push_back(r);
         if ((r - rr.first) % 4 == 3 || r + 1 == rr.second) tile_ptr.push_back((int)tile_rows.size());
       }
+    }
     }
   }
   P.line_order.clear();
@@ -251,9 +309,30 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
             for (int I = 0, t = 0; I < 4; ++I)
               for (int J = 0; J <= I; ++J, ++t) if (blk[I] && blk[J]) tiles_touched |= 1u << t;
             P.line_desc[s] = m | ((uint32_t)lane << 10) | (tiles_touched << 16);
+            if (grouping) {
+              // grouped sweep: the rows of the line's cameras counted from its first one, a = lowest bit of m: 6 (hi - a + 1) rows
+              // = that many 16-row blocks
+              // ... | bit 23: the range has holes (some camera between the first and the last does not see the line: the
+              // observation of camera a + i is then NOT lane first + i) | cameras in the range << 24
+              uint32_t a = 0, nblk = 0, wdt = 0, holes = 0;
+              if (m) {
+                a = (uint32_t)__builtin_ctz(m);
+                wdt = (uint32_t)(31 - __builtin_clz(m)) - a + 1u;
+                nblk = (6u * wdt + 15u) / 16u;
+                holes = (uint32_t)__builtin_popcount(m) != wdt ? 1u : 0u;
+              }
+              P.line_desc[s] = m | ((uint32_t)lane << 10) | (a << 16) | (nblk << 20) | (holes << 23) | (wdt << 24);
+            }
           }
           lane += run;
         }
+      }
+      if (grouping) {
+        // the grouped sweep walks a tile's descriptors, not its lanes (a descriptor names its first lane): group after group,
+        // inside a group by the number of blocks, lines without elimination work last (the walk ends at the first of them)
+        auto key = [](uint32_t d) { return (d & 0x3ffu) ? (int)(((d >> 16) & 15u) * 8u + ((d >> 20) & 7u)) : 1 << 20; };
+        std::stable_sort(P.line_desc.begin() + t.line_begin, P.line_desc.begin() + t.line_begin + nl,
+                         [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
       }
       const int rounds_log2 = min_lanes >= 4 ? 0 : min_lanes >= 2 ? 1 : 2;
       t.nlines = (int16_t)nl;
@@ -265,6 +344,29 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out) {
     P.items.resize((size_t)(item_w - P.items.data()));
   }
   return SLSLAM_OK;
+}
+
+int repack_window(const PackedWindow& P, int grouping, PackedWindow* out) {
+  if (!out) return SLSLAM_ERR_INVALID_ARGUMENT;
+  const size_t M = (size_t)P.M;
+  std::vector<int> cam(M), line(M), fixed(2 * M);
+  std::vector<double> obs(8 * M);
+  for (int s = 0; s < P.L; ++s)
+    for (int o = P.line_ptr[s]; o < P.line_ptr[s + 1]; ++o) {
+      const size_t i = (size_t)P.ob_orig[o];
+      cam[i] = P.ob_cam[o]; line[i] = P.line_order[s];
+      fixed[2 * i] = P.cam_cf[P.ob_cam[o]] < 0 ? 1 : 0;       // (a camera with observations and no free index is a constant one)
+      fixed[2 * i + 1] = P.line_flags[s] & 1;
+      for (int q = 0; q < 4; ++q) {
+        obs[8 * i + 2 * q] = P.ob[((size_t)q * M + (size_t)o) * 2];
+        obs[8 * i + 2 * q + 1] = P.ob[((size_t)q * M + (size_t)o) * 2 + 1];
+      }
+    }
+  slslam_lba_window w{};
+  w.num_cameras = P.C; w.num_lines = P.L; w.num_observations = P.M;
+  w.camera_index = cam.data(); w.line_index = line.data(); w.fixed_index = fixed.data();
+  w.observations = obs.data(); w.parameters = const_cast<double*>(P.params0.data());     // (read only by the packer)
+  return pack_window(&w, out, grouping);
 }
 
 std::vector<int> chunk_boundaries(int ntiles, int tiles_per_chunk) {

@@ -36,13 +36,21 @@ struct PackedWindow {
   std::vector<uint16_t> lane_map;   // [64 per tile] lane -> line slot | position << 8 (0x00FF: idle)
   std::vector<uint8_t> items;       // 2 bytes per item
   std::vector<uint32_t> line_desc;  // [L] sorted: free-camera mask | first lane of the run << 10 | touched accumulator tiles << 16
+                                    // (grouping = 1: ... | first free camera a << 16 | 16-row blocks of the line's camera range << 20)
+  int grouping = 0;                 // 0: rows dealt to the tiles by pair-item count; 1: lines grouped by their first free camera (below)
   bool big = false;                 // beyond the tiled sweeps (> 20 free / 64 cameras, a line with > 64 observations): lba_big.h
   bool dup_free_obs = false;        // some free camera observes some line more than once (the reference's map never does)
   std::vector<double> params0;      // caller's original parameter vector (for lines/cams never touched)
 };
 
 // Returns SLSLAM_OK or an error status; on error `out` is unspecified.
-int pack_window(const slslam_lba_window* w, PackedWindow* out);
+// grouping = 1 (the grouped matrix-core elimination, lba_eliminate_grouped.h): the lines of a window follow each other by the
+// FIRST free camera that sees them (a sliding window's lines are seen by runs of consecutive keyframes, so the reduced-system rows
+// a line touches, counted from its first camera, fit a few 16-row blocks), the lines whose camera range needs a fourth block
+// (more than 8 cameras) behind the others of their group; rows are bin-packed inside a group and fill the tiles in that order.
+int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping = 0);
+// The same window packed again with another grouping (the caller's arrays are rebuilt from the packed ones).
+int repack_window(const PackedWindow& P, int grouping, PackedWindow* out);
 
 // Splits ntiles into chunks of at most tiles_per_chunk tiles; returns boundaries [nchunks+1].
 std::vector<int> chunk_boundaries(int ntiles, int tiles_per_chunk);

@@ -361,9 +361,9 @@ def test_batch_equals_single_and_is_reproducible(hip, oracle):
     b.close()
 
 
-@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("mode", [2, 3, 4])
 def test_matrix_core_elimination_sweep(hip, oracle, mode):
-    """lba_elimination = 2 / 3: Schur outer products on v_mfma_f64_16x16x4_f64 with the accumulator tiles in registers
+    """lba_elimination = 2 / 3 / 4 (4: group-local accumulators, lba_eliminate_grouped.h, lines packed by first free camera): Schur outer products on v_mfma_f64_16x16x4_f64 with the accumulator tiles in registers
     (lba_eliminate_mfma.h), normal-equation blocks from the Gram formulation (lba_gram.h), camera constants applied by the
     reduced solve.  Different operation order than the default sweep and the oracle, the same algebra: the first three
     iterations agree with the oracle to the trace tolerances above, step counts and terminations are equal, final cost

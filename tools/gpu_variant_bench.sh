@@ -1,12 +1,13 @@
 #!/bin/bash
 # builds the library with extra compile flags ON the GPU box (hipcc is in the image) and runs the short bench: one line per variant.
+# (BENCH_ARGS: extra bench.py arguments, e.g. "--elim 4"; BENCH_STEPS: timed steps, default 10)
 # usage: gpu_variant_bench.sh TAG "flags variant 1" "flags variant 2" ...
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
 TAG=$1; shift
 : > gpurun_out/${TAG}_variants.txt
 for FLAGS in "$@"; do
   SLSLAM_EXTRA_FLAGS="$FLAGS" python -c "from slslam_amd import build; build.build_lib(force=True)" > gpurun_out/${TAG}_build.log 2>&1 || { echo "BUILD FAILED: $FLAGS" >> gpurun_out/${TAG}_variants.txt; continue; }
-  timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-overlap-run --no-extra-configs > gpurun_out/${TAG}_b.json 2> gpurun_out/${TAG}_b.err
+  timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 2 ${BENCH_ARGS} --no-cpu-baseline --no-overlap-run --no-extra-configs > gpurun_out/${TAG}_b.json 2> gpurun_out/${TAG}_b.err
   python - "$FLAGS" gpurun_out/${TAG}_b.json >> gpurun_out/${TAG}_variants.txt <<'PY'
 import json,sys
 try:
