@@ -82,8 +82,9 @@ typedef struct slslam_solver_options {
   int    lba_fused_motion_only;         /* 1 (default): a batch whose windows all have one free camera and only constant lines
                                            (SLAM::motion_only_ba) is solved by one launch, one wave per window, the 6 x 6
                                            system in registers; 0: the general elimination / back-substitution path     */
-  int    lba_elimination;               /* how the elimination sweep accumulates the reduced camera system: 0 (default) / 1 = per-wave
-                                           partial in LDS fed by fp64 atomics; 2 / 3 = Schur outer products on the matrix cores
+  int    lba_elimination;               /* how the elimination sweep accumulates the reduced camera system: 0 (default) = 4 for a batch
+                                           that fills the chip with long chunks (>= 16 tiles per resident wave) when its conditions
+                                           hold, else 1; 1 = per-wave partial in LDS fed by fp64 atomics; 2 / 3 = Schur outer products on the matrix cores
                                            (v_mfma_f64_16x16x4_f64, accumulator tiles in registers) with one / two waves per chunk
                                            workgroup - for windows with <= 10 free cameras and one observation per (line, free
                                            camera), else the default sweep runs.  Same results to round-off; slower on MI355X

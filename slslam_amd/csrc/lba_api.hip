@@ -370,9 +370,16 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     for (const PackedWindow& P : b->wins) if (P.big) { b->big_mode = true; ++nbig; }
     if (nbig > 0 && nbig < B && !b->opt.reuse_elimination) return finalize_mixed(b);       // oversize windows apart (see `part`)
     if (b->big_mode) { mfma_ok = false; if (b->opt.reuse_elimination) return SLSLAM_ERR_UNSUPPORTED; }
-    b->elim_mode = (want >= 2 && mfma_ok) ? 1 : 0;
+    // automatic (0): the grouped matrix-core sweep (lba_eliminate_grouped.h) for a batch that fills the chip with long chunks -
+    // there it measures faster than the LDS-atomic sweep (1.20 against 1.27 ms per launch on the 1024 x 2000-line batch, DESIGN.md
+    // section 7d); a small batch cuts its windows into chunks of a tile or two, for which the grouped sweep's per-chunk work
+    // (zeroing its 20 KB of accumulator tiles in memory, adding the group sums into them) is not worth it
+    long long tiles_in_batch = 0;
+    for (const PackedWindow& P : b->wins) tiles_in_batch += (long long)P.tiles.size();
+    const bool auto_grouped = want == 0 && mfma_ok && b->opt.chunks_per_window <= 0 && tiles_in_batch >= 16LL * 8 * b->num_cus;
+    b->elim_mode = ((want >= 2 || auto_grouped) && mfma_ok) ? 1 : 0;
     b->elim_waves = b->elim_mode == 0 ? 1 : (want == 3 ? 2 : 1);
-    b->elim_grouped = b->elim_mode == 1 && want == 4;
+    b->elim_grouped = b->elim_mode == 1 && (want == 4 || auto_grouped);
     if (b->elim_grouped) {
       // the grouped sweep wants the lines of a window in the order of their first free camera: pack again (the default packing
       // deals rows to the tiles by pair-item count, which this sweep has no use for)

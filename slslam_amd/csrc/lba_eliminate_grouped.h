@@ -30,19 +30,28 @@
 #include <type_traits>
 #include "lba_kernels.h"
 #include "lba_eliminate_mfma.h"
+#include "lba_eliminate_grouped_maps.h"
 
-namespace slslam {
-
-enum { kGpSlab = 26 };                       // doubles per lane slab of the F panel: 6 rows x 4 columns + 2 (16-byte aligned rows, lane stride
-                                             // 52 dwords: the b128 row stores of 64 lanes spread over the banks)
-enum { kGpPanel = 65 * kGpSlab };            // 64 lanes + the zero slab that absent cameras read
-#if !defined(GP_DEPTH)
-#define GP_DEPTH 4
+// timing experiments (results WRONG when set): 1 no matrix-core phase, 2 operands fetched but no products issued, 4 one product per line only
+#if !defined(GP_ABLATE)
+#define GP_ABLATE 0
+#endif
+// lines fetched together per block count (1: one by one)
+#if !defined(GP_GB1)
+#define GP_GB1 4
+#endif
+#if !defined(GP_GB2)
+#define GP_GB2 4
+#endif
+#if !defined(GP_GB3)
+#define GP_GB3 2
 #endif
 #if !defined(GP_SETPRIO)
 #define GP_SETPRIO 1
 #endif
-enum { kGpPersist = 6, kGpDepth = GP_DEPTH };                     // accumulator tiles kept per group: block rows 0-2 of the group-local sum
+
+namespace slslam {
+
 
 __host__ __device__ inline int lds_bytes_eliminate_grouped(int C, int n) {
   return (kGpPanel + C * kCamTabG + (n / 6) * kDiagRec) * 8 + ((C + 15) / 16) * 16;
@@ -54,13 +63,9 @@ __host__ __device__ inline int lds_bytes_eliminate_grouped(int C, int n) {
 __device__ __forceinline__ void grouped_flush_tile(double* slab, const solve_acc_t& A, int r, int c, int a, int n, int lane) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int grow = 6 * a + 16 * r + (lane >> 4) + 4 * q, gcol = 6 * a + 16 * c + (lane & 15);
+    const int idx = gp_flush_index(r, c, a, q, lane, n);
     const double v = A[q];
-    if (grow < n && gcol <= grow && v != 0.0) {
-      const int I = grow >> 4, J = gcol >> 4;
-      const int idx = ((I * (I + 1)) / 2 + J) * 256 + ((grow & 15) >> 2) * 64 + (grow & 3) * 16 + (gcol & 15);
-      __hip_atomic_fetch_add(slab + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (idx >= 0 && v != 0.0) __hip_atomic_fetch_add(slab + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -311,10 +316,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
       // group's first one, entry rho % 6, column l >> 4 of that camera's F block: byte offset pre[r] from the slab of the line's first lane
       int pre[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rho = 16 * r + (l2 & 15), slot = (rho * 43) >> 8;       // rho / 6 for rho < 64
-        pre[r] = slot * (kGpSlab * 8) + ((rho - 6 * slot) * 4 + (l2 >> 4)) * 8;
-      }
+      for (int r = 0; r < 4; ++r) pre[r] = gp_pre(l2, r) * 8;              // (bytes)
       const char* pbytes = reinterpret_cast<const char*>(panel);
       // per line (lane i <-> i-th descriptor): slab of its first lane | end of its cameras' slabs << 16 | range has holes << 31
       const unsigned d_first = (descv >> 10) & 63u, d_wdt = (descv >> 24) & 15u, d_nb = (descv >> 20) & 7u, d_group = (descv >> 16) & 15u;
@@ -357,7 +359,9 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
       bool row3_used = false;
       auto products = [&](auto nbtag, const double (&X)[4]) {
         constexpr int NB = decltype(nbtag)::value;
+        if (GP_ABLATE & 2) { for (int r = 0; r < NB; ++r) keep_alive(X[r]); return; }
         acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[0], X[0], acc[0], 0, 0, 0);
+        if (GP_ABLATE & 4) { for (int r = 1; r < NB; ++r) keep_alive(X[r]); return; }
         if (NB >= 2) {
           acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[1], X[0], acc[1], 0, 0, 0);
           acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[1], X[1], acc[2], 0, 0, 0);
@@ -374,8 +378,34 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
           row3[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[3], X[3], row3[3], 0, 0, 0);
         }
       };
-      // lines [s, e) of one block count: the operands of the next line are requested before the products of this one are issued
-      auto run = [&](int s, int e, auto nbtag) {
+      // lines [s, e) of one block count, GB at a time: the operands of the next GB lines are requested before the products of these
+      // are issued - the matrix pipe gets GB * NB (NB + 1) / 2 products back to back while the next round trip to the panel is
+      // under way; the last (e - s) % GB lines one by one
+      auto run = [&](int s, int e, auto nbtag, auto gbtag) {
+        constexpr int GB = decltype(gbtag)::value;
+        if (s >= e) return;
+        if (GB > 1 && s + GB <= e) {
+          double Xa[GB][4], Xb[GB][4];
+#pragma unroll
+          for (int i = 0; i < GB; ++i) fetch(s + i, nbtag, Xa[i]);
+          for (; s + 2 * GB <= e; s += 2 * GB) {
+#pragma unroll
+            for (int i = 0; i < GB; ++i) fetch(s + GB + i, nbtag, Xb[i]);
+#pragma unroll
+            for (int i = 0; i < GB; ++i) products(nbtag, Xa[i]);
+            if (s + 3 * GB <= e) {
+#pragma unroll
+              for (int i = 0; i < GB; ++i) fetch(s + 2 * GB + i, nbtag, Xa[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < GB; ++i) products(nbtag, Xb[i]);
+          }
+          if (s + GB <= e) {
+#pragma unroll
+            for (int i = 0; i < GB; ++i) products(nbtag, Xa[i]);
+            s += GB;
+          }
+        }
         if (s >= e) return;
         double Xa[4], Xb[4];
         fetch(s, nbtag, Xa);
@@ -400,7 +430,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
         row3_used = false;
       };
       if (GP_SETPRIO) __builtin_amdgcn_s_setprio(1);   // the few VALU slots this phase needs come first: they feed the matrix pipe
-      const int nact = __popcll(__ballot(d_active));
+      const int nact = (GP_ABLATE & 1) ? 0 : __popcll(__ballot(d_active));
       for (int sb = 0; sb < nact;) {                   // a segment: the lines of one group (a tile has one, at a seam two)
         const int a = (int)(((unsigned)__builtin_amdgcn_readlane((int)descv, sb) >> 16) & 15u);
         const bool in_seg = d_active && d_group == (unsigned)a;
@@ -410,10 +440,10 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
           if (cur_a >= 0) { flush_group(cur_a); if (row3_used) flush_row3(cur_a); }
           cur_a = a;
         }
-        run(sb, e1, std::integral_constant<int, 1>());
-        run(e1, e2, std::integral_constant<int, 2>());
-        run(e2, e3, std::integral_constant<int, 3>());
-        if (e4 > e3) { run(e3, e4, std::integral_constant<int, 4>()); row3_used = true; }
+        run(sb, e1, std::integral_constant<int, 1>(), std::integral_constant<int, GP_GB1>());
+        run(e1, e2, std::integral_constant<int, 2>(), std::integral_constant<int, GP_GB2>());
+        run(e2, e3, std::integral_constant<int, 3>(), std::integral_constant<int, GP_GB3>());
+        if (e4 > e3) { run(e3, e4, std::integral_constant<int, 4>(), std::integral_constant<int, 1>()); row3_used = true; }
         sb = e4;
       }
       SLS_K1_STAMP(6);

@@ -1,5 +1,6 @@
 // slslam_amd/csrc/lba_pack.cpp — see lba_pack.h.
 #include "lba_pack.h"
+#include "lba_eliminate_grouped_maps.h"
 
 #include <algorithm>
 #include <cmath>
@@ -321,7 +322,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping) {
                 nblk = (6u * wdt + 15u) / 16u;
                 holes = (uint32_t)__builtin_popcount(m) != wdt ? 1u : 0u;
               }
-              P.line_desc[s] = m | ((uint32_t)lane << 10) | (a << 16) | (nblk << 20) | (holes << 23) | (wdt << 24);
+              P.line_desc[s] = gp_desc(m, (uint32_t)lane, a, nblk, holes, wdt);
             }
           }
           lane += run;
@@ -330,7 +331,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping) {
       if (grouping) {
         // the grouped sweep walks a tile's descriptors, not its lanes (a descriptor names its first lane): group after group,
         // inside a group by the number of blocks, lines without elimination work last (the walk ends at the first of them)
-        auto key = [](uint32_t d) { return (d & 0x3ffu) ? (int)(((d >> 16) & 15u) * 8u + ((d >> 20) & 7u)) : 1 << 20; };
+        auto key = [](uint32_t d) { return gp_mask(d) ? (int)(gp_group(d) * 8u + gp_blocks(d)) : 1 << 20; };
         std::stable_sort(P.line_desc.begin() + t.line_begin, P.line_desc.begin() + t.line_begin + nl,
                          [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
       }

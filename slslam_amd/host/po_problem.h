@@ -2,7 +2,7 @@
 // (reference src/po_problem.h:110-144) for SLAM::pose_optimization (src/slam.cpp:1262-1301).
 // Same names, argument meaning and ownership (destructor delete[]s the four arrays,
 // src/po_problem.cpp:33-38).  The SE(3) functor (src/po_problem.h:27-108) runs on the GPU
-// (slslam_amd/csrc/po_kernels.h).
+// (slslam_amd/csrc/po_kernels.h); its three SE(3) templates are kept below for host callers.
 //
 // Attribution: the class surface declared here (names, signatures, accessor layout) mirrors the interface of
 // SLSLAM's src/po_problem.h — Copyright (C) 2015 Guoxuan Zhang, Jin Han Lee, Jongwoo Lim, Il Hong Suh, distributed under the
@@ -14,6 +14,34 @@
 #include <string>
 #include "ceres/ceres.h"
 #include "ceres/rotation.h"
+
+// The SE(3) helpers of the reference header (src/po_problem.h:27-64), poses as [angle-axis (3) | translation (3)], kept so that
+// code written against that header finds the same three templates.  On the GPU the same algebra runs on dual numbers
+// (slslam_amd/csrc/po_kernels.h); these host forms are for callers and for the tests (tests/test_host_cxx.py compares them with
+// the matrix forms of gc_lite.h).
+// Pi = P^-1: rotation -w, translation R(-w)(-t)
+template <typename T>
+void gc_T_inv(T P[6], T Pi[6]) {
+  T minus_t[3];
+  for (int i = 0; i < 3; ++i) { Pi[i] = -P[i]; minus_t[i] = -P[3 + i]; }
+  ceres::AngleAxisRotatePoint(Pi, minus_t, Pi + 3);
+}
+// R20 = R21 R10 on angle-axis vectors, through unit quaternions
+template <typename T>
+void gc_w_20(T w21[3], T w10[3], T w20[3]) {
+  T qa[4], qb[4], qab[4];
+  ceres::AngleAxisToQuaternion(w21, qa);
+  ceres::AngleAxisToQuaternion(w10, qb);
+  ceres::QuaternionProduct(qa, qb, qab);
+  ceres::QuaternionToAngleAxis(qab, w20);
+}
+// T20 = T21 T10: w20 = w21 (+) w10, t20 = R(w21) t10 + t21
+template <typename T>
+void gc_T_20(T T21[6], T T10[6], T T20[6]) {
+  gc_w_20(T21, T10, T20);
+  ceres::AngleAxisRotatePoint(T21, T10 + 3, T20 + 3);
+  for (int i = 3; i < 6; ++i) T20[i] += T21[i];
+}
 
 namespace ceres {
 

@@ -29,7 +29,9 @@ def host_math():
     out_dir = os.path.join(ROOT, "tests", "_build")
     out = os.path.join(out_dir, "libhost_math.so")
     deps = [src, os.path.join(ROOT, "slslam_amd", "csrc", "lba_math.h"), os.path.join(ROOT, "slslam_amd", "csrc", "lba_pack.cpp"),
-            os.path.join(ROOT, "slslam_amd", "csrc", "lba_pack.h"), os.path.join(ROOT, "slslam_amd", "csrc", "lba_types.h")]
+            os.path.join(ROOT, "slslam_amd", "csrc", "lba_pack.h"), os.path.join(ROOT, "slslam_amd", "csrc", "lba_types.h"),
+            os.path.join(ROOT, "slslam_amd", "csrc", "lba_eliminate_grouped_maps.h"), os.path.join(ROOT, "slslam_amd", "csrc", "lba_eliminate_mfma_maps.h"),
+            os.path.join(ROOT, "slslam_amd", "csrc", "lba_gram.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(out_dir, exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src,

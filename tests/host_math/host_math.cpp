@@ -53,21 +53,49 @@ void hm_obs_gram_blocks(const double* cam, const double* line, const double* obs
   }
 }
 double hm_huber(double s, double a, double* cost) { return slslam::huber_scale<double>(s, a, cost); }
+// The grouped sweep's linearisation (obs_linearise_raw): robustified residual, J_c' = [tau | gP] sqrt(rho') (raw camera
+// coordinates), J_l sl sqrt(rho'), block cost
+void hm_obs_linearise_raw(const double* cam, const double* line, const double* obs, double baseline, double huber_delta,
+                          const double* sl, double* rs, double* jc, double* jl, double* cost) {
+  double R[9], trig[7];
+  slslam::cam_rotation<double>(cam, R);
+  slslam::line_trig<double>(line, trig);
+  slslam::obs_linearise_raw<double>(R, cam + 3, trig, sl, obs, baseline, huber_delta, rs, jl, cost,
+                                    [&](int row, const double (&j)[6]) { for (int a = 0; a < 6; ++a) jc[6 * row + a] = j[a]; });
+}
 }
 
 // ---- pack inspection (host-only code of the product, lba_pack.cpp)
 #include "../../slslam_amd/csrc/lba_pack.h"
 #include <cstring>
 extern "C" {
+int hm_pack_g(int C, int L, int M, const int* cam, const int* line, const int* fixed, const double* obs, double* params,
+              int* out_counts, int* line_order, int* line_ptr, int* ob_orig, int* ob_cam, int* tiles, unsigned char* items, int* cam_cf,
+              int max_tiles, int max_items, unsigned short* lane_map, int grouping, unsigned* line_desc);
 // Packs one window and copies the layout into caller buffers (sized generously by the test).
 int hm_pack(int C, int L, int M, const int* cam, const int* line, const int* fixed, const double* obs, double* params,
             int* out_counts /*Cf, ntiles, nitems, nfree_params, nkept*/, int* line_order, int* line_ptr, int* ob_orig,
             int* ob_cam, int* tiles /*4 ints per tile: line_begin,nlines,flags,nitems*/, unsigned char* items, int* cam_cf,
             int max_tiles, int max_items, unsigned short* lane_map /*64 per tile*/) {
+  return hm_pack_g(C, L, M, cam, line, fixed, obs, params, out_counts, line_order, line_ptr, ob_orig, ob_cam, tiles, items, cam_cf,
+                   max_tiles, max_items, lane_map, 0, nullptr);
+}
+// ... with the packer's grouping mode (1: lines by first free camera, the grouped matrix-core sweep; the window is packed the
+// default way first and packed again from the packed arrays, as the library does) and the line descriptors
+int hm_pack_g(int C, int L, int M, const int* cam, const int* line, const int* fixed, const double* obs, double* params,
+              int* out_counts, int* line_order, int* line_ptr, int* ob_orig, int* ob_cam, int* tiles, unsigned char* items, int* cam_cf,
+              int max_tiles, int max_items, unsigned short* lane_map, int grouping, unsigned* line_desc) {
   slslam_lba_window w{C, L, M, cam, line, fixed, obs, params};
   slslam::PackedWindow P;
-  const int rc = slslam::pack_window(&w, &P);
+  int rc = slslam::pack_window(&w, &P);
   if (rc) return rc;
+  if (grouping) {
+    slslam::PackedWindow Q;
+    rc = slslam::repack_window(P, grouping, &Q);
+    if (rc) return rc;
+    P = Q;
+  }
+  if (line_desc) std::memcpy(line_desc, P.line_desc.data(), sizeof(unsigned) * L);
   if ((int)P.tiles.size() > max_tiles || (int)P.items.size() / 2 > max_items) return -1;
   out_counts[0] = P.Cf; out_counts[1] = (int)P.tiles.size(); out_counts[2] = (int)P.items.size() / 2;
   out_counts[3] = P.nfree_params; out_counts[4] = P.nkept;
@@ -108,4 +136,13 @@ unsigned hm_block_cam_mask(int I) { return slslam::block_cam_mask(I); }
 int hm_ptile_of(int nw, int w, int e) { return slslam::ptile_of(nw, w, e); }
 // accumulator entry (tile t, register q, lane) -> row / column of the stacked system
 void hm_acc_rc(int t, int q, int lane, int* row, int* col) { slslam::acc_row_col(t, q, lane, row, col); }
+}
+
+// ---- the grouped matrix-core elimination's index maps (lba_eliminate_grouped.h)
+#include "../../slslam_amd/csrc/lba_eliminate_grouped_maps.h"
+extern "C" {
+int hm_gp_store(int lane, int a, int k) { return slslam::gp_store_index(lane, a, k); }
+int hm_gp_fetch(int lane, int r, unsigned d) { return slslam::gp_fetch_index(lane, r, d); }
+int hm_gp_flush(int r, int c, int a, int q, int lane, int n) { return slslam::gp_flush_index(r, c, a, q, lane, n); }
+int hm_gp_panel_doubles() { return slslam::kGpPanel; }
 }

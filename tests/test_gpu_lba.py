@@ -496,6 +496,20 @@ def test_randomised_shapes_against_oracle(hip, oracle):
     assert worst["trace"] < 1e-6
 
 
+def test_randomised_shapes_grouped_matrix_core_sweep(hip, oracle):
+    """The same 60 random windows through lba_elimination = 4 (lines packed by first free camera, group-local accumulator tiles,
+    lba_eliminate_grouped.h; windows with more than 10 free cameras or a camera that sees a line twice take the default sweep):
+    scrambled observation order, track lengths of 2 (camera ranges with holes), constant lines, motion-only shapes,
+    loss on / off, iteration caps."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, worst = mod.run(60, seed=3, verbose=True, hip_opt=dict(lba_elimination=4, lba_fused_motion_only=0))
+    assert bad == 0
+    assert worst["trace"] < 1e-6
+
+
 def test_one_shot_solves_reuse_their_device_block(hip, oracle):
     """slslam_lba_solve / slslam_po_solve keep the device block of the previous call (device_cache.h): solves of different
     shapes back to back, interleaved with pose-graph solves, still match the oracle - nothing depends on fresh memory."""

@@ -195,6 +195,20 @@ def _map_from_window(w, lib, C):
     return kfs, lms, Packed, keep, slot_to_kf
 
 
+def test_se3_templates_of_the_mirrored_header(tmp_path):
+    """gc_T_inv<T>, gc_w_20<T>, gc_T_20<T> (reference src/po_problem.h:27-64) are part of the header surface a caller of
+    po_problem.h sees: slslam_amd/host/po_problem.h keeps them, on the four rotation helpers of host/ceres/rotation.h (restated
+    from the published Ceres 1.7.0 definitions).  Instantiated for double and compared with the matrix forms of gc_lite
+    (slslam_gc_T_inv, slslam_gc_T_20) over 4000 random pose pairs with rotation angles 0, 1e-9 ... pi."""
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    exe = str(tmp_path / "se3_templates")
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-Wall", "-Werror", "-I", HOST, "-o", exe, os.path.join(ROOT, "tests", "host_cxx", "se3_templates.cpp"),
+                           "-L", LIBDIR, "-lslslam_host", "-Wl,-rpath," + LIBDIR])
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    worst_inv, worst_comp, worst_quat = (float(v) for v in out)
+    assert worst_inv < 1e-9 and worst_comp < 1e-12 and worst_quat < 1e-12, out
+
+
 def test_window_packer_reproduces_the_array_contract(oracle):
     """slslam_pack_window (SLAM::bundle_adjustment pre, slam.cpp:811-921) on a map built from a synthetic
     window gives the same problem (same solve), and slslam_unpack_window (slam.cpp:957-972) writes the

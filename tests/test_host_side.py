@@ -166,6 +166,188 @@ def test_mfma_elimination_index_maps_replay_a_window(host_math):
     assert owned == list(range(10)) and [host_math.hm_ptile_of(1, 0, e) for e in range(10)] == list(range(10))
 
 
+def _hole_window(seed):
+    """A window whose lines are seen by arbitrary SUBSETS of the free cameras (camera ranges with holes), some constant lines,
+    some lines no free camera sees, observations in scrambled order."""
+    rng = np.random.default_rng(seed)
+    Cn, ncf, L = 14, 10, 90
+    cam, line = [], []
+    for l in range(L):
+        k = int(rng.integers(1, 11))
+        cs = list(rng.choice(ncf, size=k, replace=False)) if l % 9 else []          # every ninth line: fixed cameras only
+        cs += list(ncf + rng.choice(Cn - ncf, size=int(rng.integers(0, 4)), replace=False))
+        if not cs: cs = [ncf]
+        cam += cs; line += [l] * len(cs)
+    cam, line = np.asarray(cam, dtype=np.int32), np.asarray(line, dtype=np.int32)
+    perm = rng.permutation(len(cam))
+    cam, line = cam[perm], line[perm]
+    fixed = np.zeros((len(cam), 2), dtype=np.int32)
+    fixed[cam >= ncf, 0] = 1
+    fixed[line % 7 == 3, 1] = 1
+    return dict(num_cameras=Cn, num_lines=L, camera_index=cam, line_index=line, fixed_index=fixed.reshape(-1),
+                observations=rng.normal(size=(len(cam), 8)), parameters=rng.normal(size=6 * Cn + 4 * L))
+
+
+@pytest.mark.parametrize("which", ["sliding", "wide", "holes"])
+def test_grouped_elimination_maps_replay_windows(host_math, which):
+    """The grouped matrix-core elimination sweep (lba_eliminate_grouped.h) replayed on the CPU through the index maps the kernel
+    and the packer use (lba_eliminate_grouped_maps.h compiled for the host).  Packing with grouping = 1 keeps every invariant of the
+    default packing (_check_tiles) and adds: a tile's descriptors come group after group (first free camera), inside a group by
+    their number of 16-row blocks, lines without elimination work last; every field of a descriptor is what the line's
+    observations say.  Then the sweep itself: every observation of a free camera stores a random 6 x 4 F block in its lane's panel
+    slab; per descriptor, lane l fetches X[16 r + (l & 15)][l >> 4] (gp_fetch_index) and the group-local tiles take the rank-4
+    update with the v_mfma_f64_16x16x4_f64 register layout; the tiles are added into the slab (gp_flush_index) whenever the
+    group changes, the fourth block row after every tile of lines.  Decoded with acc_row_col (what k_reduced_solve does) the slab
+    must hold sum_lines sum_{i,j} F_i F_j^T."""
+    rng = np.random.default_rng(11)
+    w = {"sliding": lambda: synth.make_window(9, num_lines=150),
+         "wide": lambda: synth.make_window(10, num_lines=60, num_kf=24, num_free=10, mean_track=40.0),
+         "holes": lambda: _hole_window(4)}[which]()
+    rc0, P0 = _pack(host_math, w)
+    rc, P = _pack(host_math, w, grouping=1)
+    assert rc0 == 0 and rc == 0
+    L, M = int(w["num_lines"]), len(w["camera_index"])
+    assert sorted(P["line_order"]) == list(range(L)) and sorted(P["ob_orig"]) == list(range(M))
+    for k in ("Cf", "nfree", "nkept", "nitems"):
+        assert P[k] == P0[k]
+    assert np.array_equal(P["cam_cf"], P0["cam_cf"])
+    assert P["ntiles"] <= P0["ntiles"] + max(2, P0["ntiles"] // 20)          # grouping costs (almost) no lanes
+    _check_tiles(P, w, L)
+    ncf = P["Cf"]
+    n = 6 * ncf
+    fixed_line = np.zeros(L, dtype=bool)
+    fixed_line[np.asarray(w["line_index"])[np.asarray(w["fixed_index"]).reshape(-1, 2)[:, 1] != 0]] = True
+    slab = np.zeros(10 * 256)
+    want = np.zeros((64, 64))
+    acc = np.zeros((6, 4, 64))
+    cur_a, nflush, nmfma, groups_seen = -1, 0, 0, []
+
+    def flush(tiles, rcs, a):
+        for (r, c), T in zip(rcs, tiles):
+            for q in range(4):
+                for lane in range(64):
+                    idx = host_math.hm_gp_flush(r, c, a, q, lane, n)
+                    if idx >= 0:
+                        slab[idx] += T[q, lane]
+            T[:] = 0.0
+    RC6 = [(0, 0), (1, 0), (1, 1), (2, 0), (2, 1), (2, 2)]
+
+    def product(Xr, Xc):
+        Am = np.array([[Xr[m + 16 * kk] for kk in range(4)] for m in range(16)])      # A[m][k] = a(lane = m + 16 k)
+        Bm = np.array([[Xc[nn + 16 * kk] for nn in range(16)] for kk in range(4)])    # B[k][n] = b(lane = n + 16 k)
+        Dm = Am @ Bm
+        return np.array([[Dm[(lane >> 4) + 4 * qq, lane & 15] for lane in range(64)] for qq in range(4)])
+    for t, (lb, nl, flags, ni) in enumerate(P["tiles"]):
+        panel = np.full(host_math.hm_gp_panel_doubles(), np.nan)
+        panel[64 * 26:] = 0.0                                   # the zero slab
+        lane_slot, lane_pos = P["lane_map"][t] & 0xFF, (P["lane_map"][t] >> 8) & 0x3F
+        F, first_of, mask_of = {}, {}, {}
+        for q in range(nl):
+            s_ = lb + q
+            lanes = np.nonzero(lane_slot == q)[0]
+            first_of[int(lanes[0])] = s_
+            sel = P["ob_orig"][P["line_ptr"][s_]:P["line_ptr"][s_ + 1]]
+            cfs = P["cam_cf"][np.asarray(w["camera_index"])[sel]]
+            mask_of[s_] = 0
+            for jj, cf in enumerate(cfs):
+                lane = int(lanes[0]) + jj
+                Fb = rng.normal(size=(6, 4))                    # (fixed-camera lanes store blocks too: never fetched)
+                for a in range(6):
+                    for k4 in range(4):
+                        panel[host_math.hm_gp_store(lane, a, k4)] = Fb[a, k4]
+                if cf >= 0 and not fixed_line[P["line_order"][s_]]:
+                    F[(s_, int(cf))] = Fb
+                    mask_of[s_] |= 1 << int(cf)
+        descs = [int(d) for d in P["desc"][lb:lb + nl]]
+        keys = [(((d >> 16) & 15) * 8 + ((d >> 20) & 7)) if d & 0x3FF else 1 << 20 for d in descs]
+        assert keys == sorted(keys)                             # group after group, by block count, idle lines last
+        seen_lines = set()
+        row3 = np.zeros((4, 4, 64))
+        row3_used = False
+        for d in descs:
+            mask, first, a, nb, holes, wdt = d & 0x3FF, (d >> 10) & 63, (d >> 16) & 15, (d >> 20) & 7, (d >> 23) & 1, (d >> 24) & 15
+            s_ = first_of[first]
+            assert s_ not in seen_lines
+            seen_lines.add(s_)
+            assert mask == mask_of[s_]                          # the line's free cameras (0: constant line / none)
+            if not mask:
+                continue
+            cams = [c for c in range(10) if (mask >> c) & 1]
+            assert a == cams[0] and wdt == cams[-1] - cams[0] + 1 and nb == (6 * wdt + 15) // 16 and holes == int(len(cams) != wdt)
+            if a != cur_a:
+                if cur_a >= 0:
+                    flush(acc, RC6, cur_a); nflush += 1
+                    if row3_used:
+                        flush(row3, [(3, c) for c in range(4)], cur_a); row3_used = False
+                cur_a = a
+                groups_seen.append(a)
+            X = np.zeros((4, 64))
+            for r in range(nb):
+                for lane in range(64):
+                    X[r, lane] = panel[host_math.hm_gp_fetch(lane, r, d)]
+            assert not np.isnan(X).any()
+            stack = np.zeros((64, 4))
+            for c in cams:
+                stack[6 * c:6 * c + 6] = F[(s_, c)]
+            want += stack @ stack.T
+            for e, (r, c) in enumerate(RC6):
+                if r < nb:
+                    acc[e] += product(X[r], X[c]); nmfma += 1
+            if nb >= 4:
+                for c in range(4):
+                    row3[c] += product(X[3], X[c]); nmfma += 1
+                row3_used = True
+        assert len(seen_lines) == nl
+        if row3_used:
+            flush(row3, [(3, c) for c in range(4)], cur_a)
+    if cur_a >= 0:
+        flush(acc, RC6, cur_a)
+    got = np.zeros((64, 64))
+    row, col = C.c_int(0), C.c_int(0)
+    for tt in range(10):
+        for qq in range(4):
+            for lane in range(64):
+                host_math.hm_acc_rc(tt, qq, lane, C.byref(row), C.byref(col))
+                got[row.value, col.value] = slab[tt * 256 + qq * 64 + lane]
+    lower = np.tril(np.ones((64, 64), dtype=bool))
+    assert abs(got - want)[lower].max() < 1e-11 and abs(want[n:, :]).max() == 0.0
+    if which == "sliding":
+        assert groups_seen == sorted(groups_seen) or nflush <= 2 * ncf      # the groups follow each other: a handful of adds to memory per window
+        assert nflush <= 3 * ncf and 2.5 < nmfma / L < 5.0
+
+
+def test_raw_linearisation_matches_the_standard_one(host_math, oracle):
+    """obs_linearise_raw (the grouped sweep: raw camera coordinates, line frame in camera coordinates, Huber factor folded into the
+    row gradients, line scale folded into the line's columns) against obs_linearise + the explicit products: r sqrt(rho'),
+    J_c' JL = J_c sqrt(rho') (dr/dw = tau^T JL(w)), J_l diag(sl) sqrt(rho'); inliers, outliers, loss off, the identity keyframe."""
+    rng = np.random.default_rng(3)
+    a = 1.0 / 406.05
+    for case in range(40):
+        cam = np.concatenate([rng.normal(0, 0.3, 3), rng.normal(0, 1.0, 3)])
+        if case % 5 == 0: cam[:3] = 0.0
+        line = np.array([rng.uniform(-3, 3), rng.uniform(-1.4, 1.4), rng.uniform(-3, 3), rng.uniform(0.2, 1.3)])
+        obs = rng.normal(0, 0.3 if case % 2 else 0.002, 8)
+        sl = rng.uniform(0.1, 1.0, 4)
+        delta = 0.0 if case % 7 == 0 else a
+        r, jc, jl = np.zeros(4), np.zeros(24), np.zeros(16)
+        host_math.hm_obs_linearise(_dp(cam), _dp(line), _dp(obs), C.c_double(0.12), _dp(r), _dp(jc), _dp(jl))
+        R, JL = np.zeros(9), np.zeros(9)
+        host_math.hm_cam_prepare(_dp(cam), _dp(R), _dp(JL))
+        JL = JL.reshape(3, 3)
+        cost_std = C.c_double(0)
+        host_math.hm_huber.restype = C.c_double
+        sr = host_math.hm_huber(C.c_double(float(r @ r)), C.c_double(delta), C.byref(cost_std))
+        rs, jcr, jlr, cost = np.zeros(4), np.zeros(24), np.zeros(16), C.c_double(0)
+        host_math.hm_obs_linearise_raw(_dp(cam), _dp(line), _dp(obs), C.c_double(0.12), C.c_double(delta), _dp(sl), _dp(rs), _dp(jcr), _dp(jlr), C.byref(cost))
+        jc, jl, jcr, jlr = jc.reshape(4, 6), jl.reshape(4, 4), jcr.reshape(4, 6), jlr.reshape(4, 4)
+        scale = max(1.0, np.abs(jc).max(), np.abs(jl).max())
+        assert np.abs(rs - sr * r).max() < 1e-13 * max(1.0, np.abs(r).max())
+        assert abs(cost.value - cost_std.value) <= 1e-14 * max(cost_std.value, 1e-30)
+        assert np.abs(jcr[:, :3] @ JL - sr * jc[:, :3]).max() < 1e-11 * scale
+        assert np.abs(jcr[:, 3:] - sr * jc[:, 3:]).max() < 1e-11 * scale
+        assert np.abs(jlr - sr * jl * sl[None, :]).max() < 1e-11 * scale
+
+
 def test_backsub_contraction_matches_jacobians(host_math):
     """The back-substitution's w = J_l^T (J_c y_c), contracted on the fly (obs_backsub_w), equals the product of the
     explicit analytic Jacobians."""
@@ -213,7 +395,7 @@ def test_huber_corrector(host_math, oracle):
     assert f == 1.0 and cost.value == 0.5
 
 
-def _pack(host_math, w):
+def _pack(host_math, w, grouping=0):
     Cn, L = int(w["num_cameras"]), int(w["num_lines"])
     cam = np.ascontiguousarray(w["camera_index"], dtype=np.int32)
     line = np.ascontiguousarray(w["line_index"], dtype=np.int32)
@@ -228,10 +410,11 @@ def _pack(host_math, w):
     tiles = np.zeros(4 * max_tiles, dtype=np.int32)
     items = np.zeros(2 * max_items, dtype=np.uint8)
     lane_map = np.zeros(64 * max_tiles, dtype=np.uint16)
-    rc = host_math.hm_pack(Cn, L, M, _ip(cam), _ip(line), _ip(fixed), _dp(obs), _dp(prm), _ip(counts), _ip(lo), _ip(lp),
-                           _ip(oo), _ip(oc), _ip(tiles), items.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cf), max_tiles, max_items,
-                           lane_map.ctypes.data_as(C.POINTER(C.c_ushort)))
-    return rc, dict(Cf=int(counts[0]), ntiles=int(counts[1]), nitems=int(counts[2]), nfree=int(counts[3]), nkept=int(counts[4]),
+    desc = np.zeros(max(L, 1), dtype=np.uint32)
+    rc = host_math.hm_pack_g(Cn, L, M, _ip(cam), _ip(line), _ip(fixed), _dp(obs), _dp(prm), _ip(counts), _ip(lo), _ip(lp),
+                             _ip(oo), _ip(oc), _ip(tiles), items.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cf), max_tiles, max_items,
+                             lane_map.ctypes.data_as(C.POINTER(C.c_ushort)), grouping, desc.ctypes.data_as(C.POINTER(C.c_uint)))
+    return rc, dict(desc=desc[:L], Cf=int(counts[0]), ntiles=int(counts[1]), nitems=int(counts[2]), nfree=int(counts[3]), nkept=int(counts[4]),
                     line_order=lo[:L], line_ptr=lp, ob_orig=oo[:M], ob_cam=oc[:M], cam_cf=cf[:Cn],
                     tiles=tiles[:4 * int(counts[1])].reshape(-1, 4), items=items[:2 * int(counts[2])].reshape(-1, 2),
                     lane_map=lane_map[:64 * int(counts[1])].reshape(-1, 64))

@@ -12,7 +12,7 @@ from oracle import pyoracle as O     # noqa: E402  (developer tool: the oracle i
 
 
 
-def run(cases, seed=2026, verbose=True, oversize=False):
+def run(cases, seed=2026, verbose=True, oversize=False, hip_opt=None):
   rng = np.random.default_rng(seed)
   worst = {"cost": 0.0, "x": 0.0, "trace": 0.0}
   bad = 0
@@ -58,7 +58,7 @@ def run(cases, seed=2026, verbose=True, oversize=False):
           opt["max_num_iterations"] = int(rng.integers(0, 30))
       oo = {k: v for k, v in opt.items() if k != "huber_delta"}
       x0, s0, t0 = O.lba_solve(w, huber_delta=opt.get("huber_delta", 1.0 / 406.05), linear_solver=1, **oo)
-      x1, s1, t1 = capi.lba_solve(w, **opt)
+      x1, s1, t1 = capi.lba_solve(w, **opt, **(hip_opt or {}))
       ok = True
       n = min(len(t0), len(t1))
       dtr = max((abs(a["cost"] - b["cost"]) / max(abs(a["cost"]), 1e-300) for a, b in list(zip(t0, t1))[:min(n, 4)]), default=0.0)

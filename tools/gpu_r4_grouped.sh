@@ -3,7 +3,7 @@
 # both, and (PHASES=1) the phase stamps of the grouped sweep from a timing build made on the box
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
 TAG=${1:-r4g}
-timeout 900 python -m pytest tests/test_gpu_lba.py -x -q -m gpu -k "matrix_core" > gpurun_out/${TAG}_tests.log 2>&1; echo "pytest rc $?" >> gpurun_out/${TAG}_tests.log
+timeout 900 python -m pytest tests/test_gpu_lba.py -x -q -m gpu -k "matrix_core or grouped" > gpurun_out/${TAG}_tests.log 2>&1; echo "pytest rc $?" >> gpurun_out/${TAG}_tests.log
 tail -n 5 gpurun_out/${TAG}_tests.log
 for E in ${ELIMS:-0 4}; do
   timeout 600 python bench.py --steps 5 --warmup 2 --elim $E --no-cpu-baseline --no-overlap-run --no-extra-configs > gpurun_out/${TAG}_bench_e$E.json 2> gpurun_out/${TAG}_bench_e$E.err
