@@ -208,6 +208,7 @@ def cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank,
     allp = allp.cpu().numpy().reshape(world, width)
     allm = allm.cpu().numpy().reshape(world, -1)
     ids, crcs, equal, maxdiff = [], [], True, 0.0
+    elim_eff = batches[0].elimination() or elim          # the sweep the timed batches ran (the automatic choice depends on the batch size)
     for r in range(world):
         lo_r, ch, sizes = int(allm[r, 0]), [int(x) for x in allm[r, 1:1 + k]], [int(x) for x in allm[r, 1 + k:1 + 2 * k]]
         off = 0
@@ -216,7 +217,7 @@ def cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank,
             off += sizes[i]
             bt = capi.LBABatch(device=local_rank)
             bt.add(synth.make_window(lo_r + i, num_lines=lines))
-            bt.finalize(use_graph=0, chunks_per_window=ch[i], lba_elimination=elim)
+            bt.finalize(use_graph=0, chunks_per_window=ch[i], lba_elimination=elim_eff)
             bt.solve(); bt.download()
             mine = bt.parameters(0)
             bt.close()
@@ -226,7 +227,7 @@ def cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank,
                 equal = False
                 maxdiff = max(maxdiff, float(np.abs(got - mine).max()))
     return {"window_ids": ids, "crc32_of_gathered_parameters": crcs, "bitwise_equal_to_rank0_resolve": equal,
-            "max_abs_diff": maxdiff, "checked_per_rank": k,
+            "max_abs_diff": maxdiff, "checked_per_rank": k, "lba_elimination": elim_eff,
             "how": "first %d windows of every rank's shard: parameters all-gathered on the device, rank 0 solves the same ids in "
                    "1-window batches with the same chunk count and compares bytes" % k}
 
@@ -319,7 +320,9 @@ def main():
     ap.add_argument("--lines", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap-run", action="store_true", help="skip the informational two-stream measurement")
-    ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph (no per-kernel events)")
+    ap.add_argument("--graph", action="store_true", help="(default since round 4) time the captured hipGraph replay; kept for old command lines")
+    ap.add_argument("--eager", action="store_true", help="time eager launches with per-kernel hipEvents in the timed region (the round 1-3 mode)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="eager profiled steps after the timed region (per-kernel times, roofline)")
     ap.add_argument("--chunks", type=int, default=0, help="waves cooperating on one window (0 = library default)")
     ap.add_argument("--elim", type=int, default=0,
                     help="lba_elimination: 0 auto, 1 LDS-atomic sweep, 2 / 3 matrix-core sweep with 1 / 2 waves per chunk")
@@ -371,6 +374,7 @@ def main():
     B = args.windows
     lo, hi = shard_range(B * world, rank, world)
     windows = [synth.make_window(i, num_lines=args.lines) for i in range(lo, hi)]
+    use_graph = not args.eager          # the production launch mode: one hipGraph replay per solve (one host call, insensitive to a busy host)
     ns = max(1, min(args.streams, B))
     bstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
     batches, owner = [], []
@@ -379,8 +383,8 @@ def main():
         for wi in range(si, B, ns):
             bt.add(windows[wi])
             owner.append((wi, si, len(bt.sizes) - 1))
-        bt.finalize(use_graph=1 if args.graph else 0, chunks_per_window=args.chunks, lba_elimination=args.elim)
-        bt.set_profiling(not args.graph)
+        bt.finalize(use_graph=1 if use_graph else 0, chunks_per_window=args.chunks, lba_elimination=args.elim)
+        bt.set_profiling(not use_graph)
         batches.append(bt)
     where = {wi: (si, li) for wi, si, li in owner}
     counts = [(w["num_cameras"], w["num_free_cameras"], w["num_lines"], len(w["camera_index"])) for w in windows]
@@ -400,7 +404,7 @@ def main():
     torch.cuda.synchronize()
     for bt, st in zip(batches, bstreams):
         bt.iterations(st.cuda_stream, clear=True)
-        bt.set_profiling(not args.graph)          # drop warm-up events
+        bt.set_profiling(not use_graph)          # drop warm-up events
 
     barrier()
     t0 = time.perf_counter()
@@ -428,12 +432,24 @@ def main():
     elapsed = float(t.item())
     check = cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank, args.lines, args.elim) if not args.no_result_check else None
 
+    # ---- per-kernel times (roofline): outside the timed region, same process, same resident batches - a profiled pass of eager
+    # launches with hipEvents around every kernel (events recorded by graph nodes cannot be read back on this runtime).  The sum
+    # of the kernel times per step must agree with the graph-replay step measured above.
+    profile_steps = 0
+    if use_graph and args.profile_steps > 0:
+        for bt in batches:
+            bt.set_profiling(True)
+        profile_steps = args.profile_steps
+        for _ in range(profile_steps):
+            run_step()
+        torch.cuda.synchronize()
+
     # ---- second, informational measurement (not `value`): the same windows as two half-batches on two HIP
     # streams, each replaying its captured hipGraph, so that the latency-bound kernels of one half (reduced
     # solve, LM update) overlap the observation sweeps of the other.  Per-kernel durations are not comparable in
     # this mode (kernels of the two halves share the GPU), so the roofline numbers come from the region above.
     overlap = None
-    if ns == 1 and not args.graph and not args.no_overlap_run and B >= 2:
+    if ns == 1 and not args.no_overlap_run and B >= 2:
         ostreams = [torch.cuda.current_stream(), torch.cuda.Stream()]
         obatches = []
         for si in range(2):
@@ -488,7 +504,7 @@ def main():
                        "windows_per_gpu": B, "total_windows": B * world, "lines": args.lines,
                        "parallelism": "windows [0, %d) split contiguously over %d GPU(s) (shard_range), no data-path collective%s" % (
                            B * world, world, "; one all-gather of the results per step (%d MB)" % (gathered_bytes >> 20) if args.gather_results else ""),
-                       "launch": "hipGraph replay" if args.graph else "eager + hipEvents", "hip_streams": ns},
+                       "launch": "hipGraph replay" if use_graph else "eager + hipEvents", "hip_streams": ns},
             "lm_iterations": iters_total,
             "sum_initial_cost_rank0": init_cost, "sum_final_cost_rank0": final_cost,
             # multi-rank evidence: size of the communicator after init (RCCL when backend == "nccl"), distinct devices the ranks
@@ -512,7 +528,7 @@ def main():
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    if tj.get("lines") == args.lines:
+                    if tj.get("lines") == args.lines and tj.get("lba_elimination", 1) == batches[0].elimination():
                         traffic = tj.get("hbm_bytes_per_launch") * (B / ns) / tj.get("windows")
                         # NOT measured in this run: PMC counters need rocprofv3 around the process; the figure is the committed
                         # result of the separate --pmc passes (tools/gpu_r3_profile.sh), scaled to this batch size
@@ -521,19 +537,31 @@ def main():
                     traffic = None
             flops_launch = algorithmic_flops_linearise(windows) / ns
             tflops = flops_launch / (ms / n * 1e-3) / 1e12
-            out["roofline"] = {"bound": "hbm", "kernel": "k_linearise_schur", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            elim_eff = batches[0].elimination()
+            kname = {1: "k_linearise_schur<false, 0>", 2: "k_eliminate_mfma<1>", 3: "k_eliminate_mfma<2>", 4: "k_eliminate_grouped<false>"}.get(elim_eff, "?")
+            out["roofline"] = {"bound": "hbm", "kernel": kname, "lba_elimination": elim_eff, "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": ms / n, "launches": n,
                                # what actually bounds the kernel: fp64 issue at two waves per SIMD
                                # (256 VGPRs) - a v_fma_f64 stream reaches 48.5 TFLOP/s there, not the 78.6 of the spec -
                                # together with the LDS fp64 atomics of the per-wave partial system
-                               "binding": "fp64 VALU issue at 2 waves/SIMD (measured ceiling %.1f TFLOP/s) + LDS ds_add_f64" % FP64_MEASURED_CEILING_TFLOPS[2],
+                               "binding": ("fp64 issue at 2 waves/SIMD (v_fma_f64 stream: measured ceiling %.1f TFLOP/s) with the Schur products on v_mfma_f64_16x16x4_f64, whose 64 cycles each are not hidden behind the VALU work (DESIGN.md section 7d)" if elim_eff == 4 else
+                                           "fp64 VALU issue at 2 waves/SIMD (measured ceiling %.1f TFLOP/s) + LDS ds_add_f64") % FP64_MEASURED_CEILING_TFLOPS[2],
                                # secondary view: the kernel's arithmetic intensity (~28 flop / algorithmic byte) is above the
                                # fp64 ridge (78.6 TF / 8 TB/s ~ 10 flop / B), so the vector-fp64 roofline is the nearer one
                                "fp64_vector": {"algorithmic_flops_per_launch": flops_launch, "achieved": tflops,
                                                "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS}}
             out["roofline"]["fp64_vector"]["frac_of_measured_ceiling_2_waves_per_simd"] = tflops / FP64_MEASURED_CEILING_TFLOPS[2]
-            out["kernel_ms_per_step"] = {k: v[0] / max(args.steps, 1) for k, v in kt.items() if v[1] > 0}
+            ksteps = profile_steps if use_graph else args.steps
+            out["kernel_ms_per_step"] = {k: v[0] / max(ksteps, 1) for k, v in kt.items() if v[1] > 0}
+            ksum = sum(out["kernel_ms_per_step"].values())
+            out["kernel_times_from"] = ("%d eager profiled steps (hipEvents around every launch) after the timed region, same resident batch" % ksteps) if use_graph \
+                else "hipEvents in the timed region"
+            # the two views of a step must agree: kernels back to back inside one graph launch vs the same kernels timed one by one
+            out["launch_consistency"] = {"sum_kernel_ms_per_step": ksum, "timed_ms_per_step": out["ms_per_step"],
+                                         "ratio": ksum / out["ms_per_step"], "within_5_percent": abs(ksum / out["ms_per_step"] - 1.0) <= 0.05}
+            if not out["launch_consistency"]["within_5_percent"]:
+                print("bench.py: WARNING sum of kernel times %.3f ms vs timed step %.3f ms differ by more than 5 %%" % (ksum, out["ms_per_step"]), file=sys.stderr)
             bms, bn = kt["backsub"]
             if bn > 0:
                 bb = algorithmic_bytes_backsub(counts) / ns

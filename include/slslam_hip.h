@@ -188,6 +188,11 @@ int  slslam_lba_batch_counts(const slslam_lba_batch* b, long long* num_windows, 
  * the caller's before the call returns control of it: SLSLAM_PATH_MIXED. */
 enum { SLSLAM_PATH_TILED = 0, SLSLAM_PATH_FUSED_MOTION_ONLY = 1, SLSLAM_PATH_GLOBAL_MEMORY = 2, SLSLAM_PATH_MIXED = 3 };
 int  slslam_lba_batch_path(const slslam_lba_batch* b, int* path);
+/* After finalize: the elimination sweep the batch runs, as a value of slslam_solver_options.lba_elimination that reproduces it
+ * (1, 2, 3 or 4; never 0): what the automatic choice resolved to, or what the request fell back to.  A window's result depends on
+ * this value (the sweeps sum in different orders) - a caller that wants one window of a large batch again, bit for bit, in a batch
+ * of its own passes it back together with the window's chunk count.  0 for batches that do not take the tiled sweeps. */
+int  slslam_lba_batch_elimination(const slslam_lba_batch* b, int* mode);
 /* After finalize: the number of chunks (waves cooperating on the window's observation sweeps) window `index` was cut into.  A
  * window's result is a function of its inputs, the options and this number only (the chunk partials are summed in chunk order):
  * a window solved again with chunks_per_window set to it - in any batch that keeps the chunk count at 8 or below, or above 8 -

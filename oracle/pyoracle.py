@@ -11,10 +11,14 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+if os.environ.get("SLSLAM_ORACLE_LIB"):          # tests/test_sanitizers.py: the same sources built with -fsanitize=address,undefined
+    _LIB_PATH = os.environ["SLSLAM_ORACLE_LIB"]
 
 
 def build(force=False):
     """Compile the C restatement with gcc (building the checker is not using it)."""
+    if os.environ.get("SLSLAM_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("lm_core.c", "lba_oracle.c", "po_oracle.c", "ransac_oracle.c", "jet_impl.h", "lm_core.h", "slslam_oracle.h")):

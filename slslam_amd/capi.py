@@ -81,7 +81,7 @@ EXPORTS = [
     "slslam_default_options", "slslam_lba_solve", "slslam_lba_batch_create", "slslam_lba_batch_destroy",
     "slslam_lba_batch_add", "slslam_lba_batch_finalize", "slslam_lba_batch_solve", "slslam_lba_batch_reset",
     "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
-    "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts", "slslam_lba_batch_window_chunks", "slslam_lba_batch_path",
+    "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts", "slslam_lba_batch_window_chunks", "slslam_lba_batch_path", "slslam_lba_batch_elimination",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
     "slslam_po_solve", "slslam_po_structure", "slslam_po_set_profiling", "slslam_po_last_timing", "slslam_debug_phase_cycles", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_release_cached_memory", "slslam_version", "slslam_status_string",
 ]
@@ -117,6 +117,7 @@ def lib():
     L.slslam_lba_batch_counts.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 5
     L.slslam_lba_batch_window_chunks.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.slslam_lba_batch_path.argtypes = [vp, C.POINTER(C.c_int)]
+    L.slslam_lba_batch_elimination.argtypes = [vp, C.POINTER(C.c_int)]
     L.slslam_lba_batch_iterations.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.c_int]
     L.slslam_lba_batch_set_profiling.argtypes = [vp, C.c_int]
     L.slslam_lba_batch_kernel_times.argtypes = [vp, dp, ip]
@@ -285,6 +286,12 @@ class LBABatch:
     def path(self):
         v = C.c_int(-1)
         _check(lib().slslam_lba_batch_path(self._h, C.byref(v)), "slslam_lba_batch_path")
+        return v.value
+
+    def elimination(self):
+        """The lba_elimination value that reproduces the sweep this batch runs (what the automatic choice resolved to)."""
+        v = C.c_int(-1)
+        _check(lib().slslam_lba_batch_elimination(self._h, C.byref(v)), "slslam_lba_batch_elimination")
         return v.value
 
     def window_chunks(self, i):

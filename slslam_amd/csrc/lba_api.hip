@@ -1092,6 +1092,13 @@ extern "C" int slslam_lba_batch_counts(const slslam_lba_batch* b, long long* nw,
   return SLSLAM_OK;
 }
 
+extern "C" int slslam_lba_batch_elimination(const slslam_lba_batch* b, int* mode) {
+  if (!b || !mode || !b->finalized) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (b->part[0]) return slslam_lba_batch_elimination(b->part[0], mode);
+  *mode = (b->big_mode || b->fused_motion_only) ? 0 : b->elim_mode == 0 ? 1 : b->elim_grouped ? 4 : b->elim_waves == 2 ? 3 : 2;
+  return SLSLAM_OK;
+}
+
 extern "C" int slslam_lba_batch_path(const slslam_lba_batch* b, int* path) {
   if (!b || !path || !b->finalized) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (b->part[0]) { *path = SLSLAM_PATH_MIXED; return SLSLAM_OK; }

@@ -27,14 +27,16 @@ def host_math():
     import ctypes as C
     src = os.path.join(ROOT, "tests", "host_math", "host_math.cpp")
     out_dir = os.path.join(ROOT, "tests", "_build")
-    out = os.path.join(out_dir, "libhost_math.so")
+    san = bool(os.environ.get("SLSLAM_SANITIZE"))          # tests/test_sanitizers.py: the packer and the math headers under ASan + UBSan
+    out = os.path.join(out_dir, "libhost_math_asan.so" if san else "libhost_math.so")
     deps = [src, os.path.join(ROOT, "slslam_amd", "csrc", "lba_math.h"), os.path.join(ROOT, "slslam_amd", "csrc", "lba_pack.cpp"),
             os.path.join(ROOT, "slslam_amd", "csrc", "lba_pack.h"), os.path.join(ROOT, "slslam_amd", "csrc", "lba_types.h"),
             os.path.join(ROOT, "slslam_amd", "csrc", "lba_eliminate_grouped_maps.h"), os.path.join(ROOT, "slslam_amd", "csrc", "lba_eliminate_mfma_maps.h"),
             os.path.join(ROOT, "slslam_amd", "csrc", "lba_gram.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(out_dir, exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src,
+        flags = ["-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"] if san else ["-O2"]
+        subprocess.check_call(["g++"] + flags + ["-std=c++17", "-shared", "-fPIC", "-o", out, src,
                                os.path.join(ROOT, "slslam_amd", "csrc", "lba_pack.cpp")])
     return C.CDLL(out)
 

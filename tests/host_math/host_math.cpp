@@ -68,6 +68,8 @@ void hm_obs_linearise_raw(const double* cam, const double* line, const double* o
 // ---- pack inspection (host-only code of the product, lba_pack.cpp)
 #include "../../slslam_amd/csrc/lba_pack.h"
 #include <cstring>
+// (memcpy with a null source is undefined even for zero bytes: an empty vector's data() may be null)
+static void copy_bytes(void* dst, const void* src, size_t n) { if (n) std::memcpy(dst, src, n); }
 extern "C" {
 int hm_pack_g(int C, int L, int M, const int* cam, const int* line, const int* fixed, const double* obs, double* params,
               int* out_counts, int* line_order, int* line_ptr, int* ob_orig, int* ob_cam, int* tiles, unsigned char* items, int* cam_cf,
@@ -95,21 +97,21 @@ int hm_pack_g(int C, int L, int M, const int* cam, const int* line, const int* f
     if (rc) return rc;
     P = Q;
   }
-  if (line_desc) std::memcpy(line_desc, P.line_desc.data(), sizeof(unsigned) * L);
+  if (line_desc) copy_bytes(line_desc, P.line_desc.data(), sizeof(unsigned) * L);
   if ((int)P.tiles.size() > max_tiles || (int)P.items.size() / 2 > max_items) return -1;
   out_counts[0] = P.Cf; out_counts[1] = (int)P.tiles.size(); out_counts[2] = (int)P.items.size() / 2;
   out_counts[3] = P.nfree_params; out_counts[4] = P.nkept;
-  std::memcpy(line_order, P.line_order.data(), sizeof(int) * L);
-  std::memcpy(line_ptr, P.line_ptr.data(), sizeof(int) * (L + 1));
-  std::memcpy(ob_orig, P.ob_orig.data(), sizeof(int) * M);
-  std::memcpy(ob_cam, P.ob_cam.data(), sizeof(int) * M);
-  std::memcpy(cam_cf, P.cam_cf.data(), sizeof(int) * C);
+  copy_bytes(line_order, P.line_order.data(), sizeof(int) * L);
+  copy_bytes(line_ptr, P.line_ptr.data(), sizeof(int) * (L + 1));
+  copy_bytes(ob_orig, P.ob_orig.data(), sizeof(int) * M);
+  copy_bytes(ob_cam, P.ob_cam.data(), sizeof(int) * M);
+  copy_bytes(cam_cf, P.cam_cf.data(), sizeof(int) * C);
   for (size_t t = 0; t < P.tiles.size(); ++t) {
     tiles[4 * t] = P.tiles[t].line_begin; tiles[4 * t + 1] = P.tiles[t].nlines;
     tiles[4 * t + 2] = P.tiles[t].flags; tiles[4 * t + 3] = P.tiles[t].nitems;
   }
-  std::memcpy(items, P.items.data(), P.items.size());
-  std::memcpy(lane_map, P.lane_map.data(), P.lane_map.size() * sizeof(unsigned short));
+  copy_bytes(items, P.items.data(), P.items.size());
+  copy_bytes(lane_map, P.lane_map.data(), P.lane_map.size() * sizeof(unsigned short));
   return 0;
 }
 }

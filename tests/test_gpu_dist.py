@@ -30,7 +30,7 @@ else:
     dist.init_process_group("gloo", rank=rank, world_size=world)
 sizes = %(sizes)r
 mk = lambda i: synth.make_window(500 + i, num_lines=sizes[i], num_kf=12, num_free=6)
-r = solve_shard(mk, len(sizes), rank, world, 0, gather=(backend == "nccl" or world == 1))
+r = solve_shard(mk, len(sizes), rank, world, 0, gather=(backend == "nccl" or world == 1), chunks_per_window=int(os.environ.get("TEST_CHUNKS", "0")))
 lo, hi = r["range"]
 local = np.concatenate([r["batch"].parameters(i - lo) for i in range(lo, hi)]) if hi > lo else np.zeros(0)
 out = {"rank": rank, "range": [lo, hi], "iterations": r["iterations"], "initial_cost": r["initial_cost"], "final_cost": r["final_cost"],
@@ -44,14 +44,14 @@ dist.destroy_process_group()
 """
 
 
-def _run(world, backend):
+def _run(world, backend, chunks=0):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   TEST_BACKEND=backend, TEST_CHUNKS=str(chunks), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT, "sizes": SIZES}], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -84,13 +84,46 @@ def test_world_size_one_through_rccl(hip):
 
 def test_two_ranks_on_one_gpu_match_one_rank(hip):
     """Two ranks, contiguous shards (`shard_range`), both solving on the one visible GPU: the concatenated results are
-    bitwise those of the one-rank run (windows are independent; a window's chunking does not depend on its batch here
-    because every batch is small), the all-reduced summary is the same."""
-    (one,) = _run(1, "gloo")
-    two = _run(2, "gloo")
+    BITWISE those of the one-rank run (1 / 2 / 4 / 8-rank runs give bit-identical per-window results).  A
+    window's result is a function of its inputs, the options and the number of chunks it is cut into (the chunk partials are
+    summed in chunk order); the library's automatic chunk count depends on the batch a window keeps company with, so the job
+    fixes it (chunks_per_window) - what a multi-rank caller that wants rank-count-independent bytes does.  The all-reduced
+    summary is the same on every rank."""
+    (one,) = _run(1, "gloo", chunks=4)
+    two = _run(2, "gloo", chunks=4)
     assert [o["range"] for o in two] == [[0, 3], [3, 6]]
     both = np.concatenate([np.array(o["local"]) for o in two])
-    assert np.abs(both - np.array(one["local"])).max() < 1e-9
+    assert np.array_equal(both, np.array(one["local"]))
     for o in two:
         assert o["iterations"] == one["iterations"]
         assert abs(o["final_cost"] - one["final_cost"]) <= 1e-12 * one["final_cost"]
+
+
+def test_bench_two_ranks_shared_gpu(hip):
+    """The N > 1 path of the bench line itself (what the driver launches on an 8-GPU node), two ranks sharing the one visible GPU:
+    `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with the gloo rendezvous (RCCL refuses two ranks on one
+    device).  Checks what a first multi-GPU run must show: both ranks in the communicator, one clock per rank, the window ids of the
+    cross-rank check spanning both shards, and the all-gathered results of BOTH ranks equal, byte for byte, to rank 0's re-solve of
+    the same window ids in one-window batches (same chunk count, same elimination sweep)."""
+    import json
+    import socket as _s
+    with _s.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SLSLAM_BENCH_SHARE_GPU="1", SLSLAM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    windows, lines = 24, 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--windows", str(windows), "--lines", str(lines), "--no-cpu-baseline", "--no-overlap-run", "--no-extra-configs"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["collective_backend"] == "gloo"
+    assert len(d["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in d["per_rank_ms_per_step"])
+    assert d["config"]["total_windows"] == 2 * windows and d["scaling"] == "weak"
+    chk = d["results_check"]
+    ids = chk["window_ids"]
+    assert min(ids) == 0 and max(ids) >= windows and len(ids) == 2 * chk["checked_per_rank"]      # both shards: [0, 24) and [24, 48)
+    assert chk["bitwise_equal_to_rank0_resolve"] is True, chk
+    assert d["lm_iterations"] > 0 and d["value"] > 0

@@ -11,6 +11,8 @@ from slslam_amd import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "slslam_amd", "host")
 LIBDIR = os.path.join(ROOT, "slslam_amd", "_lib")
+# (tests/test_sanitizers.py points this at the -fsanitize=address,undefined build of the same sources)
+HOST_LIB = os.environ.get("SLSLAM_HOST_LIB") or os.path.join(LIBDIR, "libslslam_host.so")
 DEMO = os.path.join(ROOT, "tests", "_build", "drop_in_demo")
 
 
@@ -86,7 +88,7 @@ def test_gc_boundary_encodings_match_numpy_restatement():
     oracle's copy: pose <-> (w,t), SE(3) algebra, line transforms, orthonormal encode/decode."""
     import ctypes as C
     subprocess.check_call(["make", "-s", "-C", HOST])
-    lib = C.CDLL(os.path.join(LIBDIR, "libslslam_host.so"))
+    lib = C.CDLL(HOST_LIB)
 
     class Pose(C.Structure):
         _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3)]
@@ -215,7 +217,7 @@ def test_window_packer_reproduces_the_array_contract(oracle):
     result back into the map."""
     import ctypes as C
     subprocess.check_call(["make", "-s", "-C", HOST])
-    lib = C.CDLL(os.path.join(LIBDIR, "libslslam_host.so"))
+    lib = C.CDLL(HOST_LIB)
     w = synth.make_window(8, num_lines=60, num_kf=12, num_free=5)
     kfs, lms, Packed, keep, slot_to_kf = _map_from_window(w, lib, C)
     pk = Packed()
@@ -256,7 +258,7 @@ def test_window_packer_reproduces_the_array_contract(oracle):
 def _host_lib():
     import ctypes as C
     subprocess.check_call(["make", "-s", "-C", HOST])
-    return C, C.CDLL(os.path.join(LIBDIR, "libslslam_host.so"))
+    return C, C.CDLL(HOST_LIB)
 
 
 def test_trajectory_writer_reproduces_the_reference_files():
@@ -402,7 +404,7 @@ def test_pose_graph_packer_reproduces_the_array_contract(oracle):
     the edges' relative poses."""
     import ctypes as C
     subprocess.check_call(["make", "-s", "-C", HOST])
-    lib = C.CDLL(os.path.join(LIBDIR, "libslslam_host.so"))
+    lib = C.CDLL(HOST_LIB)
 
     class Pose(C.Structure):
         _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3)]
@@ -468,7 +470,7 @@ def test_motion_only_packer_reproduces_the_array_contract(oracle):
     synthetic motion-only window they were taken apart from; slslam_unpack_motion_only returns camera 0."""
     import ctypes as C
     subprocess.check_call(["make", "-s", "-C", HOST])
-    lib = C.CDLL(os.path.join(LIBDIR, "libslslam_host.so"))
+    lib = C.CDLL(HOST_LIB)
 
     class Pose(C.Structure):
         _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3)]

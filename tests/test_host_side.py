@@ -525,6 +525,27 @@ def test_pack_long_and_short_lines(host_math):
         assert max(ks) < 4 or min(ks) >= 4                     # short lines never share a tile with the others
 
 
+@pytest.mark.parametrize("nfree", [21, 40, 45])
+def test_pack_oversize_windows(host_math, nfree):
+    """Windows beyond the tiled sweeps (more than 20 free cameras: the reference's W = 40 study) go through the same packer
+    (validation, constness, free indices, observations grouped by line with the free cameras first) and come out without tiles
+    or pair items: the global-memory path builds its own gather lists.  (Also run under ASan / UBSan: tests/test_sanitizers.py.)"""
+    w = synth.make_window(40 + nfree, num_lines=50, num_kf=2 * nfree, num_free=nfree, mean_track=30.0)
+    rc, P = _pack(host_math, w)
+    L, M = int(w["num_lines"]), len(w["camera_index"])
+    assert rc == 0 and P["Cf"] == nfree and P["ntiles"] == 0 and P["nitems"] == 0
+    assert np.array_equal(P["line_order"], np.arange(L)) and sorted(P["ob_orig"].tolist()) == list(range(M))
+    assert P["nfree"] == 6 * nfree + 4 * L and P["nkept"] == M
+    for s_ in range(L):
+        sel = P["ob_orig"][P["line_ptr"][s_]:P["line_ptr"][s_ + 1]]
+        assert np.all(np.asarray(w["line_index"])[sel] == s_)
+        cf = P["cam_cf"][np.asarray(w["camera_index"])[sel]]
+        nf = int((cf >= 0).sum())
+        assert np.all(cf[:nf] >= 0) and np.all(cf[nf:] < 0) and np.all(np.diff(cf[:nf]) >= 0)
+    rc2, P2 = _pack(host_math, w, grouping=1)               # asking for the grouped order changes nothing for such a window
+    assert rc2 == 0 and P2["ntiles"] == 0 and np.array_equal(P2["line_order"], P["line_order"]) and np.array_equal(P2["ob_orig"], P["ob_orig"])
+
+
 def test_pack_edge_cases(host_math):
     # motion-only shape: lines constant -> no elimination work items, 1 free camera
     rc, P = _pack(host_math, synth.make_motion_only(1, num_lines=25))
