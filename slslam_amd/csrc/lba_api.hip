@@ -303,7 +303,29 @@ extern "C" int slslam_lba_batch_add(slslam_lba_batch* b, const slslam_lba_window
 
 namespace {
 // A mixed batch: the ordinary windows and the oversize ones become two batches of their own (same device, same options).
+int finalize_mixed_impl(slslam_lba_batch* b);
+// (a failed attempt leaves the batch as it was before the call: the windows go back to it in their order, the parts are destroyed)
 int finalize_mixed(slslam_lba_batch* b) {
+  if (b->part[0] || b->part[1]) return SLSLAM_ERR_STATE;
+  const int rc = finalize_mixed_impl(b);
+  if (rc == SLSLAM_OK) return rc;
+  std::vector<PackedWindow> back(b->route.size());
+  for (size_t i = 0; i < b->route.size(); ++i) {
+    slslam_lba_batch* pb = b->part[b->route[i].first];
+    if (pb && (size_t)b->route[i].second < pb->wins.size()) back[i] = std::move(pb->wins[(size_t)b->route[i].second]);
+  }
+  if (b->wins.empty() && !b->route.empty()) b->wins = std::move(back);
+  for (int h = 0; h < 2; ++h) {
+    if (b->part[h]) { slslam_lba_batch_destroy(b->part[h]); b->part[h] = nullptr; }
+    b->d_part_out[h].release(); b->part_param_off[h].clear();
+  }
+  if (b->part_stream) { (void)hipStreamDestroy(b->part_stream); b->part_stream = nullptr; }
+  if (b->part_fork) { (void)hipEventDestroy(b->part_fork); b->part_fork = nullptr; }
+  if (b->part_join) { (void)hipEventDestroy(b->part_join); b->part_join = nullptr; }
+  b->route.clear(); b->finalized = false;
+  return rc;
+}
+int finalize_mixed_impl(slslam_lba_batch* b) {
   int rc;
   for (int h = 0; h < 2; ++h)
     if ((rc = slslam_lba_batch_create(b->device, &b->part[h])) != SLSLAM_OK) return rc;
@@ -333,8 +355,10 @@ template <typename Fn>
 int on_both_parts(slslam_lba_batch* b, hipStream_t s, Fn fn) {
   HIP_TRY(hipEventRecord(b->part_fork, s));
   HIP_TRY(hipStreamWaitEvent(b->part_stream, b->part_fork, 0));
-  int rc = fn(b->part[1], (void*)b->part_stream);
-  if (rc == SLSLAM_OK) rc = fn(b->part[0], (void*)s);
+  // (the ordinary windows first: a long solve synchronises its stream every 16 iterations, and the part enqueued second only
+  // starts once the first has been enqueued to the end)
+  int rc = fn(b->part[0], (void*)s);
+  if (rc == SLSLAM_OK) rc = fn(b->part[1], (void*)b->part_stream);
   HIP_TRY(hipEventRecord(b->part_join, b->part_stream));
   HIP_TRY(hipStreamWaitEvent(s, b->part_join, 0));
   return rc;
@@ -578,6 +602,9 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     // gather lists of the global-memory path (lba_big.h): per camera its observations, per (window, camera pair r >= c) the
     // observation pairs of the lines both cameras see - every sum is walked in list order, so results are reproducible
     if (B > 0xffff) return SLSLAM_ERR_UNSUPPORTED;
+    // a camera-pair descriptor packs (window, row camera, column camera) as wi | r << 16 | c << 24, decoded with & 0xff (lba_big.h):
+    // more than 127 free cameras would spill into the next field (and shift into the sign bit)
+    for (const PackedWindow& P : b->wins) if (P.Cf > 127) return SLSLAM_ERR_UNSUPPORTED;
     long long sys_cursor = 0, linv_cursor = 0, oc = 0, lc = 0;
     b->h_big_sys_off.resize(B); b->h_big_linv_off.resize(B);
     big_ob_line.reserve((size_t)nobs);
