@@ -186,7 +186,9 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
         for (int r = 0; r < 4; ++r) ga += Jl[4 * r + a] * rs[r];
         v[10 + a] = ga;
       }
-      seg_sum_n<14, false, true>(v, sg);
+      // (the run totals come back through ds_bpermute: this sweep's LDS pipe is lightly loaded - unlike the LDS-atomic sweep's, which
+      // moves them on the VALU - and 28 of them are cheaper than four rounds of 28 selects; measured 1.235 -> 1.224 ms)
+      seg_sum_n<14, false, false>(v, sg);
 #pragma unroll
       for (int i = 0; i < 10; ++i) H[i] = v[i];
 #pragma unroll
@@ -253,7 +255,6 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
 
     // ---- row a of the observation's blocks: h = J_c'[:, a]^T J_l (1x4), F[a] = h K^T to the panel, b'[a] = g'[a] - h z, and the
     // camera record (J_c'^T J_c' lower triangle, g', b'); after a rejected step the slab keeps J_c'^T J_c' and g'.
-    // (skewed adds: see the diagonal block of k_linearise_schur)
     SLS_K1_STAMP(3);
     SLS_PHASE("f_rows");
     {
@@ -261,13 +262,9 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
 #pragma unroll
       for (int q = 0; q < 12; ++q) { const double2 v2 = reinterpret_cast<const double2*>(slabF)[q]; Jc[2 * q] = v2.x; Jc[2 * q + 1] = v2.y; }
       double* rec = diag + (cam_free ? cf : 0) * kDiagRec;
-      const bool skew = tc.skew;
-      double pval = 0.0;
-      int poff = kDiagB;
-      auto emit = [&](int off, double val) {
-        if (cam_free) lds_add_rec(rec + (skew ? poff : off), skew ? pval : val);
-        pval = val; poff = off;
-      };
+      // (no skewed adds here - the packer's flag for lanes of a row that share a camera, see the diagonal block of
+      // k_linearise_schur: with a third of that sweep's LDS atomics left it measures neutral, 1.224 / 1.222 ms)
+      auto emit = [&](int off, double val) { if (cam_free) lds_add_rec(rec + off, val); };
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         double ga = 0.0, h[4] = { 0.0, 0.0, 0.0, 0.0 };
@@ -296,7 +293,6 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
           }
         }
       }
-      if (skew && cam_free) lds_add_rec(rec + poff, pval);       // the marked lanes' last entry
     }
 
     SLS_K1_STAMP(4);
