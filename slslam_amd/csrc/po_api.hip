@@ -5,8 +5,10 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/slslam_hip.h"
@@ -139,6 +141,43 @@ extern "C" int slslam_po_last_timing(double* total_ms, double* factor_ms, int* f
   return SLSLAM_OK;
 }
 
+namespace {
+// Blocked right-looking Cholesky of an nb-block matrix: the first diagonal block, then ONE launch per block step (k_po_step:
+// panel solve + trailing update + the next diagonal block's factorisation; three launches per step until round 4).
+template <typename T>
+void po_factor_dense(PoPtrs& pp, T* A, T* Lf, T* linv, int nb) {
+  if (nb <= 0) return;
+  static const bool old_chain = std::getenv("SLSLAM_PO_LAUNCH_CHAIN") != nullptr;     // timing comparisons only: the round 1-3 chain
+  if (old_chain) {
+    for (int bk = 0; bk < nb; ++bk) {
+      const int tb = nb - 1 - bk;
+      hipLaunchKernelGGL(k_po_potrf_diag<T>, dim3(1), dim3(256), 0, 0, pp, A, linv + (size_t)bk * kNB * kNB, bk * kNB, (T*)nullptr);
+      if (tb > 0) {
+        hipLaunchKernelGGL(k_po_panel_update<T>, dim3((unsigned)tb), dim3(256), 0, 0, pp, A, (const T*)(linv + (size_t)bk * kNB * kNB), bk * kNB, 0);
+        hipLaunchKernelGGL(k_po_panel_update<T>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, pp, A, (const T*)(linv + (size_t)bk * kNB * kNB), bk * kNB, 1);
+      }
+    }
+    // (in place: the caller's substitution reads Lf)
+    (void)hipMemcpyAsync(Lf, A, sizeof(T) * (size_t)pp.n * pp.ld, hipMemcpyDeviceToDevice, 0);
+    return;
+  }
+  hipLaunchKernelGGL(k_po_potrf_diag<T>, dim3(1), dim3(256), 0, 0, pp, A, linv, 0, Lf);
+  for (int bk = 0; bk + 1 < nb; ++bk) {
+    const int tb = nb - 1 - bk;
+    hipLaunchKernelGGL(k_po_step<T>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), kPoStepLdsTiles * kNB * kLdT * sizeof(T), 0, pp, A, Lf, linv, bk);
+  }
+}
+// (k_po_step keeps three 64 x 66 tiles in dynamic LDS: 101 KB of doubles - above the 64 KB a kernel gets without asking)
+hipError_t po_step_lds_attributes() {
+  static bool done = false;
+  if (done) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void*)k_po_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPoStepLdsTiles * kNB * kLdT * sizeof(double)));
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_po_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPoStepLdsTiles * kNB * kLdT * sizeof(float)));
+  done = e == hipSuccess;
+  return e;
+}
+}  // namespace
+
 extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_options* opt_in,
                                slslam_summary* summary, slslam_iteration* trace, int trace_cap, int* trace_len) {
   if (!g) return SLSLAM_ERR_INVALID_ARGUMENT;
@@ -201,7 +240,11 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   const int nblk_j = (nj + kNB - 1) / kNB;
   int *d_p1 = nullptr, *d_p2 = nullptr, *d_slot = nullptr;
   double *d_cons = nullptr, *d_linv = nullptr;
-  float *d_Hf = nullptr, *d_linvf = nullptr;
+  float *d_Hf = nullptr, *d_linvf = nullptr, *d_Lff = nullptr;
+  double* d_Lf = nullptr;             // the Cholesky factor (k_po_step keeps it apart from the matrix it updates)
+  unsigned* d_tri_flags = nullptr;    // k_po_trisolve_wide: one progress word per 64-row block
+  unsigned tri_epoch = 1;
+  int num_cus = 0;
   LMState hst;
   std::vector<IterRec> htrace(kMaxTrace);
   std::vector<double> x2((size_t)12 * N), ones((size_t)(n > 0 ? n : 1), 1.0);
@@ -218,6 +261,8 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
                  o_cons = take(sizeof(double) * 6 * E), o_x = take(sizeof(double) * 12 * (N > 0 ? N : 1)), o_scale = take(sizeof(double) * nn),
                  o_H = take(hbytes), o_g = take(sizeof(double) * nn), o_d2 = take(sizeof(double) * nn), o_y = take(sizeof(double) * nn),
                  o_linv = take(sizeof(double) * nb2), o_Hf = take(f32 ? sizeof(float) * (size_t)(n > 0 ? n : 1) * ld : 0),
+                 o_Lf = take(f32 ? 0 : hbytes), o_Lff = take(f32 ? sizeof(float) * (size_t)(n > 0 ? n : 1) * ld : 0),
+                 o_tri = take(sizeof(unsigned) * (size_t)(nblk + 1)),
                  o_linvf = take(f32 ? sizeof(float) * nb2 : 0), o_scal = take(sizeof(double) * 8), o_flags = take(sizeof(int) * 2),
                  o_st = take(sizeof(LMState)), o_trace = take(sizeof(IterRec) * kMaxTrace), o_chains = take(sizeof(PoChain) * (chains.size() + 1));
     arena_bytes = off;
@@ -226,7 +271,9 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     d_p1 = (int*)(arena + o_p1); d_p2 = (int*)(arena + o_p2); d_slot = (int*)(arena + o_slot); d_cons = (double*)(arena + o_cons);
     p.x = (double*)(arena + o_x); p.scale = (double*)(arena + o_scale); p.H = (double*)(arena + o_H); p.g = (double*)(arena + o_g);
     p.d2 = (double*)(arena + o_d2); p.y = (double*)(arena + o_y); d_linv = (double*)(arena + o_linv);
-    if (f32) { d_Hf = (float*)(arena + o_Hf); d_linvf = (float*)(arena + o_linvf); }
+    if (f32) { d_Hf = (float*)(arena + o_Hf); d_linvf = (float*)(arena + o_linvf); d_Lff = (float*)(arena + o_Lff); }
+    else d_Lf = (double*)(arena + o_Lf);
+    d_tri_flags = (unsigned*)(arena + o_tri);
     p.scal = (double*)(arena + o_scal); p.flags = (int*)(arena + o_flags); p.st = (LMState*)(arena + o_st);
     p.trace = (IterRec*)(arena + o_trace); d_chains = (PoChain*)(arena + o_chains);
   }
@@ -244,6 +291,8 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   PO_TRY(hipMemset(p.trace, 0, sizeof(IterRec) * kMaxTrace));
   PO_TRY(hipMemset(p.scal, 0, sizeof(double) * 8));
   PO_TRY(hipMemset(p.flags, 0, sizeof(int) * 2));
+  PO_TRY(hipMemset(d_tri_flags, 0, sizeof(unsigned) * (size_t)(nblk + 1)));
+  (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, arena_device);
   p.p1 = d_p1; p.p2 = d_p2; p.cons = d_cons; p.slot = d_slot;
   p.N = N; p.E = E; p.n = n; p.ld = ld;
   pj = p;                                  // the junction block as a matrix of its own (same leading dimension)
@@ -252,6 +301,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     PO_TRY(hipMemcpy(d_chains, chains.data(), sizeof(PoChain) * chains.size(), hipMemcpyHostToDevice));
   }
 
+  if (po_step_lds_attributes() != hipSuccess) { PO_TRY(hipErrorInvalidValue); }
   stamp(); stamp();                       // [1] is re-recorded at the end
   // ---- initial evaluation: cost, gradient, column norms -> Jacobi scale
   PO_TRY(hipMemsetAsync(p.H, 0, hbytes, 0));
@@ -275,40 +325,24 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     if (structured) {
       // chains eliminated concurrently, then the dense MFMA Cholesky of the junction block only
       if (!chains.empty()) hipLaunchKernelGGL(k_po_chain_eliminate, dim3((unsigned)chains.size()), dim3(64), 0, 0, p, (const PoChain*)d_chains);
-      for (int bk = 0; bk < nblk_j; ++bk) {
-        const int k0 = bk * kNB;
-        const int rem = nj - (k0 + kNB);
-        const int tb = rem > 0 ? (rem + kNB - 1) / kNB : 0;
-        hipLaunchKernelGGL(k_po_potrf_diag<double>, dim3(1), dim3(256), 0, 0, pj, pj.H, d_linv + (size_t)bk * kNB * kNB, k0);
-        if (tb > 0) {
-          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)tb), dim3(256), 0, 0, pj, pj.H, (const double*)(d_linv + (size_t)bk * kNB * kNB), k0, 0);
-          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, pj, pj.H, (const double*)(d_linv + (size_t)bk * kNB * kNB), k0, 1);
-        }
-      }
-      if (nj > 0) hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(1024), 0, 0, pj, (const double*)pj.H, (const double*)d_linv);
+      double* Lf_j = d_Lf + (size_t)n_chain * ld + n_chain;          // the junction block's factor (same leading dimension)
+      po_factor_dense<double>(pj, pj.H, Lf_j, d_linv, nblk_j);
+      if (nj > 0) hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(1024), 0, 0, pj, (const double*)Lf_j, (const double*)d_linv);
       if (!chains.empty()) hipLaunchKernelGGL(k_po_chain_backsub, dim3((unsigned)chains.size()), dim3(64), 0, 0, p, (const PoChain*)d_chains);
     }
-    for (int bk = 0; bk < (structured ? 0 : nblk); ++bk) {
-      const int k0 = bk * kNB;
-      const int rem = n - (k0 + kNB);
-      const int tb = rem > 0 ? (rem + kNB - 1) / kNB : 0;
-      if (f32) {
-        hipLaunchKernelGGL(k_po_potrf_diag<float>, dim3(1), dim3(256), 0, 0, p, d_Hf, d_linvf + (size_t)bk * kNB * kNB, k0);
-        if (tb > 0) {
-          hipLaunchKernelGGL(k_po_panel_update<float>, dim3((unsigned)tb), dim3(256), 0, 0, p, d_Hf, (const float*)(d_linvf + (size_t)bk * kNB * kNB), k0, 0);
-          hipLaunchKernelGGL(k_po_panel_update<float>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, p, d_Hf, (const float*)(d_linvf + (size_t)bk * kNB * kNB), k0, 1);
-        }
-      } else {
-        hipLaunchKernelGGL(k_po_potrf_diag<double>, dim3(1), dim3(256), 0, 0, p, p.H, d_linv + (size_t)bk * kNB * kNB, k0);
-        if (tb > 0) {
-          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)tb), dim3(256), 0, 0, p, p.H, (const double*)(d_linv + (size_t)bk * kNB * kNB), k0, 0);
-          hipLaunchKernelGGL(k_po_panel_update<double>, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, 0, p, p.H, (const double*)(d_linv + (size_t)bk * kNB * kNB), k0, 1);
-        }
-      }
+    if (!structured) {
+      if (f32) po_factor_dense<float>(p, d_Hf, d_Lff, d_linvf, nblk);
+      else po_factor_dense<double>(p, p.H, d_Lf, d_linv, nblk);
     }
     if (structured) { /* solved above */ }
-    else if (f32) hipLaunchKernelGGL(k_po_trisolve<float>, dim3(1), dim3(1024), 0, 0, p, (const float*)d_Hf, (const float*)d_linvf);
-    else hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(1024), 0, 0, p, (const double*)p.H, (const double*)d_linv);
+    else if (nblk >= 4 && nblk <= num_cus && !std::getenv("SLSLAM_PO_LAUNCH_CHAIN")) {
+      // one workgroup per 64-row block, all resident: the substitutions spread over the chip (k_po_trisolve_wide)
+      if (f32) hipLaunchKernelGGL(k_po_trisolve_wide<float>, dim3((unsigned)nblk), dim3(256), 0, 0, p, (const float*)d_Lff, (const float*)d_linvf, d_tri_flags, tri_epoch);
+      else hipLaunchKernelGGL(k_po_trisolve_wide<double>, dim3((unsigned)nblk), dim3(256), 0, 0, p, (const double*)d_Lf, (const double*)d_linv, d_tri_flags, tri_epoch);
+      tri_epoch += 2u;
+    }
+    else if (f32) hipLaunchKernelGGL(k_po_trisolve<float>, dim3(1), dim3(1024), 0, 0, p, (const float*)d_Lff, (const float*)d_linvf);
+    else hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(1024), 0, 0, p, (const double*)d_Lf, (const double*)d_linv);
     stamp();
     hipLaunchKernelGGL(k_po_candidate, dim3(1), dim3(256), 0, 0, p);
     hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 1);

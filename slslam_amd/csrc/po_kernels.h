@@ -310,21 +310,11 @@ __global__ __launch_bounds__(256) void k_po_to_f32(PoPtrs p, float* Hf) {
 // (L_ik = A_ik X_kk^T) and the trailing update run on the 16x16x4 MFMA of T, one tile per wave at a time.  The inverse of
 // the whole block (TRSM of the panel kernel and the substitution use it as a matrix) is then assembled tile by tile,
 // X_ij = -X_ii sum_k L_ik X_kj, wave <-> tile column, the partial sums staged in the block's unused upper triangle.
+// The 64 x 64 block in LDS (Tt: lower triangle, identity below the matrix's last row; Li: zero) -> its Cholesky factor in Tt and
+// the factor's inverse in Li.  256 threads; the caller synchronises before and after.
 template <typename T>
-__global__ __launch_bounds__(256) void k_po_potrf_diag(PoPtrs p, T* A, T* linv, int k0) {
-  if (p.st->status != kRunning) return;
-  __shared__ T Tt[kNB * kLdT];
-  __shared__ T Li[kNB * kLdT];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nb = min((int)kNB, p.n - k0);
-  for (int q = tid; q < kNB * kNB; q += 256) {
-    const int r = q / kNB, c = q - r * kNB;
-    T v = (r == c) ? T(1) : T(0);
-    if (r < nb && c <= r) v = A[(long long)(k0 + r) * p.ld + k0 + c];
-    Tt[r * kLdT + c] = (c <= r) ? v : T(0);
-    Li[r * kLdT + c] = T(0);
-  }
-  __syncthreads();
+__device__ __forceinline__ void po_potrf_lds(PoPtrs& p, T* Tt, T* Li, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
   int fail = 0;
   const int am = lane & 15, ak = lane >> 4, col = lane & 15;      // MFMA operand / result coordinates of this lane
   for (int kb = 0; kb < 4; ++kb) {
@@ -382,11 +372,30 @@ __global__ __launch_bounds__(256) void k_po_potrf_diag(PoPtrs p, T* A, T* linv, 
       for (int q = 0; q < 4; ++q) Xij[Mfma<T>::row(lane, q) * kLdT + col] = acc2[q];
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_po_potrf_diag(PoPtrs p, T* A, T* linv, int k0, T* Aout = nullptr) {     // Aout: where the factor goes (default: in place)
+  if (p.st->status != kRunning) return;
+  if (!Aout) Aout = A;
+  __shared__ T Tt[kNB * kLdT];
+  __shared__ T Li[kNB * kLdT];
+  const int tid = threadIdx.x;
+  const int nb = min((int)kNB, p.n - k0);
+  for (int q = tid; q < kNB * kNB; q += 256) {
+    const int r = q / kNB, c = q - r * kNB;
+    T v = (r == c) ? T(1) : T(0);
+    if (r < nb && c <= r) v = A[(long long)(k0 + r) * p.ld + k0 + c];
+    Tt[r * kLdT + c] = (c <= r) ? v : T(0);
+    Li[r * kLdT + c] = T(0);
+  }
+  __syncthreads();
+  po_potrf_lds<T>(p, Tt, Li, tid);
   __syncthreads();
   for (int q = tid; q < kNB * kNB; q += 256) {
     const int r = q / kNB, c = q - r * kNB;
     linv[q] = (c <= r) ? Li[r * kLdT + c] : T(0);
-    if (r < nb && c <= r) A[(long long)(k0 + r) * p.ld + k0 + c] = Tt[r * kLdT + c];
+    if (r < nb && c <= r) Aout[(long long)(k0 + r) * p.ld + k0 + c] = Tt[r * kLdT + c];
   }
 }
 
@@ -449,6 +458,95 @@ __global__ __launch_bounds__(256) void k_po_panel_update(PoPtrs p, T* A, const T
     }
 }
 
+// One block step of the right-looking factorisation in ONE launch (the launch chain above takes three: potrf_diag, TRSM, SYRK).
+// Given the factored diagonal block k and its inverse (linv_all[bk]), workgroup (bi, bj), bj <= bi, of the trailing matrix
+// (the factor goes to a matrix of its own, Lf: the raw panel blocks A(r, k) are read by every workgroup of block row / column r
+// of this launch, so the one that holds their final value may not write it over them)
+//   * solves the two panel blocks it needs itself, L_i = A(r_i, k) inv(L_kk)^T and L_j likewise (the TRSM of a 64 x 64 block costs one
+//     tile product: recomputing it per tile triples the arithmetic of a step - 1554^3 flops in all, nothing next to two launches
+//     and their gaps on the critical path of every step) - the diagonal workgroups (bi == bj) write L_i, the panel's final value;
+//   * subtracts L_i L_j^T from its tile;
+//   * and the workgroup of the NEXT diagonal block (bi == bj == 0) goes on to factor it (po_potrf_lds) and to leave its inverse in
+//     linv_all[bk + 1]: the next launch starts from there.
+// Dynamic LDS: three 64 x 66 tiles of T.
+template <typename T>
+__global__ __launch_bounds__(256) void k_po_step(PoPtrs p, T* A, T* Lf, T* linv_all, int bk) {
+  if (p.st->status != kRunning) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char po_step_smem[];
+  T* Bi = reinterpret_cast<T*>(po_step_smem);
+  T* Bj = Bi + kNB * kLdT;
+  T* Ms = Bj + kNB * kLdT;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int k0 = bk * kNB, t0 = k0 + kNB;
+  const T* linv = linv_all + (size_t)bk * kNB * kNB;
+  int bi, bj;
+  {
+    const int t = blockIdx.x;
+    bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((bi * (bi + 1)) / 2 > t) --bi;
+    while (((bi + 1) * (bi + 2)) / 2 <= t) ++bi;
+    bj = t - (bi * (bi + 1)) / 2;
+  }
+  const int ri = t0 + bi * kNB, rj = t0 + bj * kNB;
+  const bool diag = bi == bj;
+  for (int q = tid; q < kNB * kNB; q += 256) {
+    const int r = q / kNB, c = q - r * kNB;
+    const bool cin = k0 + c < p.n;
+    Bi[r * kLdT + c] = (ri + r < p.n && cin) ? A[(long long)(ri + r) * p.ld + k0 + c] : T(0);
+    if (!diag) Bj[r * kLdT + c] = (rj + r < p.n && cin) ? A[(long long)(rj + r) * p.ld + k0 + c] : T(0);
+    Ms[r * kLdT + c] = linv[q];
+  }
+  __syncthreads();
+  typename Mfma<T>::acc_t li[4], lj[4];
+  tile_mul_bt<T>(Bi, Ms, wave, lane, li);
+  if (!diag) tile_mul_bt<T>(Bj, Ms, wave, lane, lj);
+  __syncthreads();
+  const int col = lane & 15;
+#pragma unroll
+  for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = wave * 16 + Mfma<T>::row(lane, i), cc = tc * 16 + col;
+      Bi[rr * kLdT + cc] = li[tc][i];
+      if (!diag) Bj[rr * kLdT + cc] = lj[tc][i];
+      else if (ri + rr < p.n && k0 + cc < p.n) Lf[(long long)(ri + rr) * p.ld + k0 + cc] = li[tc][i];    // the panel block, final
+    }
+  __syncthreads();
+  typename Mfma<T>::acc_t acc[4];
+  tile_mul_bt<T>(Bi, diag ? Bi : Bj, wave, lane, acc);
+  const bool next_diag = bi == 0 && bj == 0;                     // (wave-uniform, workgroup-uniform)
+  T* Tt = Bj;                                                     // free from here on for the diagonal workgroups
+  T* Li = Ms;
+  if (next_diag) {
+    for (int q = tid; q < kNB * kNB; q += 256) {
+      const int r = q / kNB, c = q - r * kNB;
+      Tt[r * kLdT + c] = (r == c) ? T(1) : T(0);
+      Li[r * kLdT + c] = T(0);
+    }
+    __syncthreads();
+  }
+  for (int tc = 0; tc < 4; ++tc)
+    for (int i = 0; i < 4; ++i) {
+      const int r = ri + wave * 16 + Mfma<T>::row(lane, i), c = rj + tc * 16 + col;
+      if (r >= p.n || c >= p.n || c > r) continue;
+      const T v = A[(long long)r * p.ld + c] - acc[tc][i];
+      if (next_diag) Tt[(r - ri) * kLdT + (c - rj)] = v;          // (written to memory after the factorisation)
+      else A[(long long)r * p.ld + c] = v;
+    }
+  if (!next_diag) return;
+  __syncthreads();
+  po_potrf_lds<T>(p, Tt, Li, tid);
+  __syncthreads();
+  T* linv_next = linv_all + (size_t)(bk + 1) * kNB * kNB;
+  const int nb = min((int)kNB, p.n - t0);
+  for (int q = tid; q < kNB * kNB; q += 256) {
+    const int r = q / kNB, c = q - r * kNB;
+    linv_next[q] = (c <= r) ? Li[r * kLdT + c] : T(0);
+    if (r < nb && c <= r) Lf[(long long)(t0 + r) * p.ld + t0 + c] = Tt[r * kLdT + c];
+  }
+}
+enum { kPoStepLdsTiles = 3 };
+
 // forward then backward substitution with the factor in A and the inverted diagonal blocks in
 // linv_all (one 64x64 block per block column, kept by k_po_potrf_diag): every step is a parallel
 // matrix-vector product - no serial pivot loop.  rhs / solution stay fp64.  One workgroup.
@@ -510,6 +608,105 @@ __global__ __launch_bounds__(1024) void k_po_trisolve(PoPtrs p, const T* A, cons
       p.y[r] -= s;
     }
     __syncthreads();
+  }
+}
+
+// The same two substitutions spread over the chip: one workgroup per 64-row block, all resident (the host checks), forward
+// then backward in ONE launch.  k_po_trisolve walks the whole factor (10 MB at 1554 unknowns) with a single workgroup - bound by
+// what one CU can load, 0.8 ms, half of a dense iteration.  Here workgroup r owns block row r:
+//   forward   y_r = inv(L_rr) (b_r - sum_{k < r} L[r, k] y_k)       reads block row r of the factor, left to right
+//   backward  x_r = inv(L_rr)^T (y_r - sum_{k > r} L[k, r]^T x_k)   reads block column r, bottom up
+// and waits, block by block, for the owner of block k to publish its part (flag[k] = epoch of this launch: device-scope release /
+// acquire; parts are read with device-scope loads).  The next block of the factor is requested before the wait, so a hop of the
+// dependent chain costs the flag's trip plus one 64 x 64 matrix-vector product.  Sums are taken in a fixed order: the solution does
+// not depend on the timing.  rhs / solution stay fp64.
+template <typename T>
+__global__ __launch_bounds__(256) void k_po_trisolve_wide(PoPtrs p, const T* A, const T* linv_all, unsigned* flags, unsigned epoch) {
+  if (p.st->status != kRunning) return;
+  __shared__ double yk[kNB], part[4][kNB], acc_s[kNB];
+  const int tid = threadIdx.x, n = p.n, nblk = (n + kNB - 1) / kNB;
+  const int r = blockIdx.x, r0 = r * kNB, nbr = min((int)kNB, n - r0);
+  const T* Li = linv_all + (size_t)r * kNB * kNB;
+  auto wait_for = [&](int k, unsigned e) {
+    if (tid == 0) while (__hip_atomic_load(flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < e) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+  };
+  auto publish = [&](unsigned e) {
+    __syncthreads();
+    if (tid == 0) { __threadfence(); __hip_atomic_store(flags + r, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+  };
+  auto load_part = [&](int k) {                       // y_k / x_k of block k into LDS (zeros past the matrix)
+    if (tid < kNB) yk[tid] = (k * kNB + tid < n) ? __hip_atomic_load(p.y + k * kNB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
+  };
+  // ---- forward: four threads per row of the block, sixteen columns each
+  {
+    const int row = tid >> 2, q4 = tid & 3;
+    double acc = 0.0;
+    T cur[16] = {}, nxt[16] = {};
+    auto fetch = [&](int k, T (&v)[16]) {
+      const bool ok = r0 + row < n && k < r;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = (ok && k * kNB + 16 * q4 + j < n) ? A[(long long)(r0 + row) * p.ld + k * kNB + 16 * q4 + j] : T(0);
+    };
+    if (r > 0) fetch(0, cur);
+    for (int k = 0; k < r; ++k) {
+      if (k + 1 < r) fetch(k + 1, nxt);
+      wait_for(k, epoch);
+      load_part(k);
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s += (double)cur[j] * yk[16 * q4 + j];
+      s += __shfl_xor(s, 1, 4); s += __shfl_xor(s, 2, 4);
+      acc += s;                                        // (block after block, in order)
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 16; ++j) cur[j] = nxt[j];
+    }
+    if (q4 == 0) acc_s[row] = (r0 + row < n) ? p.y[r0 + row] - acc : 0.0;
+    __syncthreads();
+    double s = 0.0;                                    // y_r = inv(L_rr) acc_s : row `row` of the inverse, columns <= row
+    if (row < nbr) for (int j = 16 * q4; j < 16 * q4 + 16 && j <= row; ++j) s += (double)Li[row * kNB + j] * acc_s[j];
+    s += __shfl_xor(s, 1, 4); s += __shfl_xor(s, 2, 4);
+    __syncthreads();
+    if (q4 == 0 && row < nbr) __hip_atomic_store(p.y + r0 + row, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    publish(epoch);
+  }
+  // ---- backward: thread (g, j) takes column j of the block and sixteen of its rows; the four groups meet in LDS
+  {
+    const int col = tid & 63, g = tid >> 6;
+    double acc = 0.0;
+    T cur[16] = {}, nxt[16] = {};
+    auto fetch = [&](int k, T (&v)[16]) {
+      const bool ok = r0 + col < n && k > r && k < nblk;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = (ok && k * kNB + 16 * g + i < n) ? A[(long long)(k * kNB + 16 * g + i) * p.ld + r0 + col] : T(0);
+    };
+    if (r + 1 < nblk) fetch(nblk - 1, cur);
+    for (int k = nblk - 1; k > r; --k) {
+      if (k - 1 > r) fetch(k - 1, nxt);
+      wait_for(k, epoch + 1u);
+      load_part(k);
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += (double)cur[i] * yk[16 * g + i];
+      part[g][col] = s;
+      __syncthreads();
+      if (g == 0) acc += (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+    }
+    // every block has finished its forward part before any backward part is published (the last block starts the backward
+    // chain only after its own forward part, which needed all the others)
+    if (g == 0) acc_s[col] = (r0 + col < n) ? p.y[r0 + col] - acc : 0.0;
+    __syncthreads();
+    double s = 0.0;                                    // x_r = inv(L_rr)^T acc_s : column `col` of the inverse, rows >= col
+    if (col < nbr) for (int i = max(col, 16 * g); i < 16 * g + 16 && i < nbr; ++i) s += (double)Li[i * kNB + col] * acc_s[i];
+    part[g][col] = s;
+    __syncthreads();
+    if (g == 0 && col < nbr) __hip_atomic_store(p.y + r0 + col, (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    publish(epoch + 1u);
   }
 }
 
