@@ -582,6 +582,10 @@ __host__ __device__ inline int lds_doubles_linearise(int C, int n) {
 // FRESH: 1 = the first sweep of a solve (it is also Ceres' initial evaluation: every window of the launch is fresh), 0 = any later
 // sweep (none is), -1 = read LMState.fresh.  The host knows which launch is which; the two compile-time forms keep the first
 // sweep's extras (unit scales, line Jacobi scale, fixed cost, |x|) out of the steady sweep's registers.
+// INVARIANT the host relies on for FRESH = 1 / 0 (enqueue_solve, lba_api.hip): every window that is kRunning at the first launch of a solve() is fresh
+// (k_reset / finalize precede it), and none is afterwards - lm_step ends a window at max_num_iterations, so a later solve() on the same state finds
+// no kRunning window.  A 'continue solving' entry point would have to launch the FRESH = -1 instantiation (k_reduced_solve, k_backsub and the camera-table
+// mode still read LMState.fresh / cur from memory and would disagree with a hard-coded sweep).
 // Timing experiment (build with -DSLSLAM_K1_TIMING=1 and run with SLSLAM_DEBUG_ABLATE != 0: tools/k1_phases.py): shader-clock stamps
 // of one chunk's sweep, summed over chunks into dbg_cycles[chunk * 32 + i]
 #if defined(SLSLAM_K1_TIMING) && SLSLAM_K1_TIMING

@@ -1,6 +1,7 @@
 """Differential soak of the LBA path against the CPU oracle over random window shapes (tiled sweeps, global-memory path, mixed
 batches): every window alone against the oracle at the tolerances of the GPU tests, then all of them in ONE batch against their
-solo results, bit for bit (same chunk counts).  python tests/tools/soak.py [count] [seed]"""
+solo results, bit for bit (same chunk counts).  python tests/tools/soak.py [count] [seed] [lba_elimination]
+(lba_elimination = 4: the grouped matrix-core sweep wherever its conditions hold - at most 10 free cameras, no camera that sees a line twice)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -12,6 +13,8 @@ import test_gpu_lba as T
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ELIM = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+sweeps = {}
 bad, solo, ws, paths, drift = 0, [], [], {}, []
 t0 = time.time()
 for i in range(count):
@@ -24,8 +27,10 @@ for i in range(count):
         lines = int(rng.integers(12, 400)) if kind < 8 else int(rng.integers(20, 90))
         w = synth.make_window(int(rng.integers(1, 10 ** 6)), num_lines=lines, num_kf=max(kf, free), num_free=free, mean_track=float(rng.uniform(3.0, max(3.5, 0.8 * max(kf, free)))))
     x0, s0, t0_ = pyoracle.lba_solve(w, linear_solver=1)
-    b = capi.LBABatch(); b.add(w); b.finalize(); b.solve(); b.download()
+    b = capi.LBABatch(); b.add(w); b.finalize(lba_elimination=ELIM, lba_fused_motion_only=0 if ELIM else 1); b.solve(); b.download()
     x1, s1, t1 = b.parameters(0).copy(), b.summary(0), b.trace(0)
+    sweep_alone = b.elimination()
+    sweeps[sweep_alone] = sweeps.get(sweep_alone, 0) + 1
     paths[b.path()] = paths.get(b.path(), 0) + 1
     chunks = b.window_chunks(0)
     b.close()
@@ -43,20 +48,22 @@ for i in range(count):
             T._assert_summary_parity(s0, s1); T._assert_trace_parity(t0_, t1, n=3); T._assert_params_parity(w, x0, x1)
         except AssertionError:
             drift.append((i, int(w["num_cameras"]), int(w["num_lines"]), len(w["camera_index"]), rel, dx))
-    ws.append(w); solo.append((x1, s1, chunks))
-print("%d windows alone vs oracle: %d failures; paths %s; %.1f s" % (count, bad, paths, time.time() - t0))
+    ws.append(w); solo.append((x1, s1, chunks, sweep_alone))
+print("%d windows alone vs oracle: %d failures; paths %s; elimination sweeps %s; %.1f s" % (count, bad, paths, sweeps, time.time() - t0))
 for d in drift:
     print("  beyond the test tolerances at equal LM decisions: window %d (cams %d lines %d obs %d) final cost rel. diff %.1e, max |dx| %.1e" % d)
 # all in one batch (mixed sizes and paths); a window's result must not depend on its company - except that a motion-only problem
 # alone takes its one-launch kernel, and that the chunk count is part of the result (so only windows that keep theirs are compared)
 b = capi.LBABatch()
 for w in ws: b.add(w)
-b.finalize(); b.solve(); b.download()
+b.finalize(lba_elimination=ELIM, lba_fused_motion_only=0 if ELIM else 1); b.solve(); b.download()
 same = diff = skipped = 0
 for i, w in enumerate(ws):
-    x, s, ch = solo[i]
+    x, s, ch, sweep_alone = solo[i]
     alone_motion = (np.asarray(w["fixed_index"]).reshape(-1, 2)[:, 1] == 1).all()
-    if b.window_chunks(i) != ch or alone_motion: skipped += 1; continue
+    # (the elimination sweep is chosen per batch: one window with more than 10 free cameras sends the whole tiled part to the LDS-atomic
+    # sweep, and the sweeps sum in different orders - compared are the windows that ran the same sweep alone)
+    if b.window_chunks(i) != ch or alone_motion or (sweep_alone not in (0, b.elimination())): skipped += 1; continue
     if np.array_equal(b.parameters(i), x) and b.summary(i) == s: same += 1
     else: diff += 1; print("DIFF window %d in the batch vs alone: max |dx| %.3e" % (i, np.abs(b.parameters(i) - x).max()))
 print("one batch of %d (path %d): %d identical to solo, %d differ, %d not comparable (chunk count / motion-only kernel)" % (count, b.path(), same, diff, skipped))
