@@ -178,6 +178,43 @@ def ceres_probe():
     return {"ceres_available": bool(hits), "found": hits[:4]}
 
 
+def ceres_reference_leg(windows, gpu_params, nsample=8):
+    """The true-Ceres leg of the CPU baseline, run ONLY where ceres_probe() finds an installation (none of the boxes seen so far): builds
+    tools/ceres_harness.cpp (this repo's own functor and wiring on the public Ceres API) with g++, solves a sample of the bench windows on one
+    thread as the reference configures it, and compares the results with the GPU's.  Any failure (no compiler flags that work, link errors, a
+    Ceres without sparse Cholesky) returns None and the line keeps kind = "port"."""
+    import glob
+    import subprocess
+    import tempfile
+    try:
+        d = tempfile.mkdtemp(prefix="slslam_ceres_")
+        exe = os.path.join(d, "ceres_harness")
+        inc = [i for pat in ("/usr/include/eigen3", "/usr/local/include/eigen3", "/opt/*/include/eigen3") for i in glob.glob(pat)]
+        cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tools")] + [x for i in inc for x in ("-I", i)] + \
+              [os.path.join(ROOT, "tools", "ceres_harness.cpp"), "-o", exe, "-lceres", "-lglog", "-lpthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"built": False, "error": r.stderr[-400:]}
+        its, secs, worst = 0, 0.0, 0.0
+        for i, w in enumerate(windows[:nsample]):
+            fin, fout = os.path.join(d, "w%d.bin" % i), os.path.join(d, "x%d.bin" % i)
+            with open(fin, "wb") as f:
+                np.array([w["num_cameras"], w["num_lines"], len(w["camera_index"]), 10, 1], dtype=np.int32).tofile(f)
+                for k, dt in (("camera_index", np.int32), ("line_index", np.int32), ("fixed_index", np.int32), ("observations", np.float64), ("parameters", np.float64)):
+                    np.asarray(w[k], dtype=dt).tofile(f)
+            rr = subprocess.run([exe, fin, fout, "1"], capture_output=True, text=True, timeout=900)
+            if rr.returncode != 0:
+                return {"built": True, "ran": False, "error": rr.stderr[-400:]}
+            j = json.loads(rr.stdout.strip().splitlines()[-1])
+            its += j["lm_iterations"]; secs += j["seconds"]
+            worst = max(worst, float(np.abs(np.fromfile(fout) - gpu_params[i]).max()))
+        return {"built": True, "ran": True, "value": its / secs if secs > 0 else None, "unit": "LM iterations/s", "cores": 1, "kind": "reference",
+                "sample": "%d of the bench windows through Ceres (tools/ceres_harness.cpp), 1 thread" % min(nsample, len(windows)),
+                "max_abs_parameter_diff_vs_gpu": worst}
+    except Exception as e:      # the probe was wrong about the installation: the port stays the baseline
+        return {"built": False, "error": repr(e)[:400]}
+
+
 def cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank, lines, elim, k_check=4):
     """Results are a function of the window alone, so every rank's results can be checked against ANY rank's solve of the same
     window id, bit for bit.  Outside the timed region: every rank exports the solved parameters of
@@ -596,7 +633,15 @@ def main():
                                              # a shared host delivers far fewer than it advertises
                                              "parallel_efficiency": va / (ca * v) if v > 0 and ca > 0 else None,
                                              "equivalent_full_cores": va / v if v > 0 else None}
-            out["cpu_baseline"].update(ceres_probe())
+            probe = ceres_probe()
+            out["cpu_baseline"].update(probe)
+            if probe["ceres_available"]:
+                # a Ceres installation on this box: the reference's own solver, timed beside the port (never seen so far - untested path)
+                leg = ceres_reference_leg(windows, [batches[where[i][0]].parameters(where[i][1]) for i in range(min(8, B))])
+                out["cpu_baseline"]["ceres_leg"] = leg
+                if leg and leg.get("ran") and leg.get("value"):
+                    out["cpu_baseline_port"] = dict(out["cpu_baseline"])
+                    out["cpu_baseline"].update({"value": leg["value"], "kind": "reference", "sample": leg["sample"], "cores": 1})
             # trajectory error of the GPU solve against the oracle solve of the same windows
             err = []
             for i, xo in enumerate(outs):

@@ -211,6 +211,18 @@ def test_se3_templates_of_the_mirrored_header(tmp_path):
     assert worst_inv < 1e-9 and worst_comp < 1e-12 and worst_quat < 1e-12, out
 
 
+def test_ceres_harness_functor_known_answer(tmp_path):
+    """tools/ceres_harness.cpp is the optional true-Ceres leg of the CPU baseline; it can only be built where a
+    Ceres installation exists (bench.py::ceres_probe), which no box seen so far has.  What CAN be checked here is the residual it would hand to
+    Ceres: its functor (tools/ceres_harness_functor.h), instantiated for double on the repo's own rotation helpers, reproduces the survey's
+    known-answer vector at a general keyframe and at the identity keyframe."""
+    exe = str(tmp_path / "ceres_functor_kat")
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-Wall", "-Werror", "-I", HOST, "-I", os.path.join(ROOT, "tools"), "-o", exe,
+                           os.path.join(ROOT, "tests", "host_cxx", "ceres_functor_kat.cpp")])
+    worst = float(subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()[0])
+    assert worst < 1e-14, worst
+
+
 def test_window_packer_reproduces_the_array_contract(oracle):
     """slslam_pack_window (SLAM::bundle_adjustment pre, slam.cpp:811-921) on a map built from a synthetic
     window gives the same problem (same solve), and slslam_unpack_window (slam.cpp:957-972) writes the
