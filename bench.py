@@ -215,7 +215,7 @@ def ceres_reference_leg(windows, gpu_params, nsample=8):
         return {"built": False, "error": repr(e)[:400]}
 
 
-def cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank, lines, elim, k_check=4):
+def cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank, lines, elim, k_check=4, keep=1):
     """Results are a function of the window alone, so every rank's results can be checked against ANY rank's solve of the same
     window id, bit for bit.  Outside the timed region: every rank exports the solved parameters of
     the first `k_check` windows of its shard on the device, ONE all-gather (RCCL for N > 1) brings them to every rank, and rank 0
@@ -254,7 +254,7 @@ def cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank,
             off += sizes[i]
             bt = capi.LBABatch(device=local_rank)
             bt.add(synth.make_window(lo_r + i, num_lines=lines))
-            bt.finalize(use_graph=0, chunks_per_window=ch[i], lba_elimination=elim_eff)
+            bt.finalize(use_graph=0, chunks_per_window=ch[i], lba_elimination=elim_eff, lba_keep_jacobian=keep)
             bt.solve(); bt.download()
             mine = bt.parameters(0)
             bt.close()
@@ -363,6 +363,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="waves cooperating on one window (0 = library default)")
     ap.add_argument("--elim", type=int, default=0,
                     help="lba_elimination: 0 auto, 1 LDS-atomic sweep, 2 / 3 matrix-core sweep with 1 / 2 waves per chunk")
+    ap.add_argument("--keep-jacobian", type=int, default=1,
+                    help="lba_keep_jacobian: 1 (default) the sweep after a rejected step re-uses the kept Jacobian blocks, 0 every sweep linearises")
     ap.add_argument("--gather-results", action="store_true",
                     help="also all-gather the solved parameters of every rank inside the timed region (one RCCL all-gather per step)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the 500-line, latency and pose-graph blocks")
@@ -420,7 +422,7 @@ def main():
         for wi in range(si, B, ns):
             bt.add(windows[wi])
             owner.append((wi, si, len(bt.sizes) - 1))
-        bt.finalize(use_graph=1 if use_graph else 0, chunks_per_window=args.chunks, lba_elimination=args.elim)
+        bt.finalize(use_graph=1 if use_graph else 0, chunks_per_window=args.chunks, lba_elimination=args.elim, lba_keep_jacobian=args.keep_jacobian)
         bt.set_profiling(not use_graph)
         batches.append(bt)
     where = {wi: (si, li) for wi, si, li in owner}
@@ -467,7 +469,7 @@ def main():
         per_rank = tt.tolist()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    check = cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank, args.lines, args.elim) if not args.no_result_check else None
+    check = cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank, args.lines, args.elim, keep=args.keep_jacobian) if not args.no_result_check else None
 
     # ---- per-kernel times (roofline): outside the timed region, same process, same resident batches - a profiled pass of eager
     # launches with hipEvents around every kernel (events recorded by graph nodes cannot be read back on this runtime).  The sum
@@ -493,7 +495,7 @@ def main():
             bt = capi.LBABatch(device=local_rank)
             for wi in range(si, B, 2):
                 bt.add(windows[wi])
-            bt.finalize(use_graph=1, chunks_per_window=args.chunks, lba_elimination=args.elim)
+            bt.finalize(use_graph=1, chunks_per_window=args.chunks, lba_elimination=args.elim, lba_keep_jacobian=args.keep_jacobian)
             obatches.append(bt)
 
         def orun():
@@ -541,7 +543,8 @@ def main():
                        "windows_per_gpu": B, "total_windows": B * world, "lines": args.lines,
                        "parallelism": "windows [0, %d) split contiguously over %d GPU(s) (shard_range), no data-path collective%s" % (
                            B * world, world, "; one all-gather of the results per step (%d MB)" % (gathered_bytes >> 20) if args.gather_results else ""),
-                       "launch": "hipGraph replay" if use_graph else "eager + hipEvents", "hip_streams": ns},
+                       "launch": "hipGraph replay" if use_graph else "eager + hipEvents", "hip_streams": ns,
+                       "lba_keep_jacobian": args.keep_jacobian},
             "lm_iterations": iters_total,
             "sum_initial_cost_rank0": init_cost, "sum_final_cost_rank0": final_cost,
             # multi-rank evidence: size of the communicator after init (RCCL when backend == "nccl"), distinct devices the ranks

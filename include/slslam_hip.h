@@ -91,6 +91,13 @@ typedef struct slslam_solver_options {
                                            (DESIGN.md section 7), kept as a measured alternative.  4 = matrix cores with GROUP-LOCAL
                                            accumulators: the lines of a window are packed by their first free camera and the wave
                                            keeps only the 48 x 48 sum of the current group in registers (same conditions)         */
+  int    lba_keep_jacobian;             /* 0 (default): every elimination sweep linearises.  1: the sweep that follows a REJECTED step
+                                           does not - the point has not moved, only the trust-region radius has: it replays the blocks
+                                           J_c^T J_l of every observation and the line blocks the last linearising sweep left in HBM
+                                           (+192 B per observation), as ceres::TrustRegionMinimizer evaluates the Jacobian only after
+                                           a successful step.  Grouped sweep (lba_elimination 4) only; same results to round-off.
+                                           Measured SLOWER on MI355X (the stores cost the linearising sweeps more than the replays
+                                           save): kept as a tested alternative                              */
 } slslam_solver_options;
 
 /* Fills every field with the configuration the reference runs (robust loss on, 10 iterations). */

@@ -36,7 +36,7 @@ class SolverOptions(C.Structure):
                 ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
                 ("jacobi_scaling", C.c_int), ("use_graph", C.c_int), ("chunks_per_window", C.c_int),
                 ("reuse_elimination", C.c_int), ("po_factor_fp32", C.c_int), ("po_dense_factor", C.c_int), ("lba_fused_motion_only", C.c_int),
-                ("lba_elimination", C.c_int)]
+                ("lba_elimination", C.c_int), ("lba_keep_jacobian", C.c_int)]
 
 
 class Summary(C.Structure):

@@ -56,6 +56,7 @@ extern "C" void slslam_default_options(slslam_solver_options* o) {
   o->po_dense_factor = 0;
   o->lba_fused_motion_only = 1;
   o->lba_elimination = 0;
+  o->lba_keep_jacobian = 0;
 }
 
 extern "C" void slslam_release_cached_memory(void) { DeviceBlockCache::drop(); }
@@ -154,7 +155,7 @@ Policy make_policy(const slslam_solver_options& o) {
   p.function_tolerance = o.function_tolerance; p.gradient_tolerance = o.gradient_tolerance;
   p.parameter_tolerance = o.parameter_tolerance;
   p.max_num_iterations = o.max_num_iterations; p.max_invalid = o.max_num_consecutive_invalid_steps;
-  p.jacobi_scaling = o.jacobi_scaling; p.pad = 0;
+  p.jacobi_scaling = o.jacobi_scaling; p.keep_jacobian = 0;      // (set by finalize for the sweep that implements it)
   p.store_f = o.reuse_elimination ? 1 : 0;
   const char* dbg = std::getenv("SLSLAM_DEBUG_ABLATE");    // timing experiments of the elimination sweep; never set in production
   p.debug_flags = dbg ? std::atoi(dbg) : 0;
@@ -183,7 +184,7 @@ struct slslam_lba_batch {
   // device
   DeviceArena arena;
   DevBuf<uint16_t> d_sys_map;
-  DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<uint8_t> d_items; DevBuf<uint16_t> d_lane_map;
+  DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<uint8_t> d_items; DevBuf<uint16_t> d_lane_map; DevBuf<int32_t> d_lane_ctx;
   DevBuf<uint32_t> d_line_desc;
   DevBuf<unsigned long long> d_dbg_cycles;
   int elim_mode = 0, elim_waves = 1;     // see BatchPtrs
@@ -205,7 +206,7 @@ struct slslam_lba_batch {
   long long slab_sum_stride = 0;           // > 0: k_slab_reduce runs ahead of the reduced solve
   bool slab_sum_image = false;             // ... and writes the LDS image of the reduced solve (BatchPtrs.slab_sum_image)
   int line_elim_stride = kLineElim;
-  DevBuf<double> d_slab, d_bs_part, d_cost_part, d_ysys, d_params_out, d_fstore, d_line_elim;
+  DevBuf<double> d_slab, d_bs_part, d_cost_part, d_ysys, d_params_out, d_fstore, d_line_elim, d_line_h;
   DevBuf<LMState> d_state; DevBuf<IterRec> d_trace; DevBuf<long long> d_param_off;
   BatchPtrs ptrs;
   int nchunk = 0, nline = 0, ncam = 0;
@@ -246,13 +247,13 @@ struct slslam_lba_batch {
   }
 
   void release() {
-    d_sys_map.release(); d_wins.release(); d_tiles.release(); d_chunks.release(); d_items.release(); d_lane_map.release(); d_line_desc.release(); d_dbg_cycles.release();
+    d_sys_map.release(); d_wins.release(); d_tiles.release(); d_chunks.release(); d_items.release(); d_lane_map.release(); d_lane_ctx.release(); d_line_desc.release(); d_dbg_cycles.release();
     d_cam_x.release(); d_cam_x0.release(); d_cam_scale.release(); d_cam_tab.release(); d_cam_cf.release(); d_cam_win.release();
     d_line_x.release(); d_line_x0.release(); d_line_scale.release(); d_line_ptr.release(); d_line_flags.release();
     d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release();
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
     d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release(); d_active.release();
-    d_fstore.release(); d_line_elim.release(); d_slab_sum.release();
+    d_fstore.release(); d_line_elim.release(); d_line_h.release(); d_slab_sum.release();
     d_big_ob_line.release(); d_big_cam_ptr.release(); d_big_cam_obs.release(); d_big_pair_ptr.release(); d_big_pair_row.release();
     d_big_pair_col.release(); d_big_pair_desc.release(); d_big_flags.release(); d_big_J.release(); d_big_F.release(); d_big_cost.release();
     d_big_camtab.release(); d_big_line_acc.release(); d_big_sys.release(); d_big_scal.release(); d_big_linv.release(); d_big_sys_off.release();
@@ -404,6 +405,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     b->elim_mode = ((want >= 2 || auto_grouped) && mfma_ok) ? 1 : 0;
     b->elim_waves = b->elim_mode == 0 ? 1 : (want == 3 ? 2 : 1);
     b->elim_grouped = b->elim_mode == 1 && (want == 4 || auto_grouped);
+    b->pol.keep_jacobian = (b->elim_grouped && b->opt.lba_keep_jacobian && b->opt.max_num_iterations > 1) ? 1 : 0;
     if (b->elim_grouped) {
       // the grouped sweep wants the lines of a window in the order of their first free camera: pack again (the default packing
       // deals rows to the tiles by pair-item count, which this sweep has no use for)
@@ -531,6 +533,29 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.upload(b->d_lane_map, lane_map);
   if (line_desc.empty()) line_desc.push_back(0u);
   ar.upload(b->d_line_desc, line_desc);
+  // everything a lane has to know about its place in a tile, resolved once here (lba_kernels.h::fetch_tile): the sweeps get it with
+  // ONE 16-byte load whose address depends on the tile index only - no chain tile -> lane map -> line pointer inside their loops
+  std::vector<int32_t> lane_ctx((size_t)std::max<size_t>(1, tiles.size()) * 64 * 4, 0);
+  for (size_t t = 0; t < tiles.size(); ++t) {
+    const Tile& tl = tiles[t];
+    for (int lane = 0; lane < 64; ++lane) {
+      const unsigned m = lane_map[t * 64 + lane];
+      const bool ok = (m & 0xffu) != 0xffu;
+      int32_t* r = lane_ctx.data() + (t * 64 + lane) * 4;
+      const unsigned tflags = ((unsigned)tl.flags & 0xffu) << 16;
+      unsigned misc = ((m & 0xffu) << 24) | (1u << 15) | tflags;            // slot | "constant" for an idle lane | the tile's flags
+      if (ok) {
+        const int ls = tl.line_begin + (int)(m & 0xffu);
+        const int o0 = line_ptr[(size_t)ls], k = line_ptr[(size_t)ls + 1] - o0;
+        if (k > 127) return SLSLAM_ERR_UNSUPPORTED;
+        r[0] = ls; r[1] = o0;
+        misc = ((m >> 8) & 0x3fu) | (unsigned)k << 6 | 1u << 13 | ((m >> 15) & 1u) << 14 | ((unsigned)line_flags[(size_t)ls] & 1u) << 15 | tflags | (m & 0xffu) << 24;
+      }
+      r[2] = (int32_t)misc;
+      r[3] = (lane < tl.nlines && (size_t)(tl.line_begin + lane) < line_desc.size()) ? (int32_t)line_desc[(size_t)(tl.line_begin + lane)] : 0;
+    }
+  }
+  ar.upload(b->d_lane_ctx, lane_ctx);
   if (cam_x.empty()) cam_x.assign(12, 0.0);
   ar.upload(b->d_cam_x, cam_x);
   if (cam_x0.empty()) cam_x0.assign(6, 0.0);
@@ -590,7 +615,9 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.scratch(b->d_bs_part, std::max<size_t>(1, (size_t)b->nchunk * kBsStride));
   ar.scratch(b->d_cost_part, std::max<size_t>(1, (size_t)b->nchunk));
   ar.scratch(b->d_ysys, std::max<size_t>(1, (size_t)sys));
-  ar.scratch(b->d_fstore, b->opt.reuse_elimination ? (size_t)24 * (size_t)std::max<long long>(1, nobs) : 2);
+  ar.scratch(b->d_fstore, b->pol.keep_jacobian ? (size_t)(24 * 64) * std::max<size_t>(1, tiles.size())        // [tile][12][64] double2
+                          : b->opt.reuse_elimination ? (size_t)24 * (size_t)std::max<long long>(1, nobs) : 2);
+  ar.scratch(b->d_line_h, b->pol.keep_jacobian ? (size_t)10 * (size_t)std::max<long long>(1, nline) : 2);
   b->line_elim_stride = (b->opt.reuse_elimination || b->big_mode) ? kLineElim : kLeU;      // K g is kept for those two paths only
   ar.scratch(b->d_line_elim, std::max<size_t>(1, (size_t)nline * b->line_elim_stride));
   ar.scratch(b->d_params_out, std::max<size_t>(1, (size_t)param_off));
@@ -697,7 +724,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   if ((rc = ar.commit())) return rc;
 
   BatchPtrs& p = b->ptrs;
-  p.wins = b->d_wins.p; p.tiles = b->d_tiles.p; p.chunks = b->d_chunks.p; p.items = b->d_items.p; p.lane_map = b->d_lane_map.p;
+  p.wins = b->d_wins.p; p.tiles = b->d_tiles.p; p.chunks = b->d_chunks.p; p.items = b->d_items.p; p.lane_map = b->d_lane_map.p; p.lane_ctx = b->d_lane_ctx.p;
   p.cam_x = b->d_cam_x.p; p.cam_scale = b->d_cam_scale.p; p.cam_cf = b->d_cam_cf.p;
   p.cam_tab = share_cam_tab ? b->d_cam_tab.p : nullptr;
   p.line_x = b->d_line_x.p; p.line_scale = b->d_line_scale.p; p.line_ptr = b->d_line_ptr.p;
@@ -705,7 +732,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.ob = b->d_ob.p; p.ob_cam = b->d_ob_cam.p; p.ob_stride = std::max<long long>(1, nobs);
   p.slab_sum = b->slab_sum_stride ? b->d_slab_sum.p : nullptr; p.slab_sum_stride = b->slab_sum_stride; p.slab_sum_image = b->slab_sum_image ? 1 : 0;
   p.slab = b->d_slab.p; p.bs_part = b->d_bs_part.p; p.cost_part = b->d_cost_part.p; p.ysys = b->d_ysys.p;
-  p.fstore = b->d_fstore.p; p.line_elim = b->d_line_elim.p; p.line_elim_stride = b->line_elim_stride;
+  p.fstore = b->d_fstore.p; p.line_elim = b->d_line_elim.p; p.line_elim_stride = b->line_elim_stride; p.line_h = b->d_line_h.p;
   p.state = b->d_state.p; p.trace = b->d_trace.p;
   p.iter_counter = b->d_iter_counter.p; p.active_counter = b->d_active.p; p.cam_x0 = b->d_cam_x0.p; p.line_u0 = b->d_line_x0.p;
   p.nwin = B; p.nchunk = b->nchunk; p.nline = b->nline; p.ncam = b->ncam;
@@ -745,6 +772,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_mfma<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_grouped<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_grouped<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_grouped<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
   }
   if (b->lds_solve > 48 * 1024 && !b->big_mode) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
@@ -913,6 +941,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     if (!capturing && ((it + 1) % 16) == 0) HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
     if (b->nchunk > 0) {
       if (b->elim_grouped && it == 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_eliminate_grouped<true>, g_chunk, blk64, b->lds_elim, s, p, pol));
+      else if (b->elim_grouped && pol.keep_jacobian) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_grouped<false, true>), g_chunk, blk64, b->lds_elim, s, p, pol));
       else if (b->elim_grouped) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_eliminate_grouped<false>, g_chunk, blk64, b->lds_elim, s, p, pol));
       else if (b->elim_mode == 1 && pol.debug_flags) {          // timing experiments (SLSLAM_DEBUG_ABLATE)
         if (b->elim_waves == 2) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_mfma<2, true>), g_chunk, dim3(128), b->lds_elim, s, p, pol));

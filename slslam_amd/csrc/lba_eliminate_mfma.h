@@ -30,16 +30,6 @@
 
 namespace slslam {
 
-// line descriptors of tile t for the lanes below its line count (0 elsewhere)
-__device__ __forceinline__ unsigned fetch_desc(const BatchPtrs& p, int t, int t_end, int lane) {
-  unsigned d = 0u;
-  if (t < t_end) {
-    const Tile tl = p.tiles[t];
-    if (lane < tl.nlines) d = p.line_desc[tl.line_begin + lane];
-  }
-  return d;
-}
-
 __host__ __device__ inline int lds_bytes_eliminate_mfma(int C, int n, int NW) {
   const int doubles = C * 13 /* kCamTabG */ + NW * (n / 6) * kDiagRec + NW * kPanelDoubles + NW * 8;
   return doubles * 8 + NW * 64 * 4 + NW * kGatherLines * 64 + 16 * 4 + ((C + 15) / 16) * 16;
@@ -189,17 +179,15 @@ void k_eliminate_mfma(BatchPtrs p, Policy pol) {
   TileCtx nxt = fetch_tile(p, ck.tile_begin + wave, ck.tile_end, lane);
   ObsPref pfn;
   prefetch_obs<false, false>(p, nxt, cur, wd.obs_off, pfn, lane);
-  unsigned dnext = fetch_desc(p, ck.tile_begin + wave, ck.tile_end, lane);
   for (int t0 = ck.tile_begin; t0 < ck.tile_end; t0 += NW) {
     const int t = t0 + wave;
     const bool active = t < ck.tile_end;            // wave-uniform
     if (active) {
       const TileCtx tc = nxt;
       const ObsPref pf = pfn;
-      ldesc[wave * 64 + lane] = dnext;
+      ldesc[wave * 64 + lane] = tc.desc;            // (line descriptors of the tile: TileCtx, lba_kernels.h)
       if (lane == 0) nlin[wave] = tc.nlines;
-      nxt = fetch_tile(p, t + NW, ck.tile_end, lane);      // in flight while this tile is processed
-      dnext = fetch_desc(p, t + NW, ck.tile_end, lane);
+      const TileReq rq = request_tile(p, t + NW, ck.tile_end, lane);      // in flight while this tile is processed
       const SegCtx sg = make_seg(tc, lane);
       const int j = tc.j, ls = tc.ls, k = tc.k;
       const bool line_ok = tc.line_ok;
@@ -357,6 +345,7 @@ void k_eliminate_mfma(BatchPtrs p, Policy pol) {
       }
       SLS_STAMP(5);
       // the next tile's loads go out here: their latency overlaps the matrix-core phase
+      nxt = resolve_tile(rq);
       prefetch_obs<false, false>(p, nxt, cur, wd.obs_off, pfn, lane);
     } else {
       if (lane == 0) nlin[wave] = 0;

@@ -262,24 +262,42 @@ struct TileCtx {
   bool skew;                // lane_map bit 15: this lane adds its camera-record entries one step late (see the diagonal block)
   int slot, nlines;         // the lane's line slot in the tile (matrix-core sweep), lines of the tile (wave-uniform)
   bool line_ok;
+  unsigned desc;            // the tile's lane-th line descriptor (matrix-core sweeps; 0 past the tile's lines)
 };
-__device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_end, int lane) {
+// One 16-byte load per lane (BatchPtrs.lane_ctx, resolved by the host: sorted line | first observation | j, k, flags | descriptor) and the
+// tile record: nothing here depends on a loaded value, and nothing is decoded here - request_tile only issues the loads, resolve_tile
+// (called where the next tile's observations are requested, most of a tile later) waits for them.  The chain
+// tile -> lane map -> line pointer this replaces cost every tile of every sweep three exposed round trips to memory
+// (s_waitcnt vmcnt(0) between dependent loads in the middle of the tile loop).
+struct TileReq { int4 r; int2 items; int nl; bool live; };
+__device__ __forceinline__ TileReq request_tile(const BatchPtrs& p, int t, int t_end, int lane) {
+  // (no branch around the loads: the copies that merge a conditional load with its default would be uses, i.e. waits; past the end of
+  // the chunk the previous tile is read again and resolve_tile discards it)
+  TileReq q;
+  q.live = t < t_end;
+  const int tt = q.live ? t : (t_end > 0 ? t_end - 1 : 0);
+  q.r = reinterpret_cast<const int4*>(p.lane_ctx)[(long long)tt * 64 + lane];
+  const int* tl = reinterpret_cast<const int*>(p.tiles + tt);    // Tile: line_begin | nlines, flags | item_off | nitems (separate loads: a sweep
+  q.nl = tl[1];                                                  // that does not use a part does not carry it)
+  q.items = *reinterpret_cast<const int2*>(tl + 2);
+  return q;
+}
+__device__ __forceinline__ TileCtx resolve_tile(const TileReq& q) {
   TileCtx c;
-  c.flags = 0; c.ls = 0; c.j = 0; c.o0 = 0; c.k = 0; c.lflags = 1; c.nitems = 0; c.item_off = 0; c.line_ok = false;
-  c.slot = 0; c.nlines = 0; c.skew = false;
-  if (t < t_end) {
-    const Tile tl = p.tiles[t];
-    const int m = p.lane_map[(long long)t * 64 + lane];
-    c.flags = tl.flags; c.nitems = tl.nitems; c.item_off = tl.item_off; c.nlines = tl.nlines; c.slot = m & 0xff;
-    c.line_ok = (m & 0xff) != 0xff;
-    if (c.line_ok) {
-      c.j = (m >> 8) & 0x3f;
-      c.skew = (m & 0x8000) != 0;
-      c.ls = tl.line_begin + (m & 0xff);
-      c.o0 = p.line_ptr[c.ls]; c.k = p.line_ptr[c.ls + 1] - c.o0; c.lflags = p.line_flags[c.ls];
-    }
-  }
+  int rx = q.r.x, ry = q.r.y, rz = q.r.z, rw = q.r.w;
+  asm volatile("" : "+v"(rx), "+v"(ry), "+v"(rz), "+v"(rw));      // the decode (and with it the wait for the load) stays HERE
+  if (!q.live) { rx = 0; ry = 0; rz = (int)(0xffu << 24 | 1u << 15); rw = 0; }      // an idle lane: no line, "constant"
+  const unsigned m = (unsigned)rz;
+  c.ls = rx; c.o0 = ry; c.desc = (unsigned)rw;
+  c.j = (int)(m & 0x3fu); c.k = (int)((m >> 6) & 0x7fu); c.line_ok = ((m >> 13) & 1u) != 0u; c.skew = ((m >> 14) & 1u) != 0u;
+  c.lflags = (int)((m >> 15) & 1u); c.slot = (int)(m >> 24);
+  c.flags = q.live ? __builtin_amdgcn_readfirstlane((int)((m >> 16) & 0xffu)) : 0;          // (wave-uniform values to the scalar registers)
+  c.nlines = q.live ? __builtin_amdgcn_readfirstlane((int)(short)(q.nl & 0xffff)) : 0;
+  c.item_off = q.live ? __builtin_amdgcn_readfirstlane(q.items.x) : 0; c.nitems = q.live ? __builtin_amdgcn_readfirstlane(q.items.y) : 0;
   return c;
+}
+__device__ __forceinline__ TileCtx fetch_tile(const BatchPtrs& p, int t, int t_end, int lane) {
+  return resolve_tile(request_tile(p, t, t_end, lane));
 }
 __device__ __forceinline__ SegCtx make_seg(const TileCtx& c, int lane) {
   SegCtx s;
@@ -636,7 +654,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     SLS_PHASE("tile_head");
     const TileCtx tc = nxt;
     const ObsPref pf = pfn;
-    nxt = fetch_tile(p, t + 1, ck.tile_end, lane);      // in flight while this tile is processed
+    const TileReq rq = request_tile(p, t + 1, ck.tile_end, lane);      // in flight while this tile is processed (resolved at the prefetch)
     const SegCtx sg = make_seg(tc, lane);
     const int j = tc.j, ls = tc.ls, o0 = tc.o0, k = tc.k;
     const bool line_ok = tc.line_ok;
@@ -672,6 +690,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           lds_add(&rec[kRecH + a], ha);
         }
       }
+      nxt = resolve_tile(rq);
       prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
       continue;
     }
@@ -749,6 +768,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 
     SLS_PHASE("prefetch_next");
+    nxt = resolve_tile(rq);
     prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
     __builtin_amdgcn_sched_barrier(0);
     SLS_PHASE("diag_block");
@@ -1648,7 +1668,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     SLS_PHASE("bs_tile_head");
     const TileCtx tc = nxt;
     const ObsPref pf = pfn;
-    nxt = fetch_tile(p, t + nw, ck.tile_end, lane);
+    const TileReq rq = request_tile(p, t + nw, ck.tile_end, lane);      // resolved at the prefetch below
     const SegCtx sg = make_seg(tc, lane);
     const int j = tc.j, ls = tc.ls, k = tc.k;
     const bool line_ok = tc.line_ok;
@@ -1677,6 +1697,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     }
     // the next tile's loads go out here (the linearisation's temporaries are dead), see prefetch_obs
     SLS_PHASE("bs_prefetch_next");
+    nxt = resolve_tile(rq);
     prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
     __builtin_amdgcn_sched_barrier(0);
     seg_sum_n<4, true>(wv, sg);        // (the DPP form of the run total measured slower here: 0.505 -> 0.518 ms; this sweep has no atomics)

@@ -99,7 +99,9 @@ struct Policy {             // numeric policy, by value into every kernel that n
   double initial_radius, max_radius, min_radius;
   double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
   double function_tolerance, gradient_tolerance, parameter_tolerance;
-  int max_num_iterations, max_invalid, jacobi_scaling, pad;
+  int max_num_iterations, max_invalid, jacobi_scaling;
+  int keep_jacobian;           // 1: the grouped elimination sweep leaves J_c^T J_l of every observation (BatchPtrs.fstore) and the line blocks
+                               // (BatchPtrs.line_h) in memory and the sweep after a rejected step starts from them instead of linearising again
   int store_f;                 // 1: spill F blocks for the streaming back-substitution (variant B)
   int debug_flags;             // timing experiments only (environment SLSLAM_DEBUG_ABLATE; results are wrong when set): bit 0 skip the
                                // matrix-core phase, bit 1 fetch operands without MFMA, bit 2 skip the camera-record atomics
@@ -111,6 +113,9 @@ struct BatchPtrs {
   const Tile* tiles;
   const Chunk* chunks;
   const uint16_t* lane_map;   // [ntile][64] lane -> (line slot, position in the line's run), see Tile
+  const int32_t* lane_ctx;    // [ntile][64][4] per lane of a tile: sorted line | first observation of the line | j (bits 0-5), k (6-12), lane has a line (13),
+                              // skew (14), line flags (16-23), line slot (24-31) | the tile's lane-th line descriptor: lane_map, line_ptr, line_flags and
+                              // line_desc resolved on the host, one 16-byte load per lane and tile (fetch_tile)
   const uint8_t* items;       // 2 bytes per item: (lane_i, lane_j), camera(lane_i) <= camera(lane_j)
   const uint32_t* line_desc;  // [nline] matrix-core elimination: free-camera mask (bits 0-9, 0 for a constant line) | first lane of the
                               // line's run in its tile << 10 | accumulator tiles the line updates << 16
@@ -138,8 +143,10 @@ struct BatchPtrs {
   double* bs_part;            // [nchunk][kBsStride]
   double* cost_part;          // [nchunk]
   double* ysys;               // y_c per window (sys_off)
-  double* fstore;             // [12][ob_stride] double2: F = (Jc^T Jl) K^T (6x4, row-major) of every coupled observation
+  double* fstore;             // [12][ob_stride] double2: F = (Jc^T Jl) K^T (6x4, row-major) of every coupled observation (store_f);
+                              // keep_jacobian: [tile][12][64] double2, h = Jc'^T Jl (6x4, row-major, raw camera coordinates) of the observation of every lane - 12 KB a tile, contiguous
   double* line_elim;          // [nline][line_elim_stride]
+  double* line_h;             // [nline][10] keep_jacobian: lower triangle of the line's block J_l^T J_l (scaled line coordinates, undamped)
   int line_elim_stride;
   LMState* state;
   IterRec* trace;             // [nwin][kMaxTrace]

@@ -224,7 +224,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   pol.min_lm_diagonal = opt.min_lm_diagonal; pol.max_lm_diagonal = opt.max_lm_diagonal;
   pol.function_tolerance = opt.function_tolerance; pol.gradient_tolerance = opt.gradient_tolerance;
   pol.parameter_tolerance = opt.parameter_tolerance; pol.max_num_iterations = opt.max_num_iterations;
-  pol.max_invalid = opt.max_num_consecutive_invalid_steps; pol.jacobi_scaling = opt.jacobi_scaling; pol.pad = 0;
+  pol.max_invalid = opt.max_num_consecutive_invalid_steps; pol.jacobi_scaling = opt.jacobi_scaling; pol.keep_jacobian = 0;
 
   int rc = SLSLAM_OK;
   const bool timing = g_po_timing.enabled;

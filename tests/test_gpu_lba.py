@@ -510,6 +510,47 @@ def test_randomised_shapes_grouped_matrix_core_sweep(hip, oracle):
     assert worst["trace"] < 1e-6
 
 
+def test_kept_jacobian_sweep_after_rejected_steps(hip, oracle):
+    """lba_keep_jacobian (grouped sweep): after a REJECTED step the next elimination sweep does not linearise - it replays the
+    blocks J_c'^T J_l and the line blocks the last linearising sweep left in memory, with the new radius (what
+    ceres::TrustRegionMinimizer does: the Jacobian is evaluated after successful steps only).  Windows whose solves reject steps
+    (the bench family rejects about a third, several in a row among them): the iteration traces with and without the replay
+    agree to round-off at every iteration, decisions and terminations are equal, both match the oracle, a batch is reproducible
+    bit for bit and equal to its windows solved alone."""
+    ws = [synth.make_window(i, num_lines=n) for i, n in ((0, 400), (1, 400), (3, 250), (7, 600), (11, 150))]
+    ws.append(synth.make_window(75, num_lines=60, num_kf=24, num_free=10, mean_track=40.0))
+    rejected = 0
+    for w in ws:
+        x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+        xk, sk, tk = hip.lba_solve(w, lba_elimination=4, lba_keep_jacobian=1)
+        xn, sn, tn = hip.lba_solve(w, lba_elimination=4, lba_keep_jacobian=0)
+        rejected += sk["num_unsuccessful_steps"]
+        assert len(tk) == len(tn) == len(t0)
+        for a, b, c in zip(tk, tn, t0):
+            assert a["step_is_successful"] == b["step_is_successful"] == c["step_is_successful"]
+            assert abs(a["cost"] - b["cost"]) <= 1e-10 * abs(b["cost"]) + 1e-300
+            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-7 * b["trust_region_radius"]
+        _assert_trace_parity(t0, tk, n=3)
+        for k in ("num_successful_steps", "num_unsuccessful_steps", "termination_type"):
+            assert s0[k] == sk[k] == sn[k], k
+        assert abs(sk["final_cost"] - sn["final_cost"]) <= 1e-9 * sn["final_cost"]
+        assert np.abs(xk - xn).max() < 1e-7 and np.abs(xk - x0).max() < 1e-5
+    assert rejected >= 6, "the shapes of this test are meant to reject steps"
+    b = hip.LBABatch()
+    for w in ws[:5]:
+        b.add(w)
+    b.finalize(lba_elimination=4, lba_keep_jacobian=1)
+    assert b.elimination() == 4
+    b.solve(); b.download()
+    first = [b.parameters(i).copy() for i in range(5)]
+    b.reset(); b.solve(); b.download()
+    for i in range(5):
+        assert np.array_equal(first[i], b.parameters(i)), "window %d not reproducible" % i
+        xs, _, _ = hip.lba_solve(ws[i], lba_elimination=4, lba_keep_jacobian=1)
+        assert np.abs(xs - first[i]).max() < 1e-8
+    b.close()
+
+
 def test_one_shot_solves_reuse_their_device_block(hip, oracle):
     """slslam_lba_solve / slslam_po_solve keep the device block of the previous call (device_cache.h): solves of different
     shapes back to back, interleaved with pose-graph solves, still match the oracle - nothing depends on fresh memory."""
