@@ -323,8 +323,9 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
       double H[10], g[4];
       // the launch after an accepted step tests the gradient in unscaled coordinates: the line's Jacobi scale again (its registers went
       // to the linearisation), requested here so that the round trip overlaps the scans instead of standing before its use
+      // (on every sweep: a load under the uniform condition would be merged with its default by copies, i.e. waited for on the spot)
       double lsc_again[4] = { 1.0, 1.0, 1.0, 1.0 };
-      if (!fresh && need_grad) {
+      if (!fresh) {
         const double2* lp = reinterpret_cast<const double2*>(p.line_scale + (long long)(line_ok ? ls : 0) * 4);
         const double2 s01 = lp[0], s23 = lp[1];
         lsc_again[0] = s01.x; lsc_again[1] = s01.y; lsc_again[2] = s23.x; lsc_again[3] = s23.y;
@@ -351,6 +352,12 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
         // (the run totals come back through ds_bpermute: this sweep's LDS pipe is lightly loaded - unlike the LDS-atomic sweep's, which
         // moves them on the VALU - and 28 of them are cheaper than four rounds of 28 selects; measured 1.235 -> 1.224 ms)
         seg_sum_n<14, false, false>(v, sg);
+        if (!fresh) {
+          // the scale has arrived by now; taking it HERE, on every path, keeps its wait ahead of the stores of the line's factor below (a
+          // wait behind them - the registers are re-used on the lanes that do not test the gradient - would stand until the stores are
+          // acknowledged)
+          asm volatile("" : "+v"(lsc_again[0]), "+v"(lsc_again[1]), "+v"(lsc_again[2]), "+v"(lsc_again[3]));
+        }
 #pragma unroll
         for (int i = 0; i < 10; ++i) H[i] = v[i];
 #pragma unroll

@@ -280,6 +280,9 @@ __device__ __forceinline__ TileReq request_tile(const BatchPtrs& p, int t, int t
   const int* tl = reinterpret_cast<const int*>(p.tiles + tt);    // Tile: line_begin | nlines, flags | item_off | nitems (separate loads: a sweep
   q.nl = tl[1];                                                  // that does not use a part does not carry it)
   q.items = *reinterpret_cast<const int2*>(tl + 2);
+#if defined(SLS_BLOCKING_TILE_FETCH)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // timing control: ONE exposed round trip per tile (the old chain had three)
+#endif
   return q;
 }
 __device__ __forceinline__ TileCtx resolve_tile(const TileReq& q) {
@@ -328,14 +331,19 @@ struct ObsPref {
 template <bool WITH_U, bool WITH_ITEMS = false>
 __device__ __forceinline__ void prefetch_obs(const BatchPtrs& p, const TileCtx& c, int cur, int safe_obs, ObsPref& f, int lane = 0) {
   const bool valid = c.line_ok && c.j < c.k;
+#if defined(SLS_ABLATE_OBS_CACHED)
+  const int o = safe_obs + (c.j & 7);                 // timing experiment (results WRONG): every tile reads the same few observations and lines - cache hits
+  const int lsafe = c.j & 7;
+#else
   const int o = valid ? c.o0 + c.j : safe_obs;
+  const int lsafe = c.line_ok ? c.ls : 0;
+#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) {     // (x,y) endpoint pairs: one 16-byte load per plane
     const double2 e = reinterpret_cast<const double2*>(p.ob)[(long long)q * p.ob_stride + o];
     f.ob[2 * q] = e.x; f.ob[2 * q + 1] = e.y;
   }
   f.cam = p.ob_cam[o];
-  const int lsafe = c.line_ok ? c.ls : 0;
   const double* lrec = p.line_x + line_rec(p, lsafe, cur);
 #pragma unroll
   for (int q = 0; q < 7; ++q) f.trig[q] = lrec[4 + q];

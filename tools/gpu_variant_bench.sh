@@ -7,7 +7,10 @@ TAG=$1; shift
 : > gpurun_out/${TAG}_variants.txt
 for FLAGS in "$@"; do
   SLSLAM_EXTRA_FLAGS="$FLAGS" python -c "from slslam_amd import build; build.build_lib(force=True)" > gpurun_out/${TAG}_build.log 2>&1 || { echo "BUILD FAILED: $FLAGS" >> gpurun_out/${TAG}_variants.txt; continue; }
+  CLK0=$(rocm-smi --showclocks 2>/dev/null | grep -m1 sclk | sed 's/.*(\([0-9]*Mhz\)).*/\1/')
   timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 2 ${BENCH_ARGS} --no-cpu-baseline --no-overlap-run --no-extra-configs > gpurun_out/${TAG}_b.json 2> gpurun_out/${TAG}_b.err
+  CLK1=$(rocm-smi --showclocks 2>/dev/null | grep -m1 sclk | sed 's/.*(\([0-9]*Mhz\)).*/\1/')
+  echo -n "[sclk $CLK0 -> $CLK1] " >> gpurun_out/${TAG}_variants.txt
   python - "$FLAGS" gpurun_out/${TAG}_b.json >> gpurun_out/${TAG}_variants.txt <<'PY'
 import json,sys
 try:
