@@ -215,7 +215,7 @@ def ceres_reference_leg(windows, gpu_params, nsample=8):
         return {"built": False, "error": repr(e)[:400]}
 
 
-def cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank, lines, elim, k_check=4, keep=1):
+def cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank, lines, elim, k_check=4, keep=0):
     """Results are a function of the window alone, so every rank's results can be checked against ANY rank's solve of the same
     window id, bit for bit.  Outside the timed region: every rank exports the solved parameters of
     the first `k_check` windows of its shard on the device, ONE all-gather (RCCL for N > 1) brings them to every rank, and rank 0
@@ -363,8 +363,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="waves cooperating on one window (0 = library default)")
     ap.add_argument("--elim", type=int, default=0,
                     help="lba_elimination: 0 auto, 1 LDS-atomic sweep, 2 / 3 matrix-core sweep with 1 / 2 waves per chunk")
-    ap.add_argument("--keep-jacobian", type=int, default=1,
-                    help="lba_keep_jacobian: 1 (default) the sweep after a rejected step re-uses the kept Jacobian blocks, 0 every sweep linearises")
+    ap.add_argument("--keep-jacobian", type=int, default=0,
+                    help="lba_keep_jacobian: 0 (default) every sweep linearises, 1 the sweep after a rejected step replays the kept Jacobian blocks (measured slower)")
     ap.add_argument("--gather-results", action="store_true",
                     help="also all-gather the solved parameters of every rank inside the timed region (one RCCL all-gather per step)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the 500-line, latency and pose-graph blocks")

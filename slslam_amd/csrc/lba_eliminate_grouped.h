@@ -85,6 +85,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
   const LMState* st = p.state + ck.win;
   if (st->status != kRunning) return;
   const int cur = st->cur;
+  const TileReq rq0 = request_tile(p, ck.tile_begin, ck.tile_end, lane);      // the first tile's context travels while the tables are built
   const double inv_radius = 1.0 / st->radius;
   const bool need_grad = st->need_grad_check != 0;
   const bool same_point = st->same_point != 0;     // J_c'^T J_c' and g_c' in the slab are still those of this point
@@ -273,7 +274,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
   double acc_cost = 0.0, acc_fixed = 0.0, acc_gmax = 0.0, acc_xn2 = 0.0;
   int fail = 0;
   if (!replay) {
-    TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
+    TileCtx nxt = resolve_tile(rq0);
     ObsPref pfn;
     prefetch_obs<false, false>(p, nxt, cur, wd.obs_off, pfn, lane);
     SLS_K1_STAMP(0);
@@ -500,7 +501,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
       const double2* lg = reinterpret_cast<const double2*>(p.line_elim + (long long)lsafe * p.line_elim_stride + kLeG);
       kq.g[0] = lg[0]; kq.g[1] = lg[1];
     };
-    TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
+    TileCtx nxt = resolve_tile(rq0);
     Kept kn;
     request(ck.tile_begin, nxt, kn);
     for (int t = ck.tile_begin; t < ck.tile_end; ++t) {

@@ -1619,6 +1619,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
   const int cur = st->cur;
   const int n = wd.n;
   const bool refresh_table = (st->n_success & 15) == 15;
+  const TileReq rq0 = request_tile(p, ck.tile_begin + wave, ck.tile_end, lane);      // the first tile's context travels while the tables are built
   double* bstab = smem;
   double* candtab = bstab + wd.C * kBsTab;
   double* red = candtab + wd.C * kCandTab;             // [2][4] per-wave sums
@@ -1665,7 +1666,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
   SLS_K1_STAMP(8);
 
   double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0, acc_cost = 0.0;
-  TileCtx nxt = fetch_tile(p, ck.tile_begin + wave, ck.tile_end, lane);
+  TileCtx nxt = resolve_tile(rq0);
   ObsPref pfn;
   prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
 #if defined(SLSLAM_K1_TIMING) && SLSLAM_K1_TIMING
