@@ -100,6 +100,12 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
   double* diag = camtab + wd.C * kCamTabG;                     // [ncf][kDiagRec]
   signed char* camcf = (signed char*)(diag + ncf * kDiagRec);
   double* slab = p.slab + ck.slab_off;
+  // the first tile's observations are requested before the camera table is built (not after it and the zeroing below: the set-up of a
+  // chunk is a chain of round trips to memory - chunk, window and state, cameras, first tile, its observations - and every link
+  // that can overlap another one is a few microseconds per chunk)
+  TileCtx nxt = resolve_tile(rq0);
+  ObsPref pfn;
+  if (!keep) prefetch_obs<false, false>(p, nxt, cur, wd.obs_off, pfn, lane);      // (the KEEP form has no register for it here)
   for (int c = lane; c < wd.C; c += 64) {
     const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + cur) * kCamRec;
     double w[3] = { x[0], x[1], x[2] }, R[9];
@@ -274,9 +280,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
   double acc_cost = 0.0, acc_fixed = 0.0, acc_gmax = 0.0, acc_xn2 = 0.0;
   int fail = 0;
   if (!replay) {
-    TileCtx nxt = resolve_tile(rq0);
-    ObsPref pfn;
-    prefetch_obs<false, false>(p, nxt, cur, wd.obs_off, pfn, lane);
+    if (keep) prefetch_obs<false, false>(p, nxt, cur, wd.obs_off, pfn, lane);
     SLS_K1_STAMP(0);
     for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
       SLS_PHASE("tile_head");
@@ -501,7 +505,6 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
       const double2* lg = reinterpret_cast<const double2*>(p.line_elim + (long long)lsafe * p.line_elim_stride + kLeG);
       kq.g[0] = lg[0]; kq.g[1] = lg[1];
     };
-    TileCtx nxt = resolve_tile(rq0);
     Kept kn;
     request(ck.tile_begin, nxt, kn);
     for (int t = ck.tile_begin; t < ck.tile_end; ++t) {

@@ -642,6 +642,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double* S = camscale + (n > 0 ? n : 6);
   signed char* camcf = (signed char*)(S + nsys);
   const bool fresh = !INIT && (FRESH < 0 ? st->fresh != 0 : FRESH == 1);   // this sweep is also the initial evaluation: see below
+  // first tile: context and observations requested before the camera table is built (a chunk's set-up is a chain of round trips to
+  // memory; on the latency path - chunks of a tile or two - it is a third of the sweep)
+  TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
+  ObsPref pfn;
+  prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
   SLS_K1_STAMP(6);
   load_cam_table<true>(p, wd, cur, lane, camtab, camscale, camcf, INIT || fresh, p.cam_tab ? ((INIT || fresh) ? 1 : 2) : 0);
   SLS_K1_STAMP(7);
@@ -651,9 +656,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
   double acc_cost = 0.0, acc_fixed = 0.0, acc_gmax = 0.0, acc_xn2 = 0.0;
   int fail = 0;
-  TileCtx nxt = fetch_tile(p, ck.tile_begin, ck.tile_end, lane);
-  ObsPref pfn;
-  prefetch_obs<false, !INIT>(p, nxt, cur, wd.obs_off, pfn, lane);
 #if defined(SLSLAM_K1_TIMING) && SLSLAM_K1_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1624,6 +1626,11 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
   double* candtab = bstab + wd.C * kBsTab;
   double* red = candtab + wd.C * kCandTab;             // [2][4] per-wave sums
   signed char* camcf = (signed char*)(red + 8);
+  // the first tile's observations are requested before the tables are built (see k_eliminate_grouped: a chunk's set-up is a chain of
+  // round trips to memory, and this link can overlap the next ones)
+  TileCtx nxt = resolve_tile(rq0);
+  ObsPref pfn;
+  prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
   for (int c = tid; c < wd.C; c += 64 * nw) {
     // accepted pose: R, t and the camera step folded through JL and the Jacobi scale;
     // candidate pose (written by k_reduced_solve): R, t for the cost at the candidate point
@@ -1666,9 +1673,6 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
   SLS_K1_STAMP(8);
 
   double acc_model = 0.0, acc_dn2 = 0.0, acc_xn2 = 0.0, acc_cost = 0.0;
-  TileCtx nxt = resolve_tile(rq0);
-  ObsPref pfn;
-  prefetch_obs<true>(p, nxt, cur, wd.obs_off, pfn);
 #if defined(SLSLAM_K1_TIMING) && SLSLAM_K1_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
