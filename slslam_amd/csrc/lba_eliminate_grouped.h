@@ -105,7 +105,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
   // that can overlap another one is a few microseconds per chunk)
   TileCtx nxt = resolve_tile(rq0);
   ObsPref pfn;
-  if (!keep) prefetch_obs<false, false>(p, nxt, cur, wd.obs_off, pfn, lane);      // (the KEEP form has no register for it here)
+  if (!keep) prefetch_obs<FRESH, false>(p, nxt, cur, wd.obs_off, pfn, lane);      // (the KEEP form has no register for it here)
   for (int c = lane; c < wd.C; c += 64) {
     const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + cur) * kCamRec;
     double w[3] = { x[0], x[1], x[2] }, R[9];
@@ -280,7 +280,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
   double acc_cost = 0.0, acc_fixed = 0.0, acc_gmax = 0.0, acc_xn2 = 0.0;
   int fail = 0;
   if (!replay) {
-    if (keep) prefetch_obs<false, false>(p, nxt, cur, wd.obs_off, pfn, lane);
+    if (keep) prefetch_obs<FRESH, false>(p, nxt, cur, wd.obs_off, pfn, lane);
     SLS_K1_STAMP(0);
     for (int t = ck.tile_begin; t < ck.tile_end; ++t) {
       SLS_PHASE("tile_head");
@@ -296,6 +296,9 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
       const bool kept = valid && !(cf < 0 && !line_free);
       const bool line_active = line_free && k > 0;     // uniform over the line's run
       const bool cam_free = valid && cf >= 0;
+      // (first sweep: |x|^2 of the line's parameters for Ceres' initial evaluation, from the prefetched record - a load where it is
+      // needed would stand there for a round trip)
+      const double un2 = fresh ? pf.u[0] * pf.u[0] + pf.u[1] * pf.u[1] + pf.u[2] * pf.u[2] + pf.u[3] * pf.u[3] : 0.0;
 
       // ---- residual and Jacobians in raw camera coordinates, robustified; the line's columns Jacobi-scaled.  The rows of J_c' are
       // parked in the lane's own slab of the F panel (free until this tile's F rows are written) and come back when the
@@ -378,11 +381,11 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
         for (int a = 0; a < 4; ++a) sl[a] = (pol.jacobi_scaling && line_active) ? 1.0 / (1.0 + sqrt(d[a])) : 1.0;
         if (line_ok && j == 0) {
           double* lsc = p.line_scale + (long long)ls * 4;
-          const double* ul = p.line_x + line_rec(p, ls, cur);
           for (int a = 0; a < 4; ++a) {
             lsc[a] = sl[a];
-            if (line_active) { acc_gmax = fmax(acc_gmax, fabs(g[a])); acc_xn2 += ul[a] * ul[a]; }
+            if (line_active) acc_gmax = fmax(acc_gmax, fabs(g[a]));
           }
+          if (line_active) acc_xn2 += un2;
         }
         H[0] *= sl[0] * sl[0]; H[1] *= sl[1] * sl[0]; H[2] *= sl[1] * sl[1]; H[3] *= sl[2] * sl[0]; H[4] *= sl[2] * sl[1];
         H[5] *= sl[2] * sl[2]; H[6] *= sl[3] * sl[0]; H[7] *= sl[3] * sl[1]; H[8] *= sl[3] * sl[2]; H[9] *= sl[3] * sl[3];
@@ -482,7 +485,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
       SLS_PHASE("prefetch_next");
       // the next tile's loads go out here: their latency overlaps the matrix-core phase
       nxt = resolve_tile(rq);
-      prefetch_obs<false, false>(p, nxt, cur, wd.obs_off, pfn, lane);
+      prefetch_obs<FRESH, false>(p, nxt, cur, wd.obs_off, pfn, lane);
 
       matrix_phase(descv);
     }
