@@ -455,8 +455,11 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
       const long long per_round = 36LL * b->elim_waves * slots;
       const long long rounds = std::max<long long>(1, (total_tiles + per_round - 1) / per_round);
       const long long cpw = std::max<long long>(1, (slots * rounds) / std::max(1, B));
-      // (at least 2 tiles per wave: below that the camera table set-up and the partial written per chunk outweigh the tiles)
-      per_chunk = (int)std::max<long long>(2 * b->elim_waves, (wd.ntiles + cpw - 1) / cpw);
+      // (down to ONE tile per wave when the chip has room: since the camera tables are shared through memory, the partials of a
+      // many-chunk window summed chip-wide (k_slab_reduce) and the first tile's loads requested ahead of the set-up, a second tile
+      // costs a resident window more than a second chunk does - 0.44 / 0.60 / 0.98 -> 0.38 / 0.50 / 0.89 ms at W = 5 / 10 / 20,
+      // round 4; rounds 2-3 kept at least two tiles per wave)
+      per_chunk = (int)std::max<long long>(b->elim_waves, (wd.ntiles + cpw - 1) / cpw);
     }
     std::vector<int> bounds = chunk_boundaries(wd.ntiles, per_chunk);
     if (b->big_mode) { bounds.assign(2, 0); }            // no tiles: one chunk per window carries its step statistics
