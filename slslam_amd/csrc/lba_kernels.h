@@ -1038,6 +1038,20 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
   const int fresh = st->fresh;            // read before the barriers below: wave 0 clears it in step 1b
   const bool timing = (pol.debug_flags & 512) && p.dbg_cycles;
   unsigned long long tlast_ = timing ? solve_clock() : 0ull;
+  // The latency form (RESIDENT == 1: at most one window per CU) asks NOW for what its last phase needs of the window's cameras -
+  // pose, Jacobi scale, free index: known before the solve, read after it as a chain of dependent round trips otherwise
+  // (index, then per component the pose entry behind the store of the previous one: ~3 k of the launch's 50 k cycles).
+  constexpr bool kPreloadCams = RESIDENT == 1;
+  double pre_x[6], pre_s[6];
+  int pre_cf = -1;
+  if (kPreloadCams && wave < 2) {
+    const int c = lane < wd.C ? lane : 0;
+    pre_cf = p.cam_cf[wd.cam_off + c];
+    const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + cur) * kCamRec;
+    const double* sc = p.cam_scale + (long long)(wd.cam_off + c) * 6;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { pre_x[a] = x[a]; pre_s[a] = sc[a]; }
+  }
 
   // ---- 1. ordered reduction over the window's chunk partials (uniform stride between consecutive slabs)
   const bool mfma_slab = p.elim_mode == 1;          // slab layout of lba_eliminate_mfma.h
@@ -1046,6 +1060,17 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
   const int nsys_slab = mfma_slab ? kMfmaTiles * 256 + ncf * kMfmaRec : image ? N * ld + 6 * N : nsys;
   const double* slab_base = presummed ? p.slab_sum : p.slab;
   const long long slab0 = presummed ? (long long)w * p.slab_sum_stride : (wd.nchunks > 0 ? p.chunks[wd.chunk_off].slab_off : 0);
+  const long long sstride = (long long)nsys_slab + kSlabScalars;
+  const int nchunks = presummed ? 1 : wd.nchunks;
+  // (the first chunk scalars of every thread are requested ahead of the image / the zeroing, so that their round trip overlaps it)
+  // (latency form only: the batch form - four workgroups per CU, 128 registers - has other waves to run meanwhile and no register for it)
+  constexpr bool kEarlyScalars = RESIDENT == 1;
+  const bool have_sc0 = kEarlyScalars && tid < nchunks;
+  double sc0_gmax = 0.0, sc0_fail = 0.0;
+  if (kEarlyScalars) {
+    const double* sc0 = slab_base + slab0 + (long long)(have_sc0 ? tid : 0) * sstride + nsys_slab;
+    sc0_gmax = sc0[kScGradMaxLine]; sc0_fail = sc0[kScFail];
+  }
   if (image) {
     const double2* src = reinterpret_cast<const double2*>(slab_base + slab0);
     double2* dst = reinterpret_cast<double2*>(smem);
@@ -1055,8 +1080,6 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
     for (int q = tid; q < 6 * N; q += 256) bvec[q] = 0.0;
   }
   __syncthreads();
-  const long long sstride = (long long)nsys_slab + kSlabScalars;
-  const int nchunks = presummed ? 1 : wd.nchunks;
   const unsigned short* smap = p.sys_map + wd.map_off;
   if (mfma_slab) {
     // The matrix-core sweep leaves everything in RAW camera coordinates (J_c' = [tau | gP]: no SO(3) left Jacobian, no
@@ -1232,9 +1255,9 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
   int fail = 0;
   {
     // per-chunk scalars: the threads share the chunks (a single window has ~50 of them), then a block-wide max / any
-    double gm = 0.0;
-    int fl = 0;
-    for (int k = tid; k < nchunks; k += 256) {
+    double gm = have_sc0 ? sc0_gmax : 0.0;
+    int fl = (have_sc0 && sc0_fail != 0.0) ? 1 : 0;
+    for (int k = kEarlyScalars ? tid + 256 : tid; k < nchunks; k += 256) {
       const double* sc = slab_base + slab0 + (long long)k * sstride + nsys_slab;
       gm = fmax(gm, sc[kScGradMaxLine]);
       if (sc[kScFail] != 0.0) fl = 1;
@@ -1471,13 +1494,14 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
   // rotation / Jacobian table for the sweeps that follow (BatchPtrs.cam_tab)
   if (wave == 1 && p.cam_tab) {
     for (int c = lane; c < wd.C; c += 64) {
-      const int cf = p.cam_cf[wd.cam_off + c];
+      const bool pre = kPreloadCams && c == lane;          // (kMaxCams = 64: the loop runs once)
+      const int cf = pre ? pre_cf : p.cam_cf[wd.cam_off + c];
       const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + cur) * kCamRec;
       double xc[6];
       for (int a = 0; a < 6; ++a) {
-        double v = x[a];
+        double v = pre ? pre_x[a] : x[a];
         if (cf >= 0) {                                      // (the candidate pose, statement for statement as wave 0 forms it)
-          const double d = -yvec[6 * cf + a] * p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
+          const double d = -yvec[6 * cf + a] * ((pre && !fresh) ? pre_s[a] : p.cam_scale[(long long)(wd.cam_off + c) * 6 + a]);
           const double xn = v + d;
           v = xn;
         }
@@ -1500,13 +1524,14 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
     p.ysys[wd.sys_off + q] = y;
   }
   for (int c = lane; c < wd.C; c += 64) {
-    const int cf = p.cam_cf[wd.cam_off + c];
+    const bool pre = kPreloadCams && c == lane;
+    const int cf = pre ? pre_cf : p.cam_cf[wd.cam_off + c];
     const double* x = p.cam_x + ((long long)(wd.cam_off + c) * 2 + cur) * kCamRec;
     double* xc = p.cam_x + ((long long)(wd.cam_off + c) * 2 + (1 - cur)) * kCamRec;
     for (int a = 0; a < 6; ++a) {
-      double v = x[a];
+      double v = pre ? pre_x[a] : x[a];
       if (cf >= 0) {
-        const double d = -yvec[6 * cf + a] * p.cam_scale[(long long)(wd.cam_off + c) * 6 + a];
+        const double d = -yvec[6 * cf + a] * ((pre && !fresh) ? pre_s[a] : p.cam_scale[(long long)(wd.cam_off + c) * 6 + a]);
         const double xn = v + d;
         const double dd = v - xn;
         dn2 += dd * dd;
