@@ -238,6 +238,9 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   int arena_device = 0;
   const int nj = structured ? n - n_chain : 0;
   const int nblk_j = (nj + kNB - 1) / kNB;
+  const long long zero_items = (long long)E * 144 + (long long)nj * nj + n + 1;       // k_po_zero_structured
+  const dim3 g_zero((unsigned)((zero_items + 255) / 256));
+  const bool zero_small = structured && n > 0 && !std::getenv("SLSLAM_PO_FULL_MEMSET");
   int *d_p1 = nullptr, *d_p2 = nullptr, *d_slot = nullptr;
   double *d_cons = nullptr, *d_linv = nullptr;
   float *d_Hf = nullptr, *d_linvf = nullptr, *d_Lff = nullptr;
@@ -304,8 +307,14 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   if (po_step_lds_attributes() != hipSuccess) { PO_TRY(hipErrorInvalidValue); }
   stamp(); stamp();                       // [1] is re-recorded at the end
   // ---- initial evaluation: cost, gradient, column norms -> Jacobi scale
-  PO_TRY(hipMemsetAsync(p.H, 0, hbytes, 0));
-  PO_TRY(hipMemsetAsync(p.g, 0, sizeof(double) * ones.size(), 0));
+  // (structured: only what the linearisation adds into and the junction block are zeroed, by one small launch: k_po_zero_structured)
+  if (zero_small) {
+    PO_TRY(hipMemsetAsync(p.g, 0, sizeof(double) * ones.size(), 0));      // (once: the padding behind the n gradient entries)
+    hipLaunchKernelGGL(k_po_zero_structured, g_zero, dim3(256), 0, 0, p, n_chain);
+  } else {
+    PO_TRY(hipMemsetAsync(p.H, 0, hbytes, 0));
+    PO_TRY(hipMemsetAsync(p.g, 0, sizeof(double) * ones.size(), 0));
+  }
   hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 0);
   hipLaunchKernelGGL(k_po_prepare, dim3(1), dim3(256), 0, 0, p, pol, 1);
   // ---- LM iterations, enqueued without host synchronisation; finished solves early-out on device
@@ -315,9 +324,12 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
       PO_TRY(hipStreamSynchronize(0));
       if (hst.status != kRunning) break;
     }
-    PO_TRY(hipMemsetAsync(p.H, 0, hbytes, 0));
-    PO_TRY(hipMemsetAsync(p.g, 0, sizeof(double) * ones.size(), 0));
-    PO_TRY(hipMemsetAsync(p.scal, 0, sizeof(double), 0));            // kPoCost
+    if (zero_small) hipLaunchKernelGGL(k_po_zero_structured, g_zero, dim3(256), 0, 0, p, n_chain);
+    else {
+      PO_TRY(hipMemsetAsync(p.H, 0, hbytes, 0));
+      PO_TRY(hipMemsetAsync(p.g, 0, sizeof(double) * ones.size(), 0));
+      PO_TRY(hipMemsetAsync(p.scal, 0, sizeof(double), 0));            // kPoCost
+    }
     hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 0);
     hipLaunchKernelGGL(k_po_prepare, dim3(1), dim3(256), 0, 0, p, pol, 0);
     if (f32) hipLaunchKernelGGL(k_po_to_f32, dim3(256), dim3(256), 0, 0, p, d_Hf);

@@ -205,6 +205,33 @@ __global__ __launch_bounds__(64) void k_po_linearise(PoPtrs p, int mode) {
   if (lane == 0) atomicAdd(&p.scal[kPoCost], cost);
 }
 
+// Structured factorisation only: zeroes what the linearisation is about to add into - the lower-triangle entries of every edge's two
+// pose blocks and their coupling (the same index rule as k_po_linearise), the junction block (the dense factorisation reads all of it),
+// the gradient and the cost - instead of a memset of the whole dense matrix (20 MB at 1554 unknowns, a third of a structured solve
+// in fill kernels).  Everything else the structured path reads from H it has written itself (k_po_chain_eliminate: factor and fill).
+__global__ __launch_bounds__(256) void k_po_zero_structured(PoPtrs p, int n_chain) {
+  if (p.st->status != kRunning) return;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long n_edge = (long long)p.E * 144;
+  const int nj = p.n - n_chain;
+  const long long n_junc = (long long)nj * nj;
+  if (t < n_edge) {
+    const int e = (int)(t / 144), q = (int)(t - 144LL * e), d = q / 12, dp = q - 12 * d;
+    const int sa = p.slot[p.p1[e]], sb = p.slot[p.p2[e]];
+    const int my = d < 6 ? (sa >= 0 ? sa + d : -1) : (sb >= 0 ? sb + d - 6 : -1);
+    const int other = dp < 6 ? (sa >= 0 ? sa + dp : -1) : (sb >= 0 ? sb + dp - 6 : -1);
+    if (my >= 0 && other >= 0 && my >= other) p.H[(long long)my * p.ld + other] = 0.0;
+  } else if (t < n_edge + n_junc) {
+    const long long q = t - n_edge;
+    const int r = (int)(q / nj), c = (int)(q - (long long)r * nj);
+    p.H[(long long)(n_chain + r) * p.ld + n_chain + c] = 0.0;
+  } else if (t < n_edge + n_junc + p.n) {
+    p.g[t - n_edge - n_junc] = 0.0;
+  } else if (t == n_edge + n_junc + p.n) {
+    p.scal[kPoCost] = 0.0;
+  }
+}
+
 // one workgroup: gradient max-norm, Jacobi scale on the first call, damping, rhs.
 // first = 1: H holds the UNSCALED J^T J (scale == 1); compute scale, rescale H and g in place.
 __global__ __launch_bounds__(256) void k_po_prepare(PoPtrs p, Policy pol, int first) {
