@@ -240,14 +240,26 @@ __global__ __launch_bounds__(256) void k_po_prepare(PoPtrs p, Policy pol, int fi
   __shared__ double red[256];
   const int tid = threadIdx.x;
   double gm = 0.0;
-  for (int i = tid; i < p.n; i += 256) {
-    double s = p.scale[i];
-    if (first) {
-      s = pol.jacobi_scaling ? 1.0 / (1.0 + sqrt(p.H[(long long)i * p.ld + i])) : 1.0;
-      gm = fmax(gm, fabs(p.g[i]));
-      p.scale[i] = s;
-    } else {
-      gm = fmax(gm, fabs(p.g[i] / s));
+  for (int i0 = tid; i0 < p.n; i0 += 8 * 256) {        // eight entries of this thread at a time: their loads travel together
+    double sv[8], hv[8], gv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u, is = i < p.n ? i : 0;
+      sv[u] = p.scale[is]; gv[u] = p.g[is];
+      hv[u] = p.H[(long long)is * p.ld + is];             // (unconditionally: a load under `first` is merged with its default by copies, i.e. waited for on the spot)
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u;
+      if (i >= p.n) continue;
+      double s = sv[u];
+      if (first) {
+        s = pol.jacobi_scaling ? 1.0 / (1.0 + sqrt(hv[u])) : 1.0;
+        gm = fmax(gm, fabs(gv[u]));
+        p.scale[i] = s;
+      } else {
+        gm = fmax(gm, fabs(gv[u] / s));
+      }
     }
   }
   red[tid] = gm;
@@ -287,11 +299,22 @@ __global__ __launch_bounds__(256) void k_po_prepare(PoPtrs p, Policy pol, int fi
     if (st->status != kRunning) return;
   }
   const double radius = st->radius;
-  for (int i = tid; i < p.n; i += 256) {
-    const double d2 = fmin(fmax(p.H[(long long)i * p.ld + i], pol.min_lm_diagonal), pol.max_lm_diagonal) / radius;
-    p.d2[i] = d2;
-    p.H[(long long)i * p.ld + i] += d2;
-    p.y[i] = p.g[i];
+  for (int i0 = tid; i0 < p.n; i0 += 8 * 256) {
+    double hv[8], gv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u, is = i < p.n ? i : 0;
+      hv[u] = p.H[(long long)is * p.ld + is]; gv[u] = p.g[is];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u;
+      if (i >= p.n) continue;
+      const double d2 = fmin(fmax(hv[u], pol.min_lm_diagonal), pol.max_lm_diagonal) / radius;
+      p.d2[i] = d2;
+      p.H[(long long)i * p.ld + i] = hv[u] + d2;
+      p.y[i] = gv[u];
+    }
   }
   if (tid == 0) { p.flags[0] = 0; p.scal[kPoCandCost] = 0.0; }
 }
@@ -963,14 +986,20 @@ __global__ __launch_bounds__(256) void k_po_candidate(PoPtrs p) {
   double model = 0.0, dn2 = 0.0, xn2 = 0.0;
   int bad = 0;
   for (int k = tid; k < p.N; k += 256) {
-    const int s = p.slot[k];
+    // (all loads of a pose first, the conditional ones from a safe index: behind the stores of the candidate and under the
+    // condition they would be one dependent round trip per component)
+    const int s = p.slot[k], ss = s >= 0 ? s : 0;
+    double xv[6], yv[6], gv[6], dv[6], sv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { xv[i] = X[6 * k + i]; yv[i] = p.y[ss + i]; gv[i] = p.g[ss + i]; dv[i] = p.d2[ss + i]; sv[i] = p.scale[ss + i]; }
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
-      double v = X[6 * k + i];
+      double v = xv[i];
       if (s >= 0) {
-        const double y = p.y[s + i];
+        const double y = yv[i];
         if (!isfinite(y)) bad = 1;
-        model += 0.5 * y * (p.g[s + i] + p.d2[s + i] * y);
-        const double xn = v - y * p.scale[s + i];
+        model += 0.5 * y * (gv[i] + dv[i] * y);
+        const double xn = v - y * sv[i];
         const double dd = v - xn;
         dn2 += dd * dd; xn2 += xn * xn;
         v = xn;
