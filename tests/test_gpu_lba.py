@@ -551,6 +551,39 @@ def test_kept_jacobian_sweep_after_rejected_steps(hip, oracle):
     b.close()
 
 
+def test_non_finite_input_is_refused_at_the_boundary(hip):
+    """ADVICE round 3 (lane_F / line_block rely on K = 0 for constant lines: 0 x inf would be NaN): non-finite observations or
+    parameters never reach a kernel - slslam_pack_window / slslam_lba_solve / slslam_lba_batch_add return
+    SLSLAM_ERR_INVALID_ARGUMENT (the reference has no error convention, SURVEY 8b: a replacement may add a status) on every
+    path (fused motion-only, general sweeps, constant lines among free ones), whichever block holds the value."""
+    mo = synth.make_motion_only(12, num_lines=60)
+    mixed = dict(synth.make_window(13, num_lines=120))
+    fx = np.asarray(mixed["fixed_index"]).reshape(-1, 2).copy()
+    fx[np.isin(np.asarray(mixed["line_index"]), (3, 17, 40)), 1] = 1
+    mixed["fixed_index"] = fx.reshape(-1)
+    for base, opts in ((mo, dict()), (mo, dict(lba_fused_motion_only=0)), (mixed, dict()), (mixed, dict(lba_elimination=4))):
+        hip.lba_solve(base, **opts)                            # the finite window solves
+        fixed = np.asarray(base["fixed_index"]).reshape(-1, 2)
+        for cam_fixed in (0, 1):
+            idx = np.flatnonzero((fixed[:, 1] == 1) & (fixed[:, 0] == cam_fixed))
+            if len(idx) == 0:
+                idx = np.flatnonzero(fixed[:, 0] == cam_fixed)
+            i = int(idx[len(idx) // 2])
+            for val in (np.inf, -np.inf, np.nan):
+                w = dict(base); ob = np.array(w["observations"], dtype=np.float64).reshape(-1, 8).copy()
+                ob[i, 3] = val; w["observations"] = ob.reshape(-1)
+                with pytest.raises(hip.SlslamError) as e:
+                    hip.lba_solve(w, **opts)
+                assert e.value.status == 1
+                b = hip.LBABatch()
+                with pytest.raises(hip.SlslamError):
+                    b.add(w)
+                b.close()
+        w = dict(base); x = np.array(w["parameters"], dtype=np.float64).reshape(-1).copy(); x[7] = np.nan; w["parameters"] = x
+        with pytest.raises(hip.SlslamError):
+            hip.lba_solve(w, **opts)
+
+
 def test_one_shot_solves_reuse_their_device_block(hip, oracle):
     """slslam_lba_solve / slslam_po_solve keep the device block of the previous call (device_cache.h): solves of different
     shapes back to back, interleaved with pose-graph solves, still match the oracle - nothing depends on fresh memory."""
