@@ -224,6 +224,7 @@ struct slslam_lba_batch {
   slslam_lba_batch* part[2] = { nullptr, nullptr };
   std::vector<std::pair<int, int>> route;
   std::vector<long long> part_param_off[2];  // per window of a part: where its parameters go in the caller's export layout
+  DevBuf<long long> d_part_off[2];           // [3 nwin] per window of a part: offset in the part's export | offset in the caller's | length (k_scatter_windows)
   hipStream_t part_stream = nullptr;
   hipEvent_t part_fork = nullptr, part_join = nullptr;
   DevBuf<double> d_part_out[2];
@@ -318,7 +319,7 @@ int finalize_mixed(slslam_lba_batch* b) {
   if (b->wins.empty() && !b->route.empty()) b->wins = std::move(back);
   for (int h = 0; h < 2; ++h) {
     if (b->part[h]) { slslam_lba_batch_destroy(b->part[h]); b->part[h] = nullptr; }
-    b->d_part_out[h].release(); b->part_param_off[h].clear();
+    b->d_part_out[h].release(); b->d_part_off[h].release(); b->part_param_off[h].clear();
   }
   if (b->part_stream) { (void)hipStreamDestroy(b->part_stream); b->part_stream = nullptr; }
   if (b->part_fork) { (void)hipEventDestroy(b->part_fork); b->part_fork = nullptr; }
@@ -344,6 +345,15 @@ int finalize_mixed_impl(slslam_lba_batch* b) {
   for (int h = 0; h < 2; ++h) {
     if ((rc = slslam_lba_batch_finalize(b->part[h], &b->opt)) != SLSLAM_OK) return rc;
     if ((rc = b->d_part_out[h].alloc((size_t)std::max<long long>(1, b->part[h]->total_params))) != SLSLAM_OK) return rc;
+    const slslam_lba_batch* pb = b->part[h];
+    const size_t nw = pb->h_param_off.size();
+    std::vector<long long> offs(3 * std::max<size_t>(1, nw), 0);
+    for (size_t i = 0; i < nw; ++i) {
+      offs[3 * i] = pb->h_param_off[i]; offs[3 * i + 1] = b->part_param_off[h][i];
+      offs[3 * i + 2] = (i + 1 < nw ? pb->h_param_off[i + 1] : pb->total_params) - pb->h_param_off[i];
+    }
+    if ((rc = b->d_part_off[h].alloc(offs.size())) != SLSLAM_OK) return rc;
+    HIP_TRY(hipMemcpy(b->d_part_off[h].p, offs.data(), offs.size() * sizeof(long long), hipMemcpyHostToDevice));
   }
   HIP_TRY(hipStreamCreateWithFlags(&b->part_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&b->part_fork, hipEventDisableTiming));
@@ -1045,6 +1055,14 @@ extern "C" int slslam_lba_batch_iterations(slslam_lba_batch* b, void* stream, lo
   return SLSLAM_OK;
 }
 
+namespace {
+// mixed batch: window blockIdx.x of a part's export goes to its place in the caller's layout; offs = [source offset | destination offset | length] per window
+__global__ __launch_bounds__(256) void k_scatter_windows(const double* src, double* dst, const long long* offs) {
+  const long long so = offs[3 * (long long)blockIdx.x], dofs = offs[3 * (long long)blockIdx.x + 1], n = offs[3 * (long long)blockIdx.x + 2];
+  for (long long q = threadIdx.x; q < n; q += 256) dst[dofs + q] = src[so + q];
+}
+}  // namespace
+
 extern "C" int slslam_lba_batch_export_device(slslam_lba_batch* b, double* device_out, void* stream) {
   if (!b || !device_out) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (!b->finalized) return SLSLAM_ERR_STATE;
@@ -1055,10 +1073,10 @@ extern "C" int slslam_lba_batch_export_device(slslam_lba_batch* b, double* devic
       const slslam_lba_batch* pb = b->part[h];
       int rc = slslam_lba_batch_export_device(b->part[h], b->d_part_out[h].p, stream);
       if (rc != SLSLAM_OK) return rc;
-      for (size_t i = 0; i < pb->h_param_off.size(); ++i) {
-        const long long n = (i + 1 < pb->h_param_off.size() ? pb->h_param_off[i + 1] : pb->total_params) - pb->h_param_off[i];
-        if (n > 0) HIP_TRY(hipMemcpyAsync(device_out + b->part_param_off[h][i], b->d_part_out[h].p + pb->h_param_off[i], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-      }
+      // one launch per part puts its windows where the caller's order has them (not one device-to-device copy per window)
+      const unsigned nw = (unsigned)pb->h_param_off.size();
+      if (nw > 0) hipLaunchKernelGGL(k_scatter_windows, dim3(nw), dim3(256), 0, s, (const double*)b->d_part_out[h].p, device_out, (const long long*)b->d_part_off[h].p);
+      HIP_TRY(hipGetLastError());
     }
     return SLSLAM_OK;
   }
