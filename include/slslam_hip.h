@@ -69,7 +69,10 @@ typedef struct slslam_solver_options {
   double parameter_tolerance;           /* 1e-8  */
   int    jacobi_scaling;                /* 1     */
   int    use_graph;                     /* 1: replay the LM iteration as a captured hipGraph    */
-  int    chunks_per_window;             /* 0 = auto; waves cooperating on one window            */
+  int    chunks_per_window;             /* 0 = auto; n > 0: n equal chunks (waves cooperating on one window); n < 0: -(1000 r + c), c chunks
+                                           of GRADED sizes made for r rounds of the chip's wave slots - long chunks first, short ones last -
+                                           as the automatic choice cuts the windows of a batch whose slots each run several chunks (what
+                                           slslam_lba_batch_window_chunks reports for such a window: pass it back to get the same cut)     */
   int    reuse_elimination;             /* 0: the back-substitution re-linearises (HBM traffic ==
                                            algorithmic); 1: it streams Jacobian blocks the elimination
                                            spilled to HBM (+192 B per coupled observation)         */
@@ -203,7 +206,8 @@ int  slslam_lba_batch_elimination(const slslam_lba_batch* b, int* mode);
 /* After finalize: the number of chunks (waves cooperating on the window's observation sweeps) window `index` was cut into.  A
  * window's result is a function of its inputs, the options and this number only (the chunk partials are summed in chunk order):
  * a window solved again with chunks_per_window set to it - in any batch that keeps the chunk count at 8 or below, or above 8 -
- * reproduces its result bit for bit, which is how results are compared across the ranks of a multi-GPU run (bench.py). */
+ * reproduces its result bit for bit, which is how results are compared across the ranks of a multi-GPU run (bench.py).
+ * NEGATIVE: -(1000 r + c): c chunks of graded sizes made for r rounds of the wave slots (chunks_per_window set to it asks for the same cut). */
 int  slslam_lba_batch_window_chunks(const slslam_lba_batch* b, int index, int* num_chunks);
 /* Device time (ms) spent in each kernel family during the last solve, measured with HIP events
  * on the solve stream while profiling is enabled (solves are then launched eagerly instead of
@@ -315,6 +319,10 @@ int slslam_po_last_timing(double* total_ms, double* factor_ms, int* factor_calls
 /* Timing experiments of the matrix-core elimination sweep / the reduced solve (environment SLSLAM_DEBUG_ABLATE, bits 8 / 9):
  * wave-clock cycles per phase summed over the batch since finalize; out[16].  SLSLAM_ERR_STATE unless the variable was set. */
 int slslam_debug_phase_cycles(slslam_lba_batch* batch, double* out);
+/* The same buffer raw (timing builds, -DSLSLAM_K1_TIMING=1: 32 words per chunk - the elimination sweep's phase cycles and, in words
+ * 30 / 31, the constant-clock (s_memrealtime, 100 MHz) times at which the chunk's wave started and ended its last sweep: what
+ * tools/chunk_timeline.py reads).  Copies min(n, size) words; *size = words the buffer holds. */
+int slslam_debug_read_cycles(slslam_lba_batch* batch, unsigned long long* out, long long n, long long* size);
 
 /* ------------------------------------------------------------------ misc */
 int         slslam_device_count(void);          /* 0 when no HIP device is usable */

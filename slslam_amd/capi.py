@@ -83,7 +83,7 @@ EXPORTS = [
     "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts", "slslam_lba_batch_window_chunks", "slslam_lba_batch_path", "slslam_lba_batch_elimination",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
-    "slslam_po_solve", "slslam_po_structure", "slslam_po_set_profiling", "slslam_po_last_timing", "slslam_debug_phase_cycles", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_release_cached_memory", "slslam_version", "slslam_status_string",
+    "slslam_po_solve", "slslam_po_structure", "slslam_po_set_profiling", "slslam_po_last_timing", "slslam_debug_phase_cycles", "slslam_debug_read_cycles", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_release_cached_memory", "slslam_version", "slslam_status_string",
 ]
 
 _lib = None
@@ -134,6 +134,7 @@ def lib():
     L.slslam_po_set_profiling.argtypes = [C.c_int]
     L.slslam_po_last_timing.argtypes = [dp, dp, ip, ip, ip]
     L.slslam_debug_phase_cycles.argtypes = [vp, dp]
+    L.slslam_debug_read_cycles.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_longlong, C.POINTER(C.c_longlong)]
     L.slslam_device_count.restype = C.c_int
     L.slslam_release_cached_memory.restype = None
     L.slslam_version.restype = C.c_char_p

@@ -223,6 +223,7 @@ struct slslam_lba_batch {
   // the caller's.  This object then only routes: window i of the caller is window route[i].second of part[route[i].first].
   slslam_lba_batch* part[2] = { nullptr, nullptr };
   std::vector<std::pair<int, int>> route;
+  std::vector<int> h_win_graded;             // per window: 0, or the number of slot rounds its graded chunk sizes were made for (finalize)
   std::vector<long long> part_param_off[2];  // per window of a part: where its parameters go in the caller's export layout
   DevBuf<long long> d_part_off[2];           // [3 nwin] per window of a part: offset in the part's export | offset in the caller's | length (k_scatter_windows)
   hipStream_t part_stream = nullptr;
@@ -411,7 +412,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     // (zeroing its 20 KB of accumulator tiles in memory, adding the group sums into them) is not worth it
     long long tiles_in_batch = 0;
     for (const PackedWindow& P : b->wins) tiles_in_batch += (long long)P.tiles.size();
-    const bool auto_grouped = want == 0 && mfma_ok && b->opt.chunks_per_window <= 0 && tiles_in_batch >= 16LL * 8 * b->num_cus;
+    const bool auto_grouped = want == 0 && mfma_ok && b->opt.chunks_per_window == 0 && tiles_in_batch >= 16LL * 8 * b->num_cus;
     b->elim_mode = ((want >= 2 || auto_grouped) && mfma_ok) ? 1 : 0;
     b->elim_waves = b->elim_mode == 0 ? 1 : (want == 3 ? 2 : 1);
     b->elim_grouped = b->elim_mode == 1 && (want == 4 || auto_grouped);
@@ -430,6 +431,8 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   }
 
   // ---- global layout
+  std::vector<int> chunk_rank;           // per chunk (window-major): 0 dispatched in the first class, 1 in the second (graded sizes)
+  b->h_win_graded.assign((size_t)std::max(1, B), 0);
   std::vector<Tile> tiles; std::vector<Chunk> chunks; std::vector<uint8_t> items; std::vector<uint16_t> lane_map; std::vector<uint32_t> line_desc;
   std::vector<double> cam_x, line_x, ob, cam_x0, line_u0; std::vector<int> cam_cf, cam_win, line_ptr, line_flags, line_win, line_orig, ob_cam, ob_orig;
   long long ncam = 0, nline = 0, nobs = 0, sys = 0, slab = 0, param_off = 0;
@@ -456,6 +459,12 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     // the reduced system (a slab in HBM) small against the observation stream; many short chunks
     // fill the chip when the batch is small.
     int per_chunk;
+    int graded_chunks = 0, graded_rounds = 0;             // > 0: graded chunk sizes (below)
+    if (b->opt.chunks_per_window < 0) {                   // the caller asks for the graded cut a batch reported (slslam_lba_batch_window_chunks < 0):
+      graded_rounds = (-b->opt.chunks_per_window) / 1000; graded_chunks = (-b->opt.chunks_per_window) % 1000;        // -(1000 rounds + chunks)
+      if (graded_rounds < 2 || graded_chunks < graded_rounds) return SLSLAM_ERR_INVALID_ARGUMENT;
+      per_chunk = 1;
+    } else
     if (b->opt.chunks_per_window > 0) per_chunk = std::max(1, (wd.ntiles + b->opt.chunks_per_window - 1) / b->opt.chunks_per_window);
     else {
       // the sweeps run 8 one-wave workgroups per CU (LDS): the same number of chunks for every window, chosen so that
@@ -470,15 +479,38 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
       // costs a resident window more than a second chunk does - 0.44 / 0.60 / 0.98 -> 0.38 / 0.50 / 0.89 ms at W = 5 / 10 / 20,
       // round 4; rounds 2-3 kept at least two tiles per wave)
       per_chunk = (int)std::max<long long>(b->elim_waves, (wd.ntiles + cpw - 1) / cpw);
+      // GRADED sizes when every wave slot runs several chunks (rounds >= 2) of many tiles.  A launch ends when the slowest slot has
+      // finished its LAST chunk; with equal chunks - exactly `rounds` per slot, so nothing is left to balance with - that wait was a
+      // fifth of the sweep (tools/chunk_timeline.py: 2048 slots 81 % busy, chunk durations 206-442 us around 297).  Now the chunks a
+      // window contributes to the first round of the slots carry 70 % of a slot's share of the tiles, those of the second round 20 %
+      // (30 % when there are only two), the rest what is left, and the chunk array - the dispatch order - lists the classes one after
+      // the other: a slot that is late with its long chunk takes fewer short ones.  The slab count per window - what the reduced
+      // solve reads - does not change.
+      if (rounds >= 2 && cpw >= rounds && cpw < 1000 && b->elim_waves == 1 && wd.ntiles >= 8 * cpw && !std::getenv("SLSLAM_EQUAL_CHUNKS")) {
+        graded_chunks = (int)cpw; graded_rounds = (int)rounds;
+      }
     }
-    std::vector<int> bounds = chunk_boundaries(wd.ntiles, per_chunk);
+    int weights[1000];
+    for (int c = 0; c < graded_chunks; ++c) {
+      const int q = (int)(((long long)c * graded_rounds) / graded_chunks);           // the round of the slots this chunk belongs to
+      weights[c] = q == 0 ? 84 : q == 1 ? (graded_rounds == 2 ? 36 : 24) : std::max(1, 12 / (graded_rounds - 2));
+    }
+    if (const char* ws = std::getenv("SLSLAM_CHUNK_WEIGHTS")) {           // (experiments: comma-separated weights of the window's chunks)
+      int c = 0;
+      for (const char* q = ws; *q && c < graded_chunks; ++c) { weights[c] = std::max(1, std::atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+    }
+    std::vector<int> bounds = graded_chunks > 0 ? chunk_boundaries_graded(wd.ntiles, graded_chunks, weights) : chunk_boundaries(wd.ntiles, per_chunk);
+    b->h_win_graded[wi] = (graded_chunks > 0 && (int)bounds.size() - 1 == graded_chunks) ? graded_rounds : 0;
     if (b->big_mode) { bounds.assign(2, 0); }            // no tiles: one chunk per window carries its step statistics
     wd.chunk_off = (int)chunks.size(); wd.nchunks = (int)bounds.size() - 1;
+    wd.slab_off = (int)slab;
     const long long slab_stride = (long long)(b->elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n)) + kSlabScalars;
     for (int c = 0; c < wd.nchunks; ++c) {
       Chunk ck; ck.win = wi; ck.tile_begin = wd.tile_off + bounds[c]; ck.tile_end = wd.tile_off + bounds[c + 1];
       ck.slab_off = (int)slab; slab += slab_stride;
+      ck.id = (int)chunks.size();
       chunks.push_back(ck);
+      chunk_rank.push_back(b->h_win_graded[wi] ? (int)(((long long)c * graded_rounds) / graded_chunks) : 0);
     }
     if (slab > 0x7fffffffLL) return SLSLAM_ERR_UNSUPPORTED;
     const int item_base = (int)(items.size() / 2);
@@ -521,6 +553,15 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
       }
       wd.map_off = off < 0 ? 0 : off;
     }
+  }
+  // dispatch order: the long chunks of the graded windows (and every chunk of the others) first, the short ones after them; inside a class
+  // the order of the ids (a stable partition: ids, slabs and partial sums keep their window-major places)
+  {
+    std::vector<Chunk> ordered; ordered.reserve(chunks.size());
+    int max_rank = 0;
+    for (int r : chunk_rank) max_rank = std::max(max_rank, r);
+    for (int r = 0; r <= max_rank; ++r) for (size_t i = 0; i < chunks.size(); ++i) if (chunk_rank[i] == r) ordered.push_back(chunks[i]);
+    chunks.swap(ordered);
   }
   b->total_params = param_off; b->nchunk = (int)chunks.size(); b->nline = (int)nline; b->ncam = (int)ncam;
 
@@ -1186,7 +1227,8 @@ extern "C" int slslam_lba_batch_path(const slslam_lba_batch* b, int* path) {
 extern "C" int slslam_lba_batch_window_chunks(const slslam_lba_batch* b, int index, int* num_chunks) {
   if (!b || !num_chunks || !b->finalized || index < 0 || index >= b->num_windows()) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (b->part[0]) return slslam_lba_batch_window_chunks(b->part[b->route[index].first], b->route[index].second, num_chunks);
-  *num_chunks = b->h_wins[index].nchunks;
+  // < 0: graded sizes, -(1000 x rounds + chunks): passed back as chunks_per_window it asks for the same cut
+  *num_chunks = b->h_win_graded[(size_t)index] ? -(1000 * (int)b->h_win_graded[(size_t)index] + b->h_wins[index].nchunks) : b->h_wins[index].nchunks;
   return SLSLAM_OK;
 }
 
@@ -1203,6 +1245,19 @@ extern "C" int slslam_debug_phase_cycles(slslam_lba_batch* b, double* out) {
   HIP_TRY(hipMemcpy(h.data(), b->d_dbg_cycles.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; ++i) out[i] = 0.0;
   for (size_t q = 0; q < n; ++q) out[q % 16] += (double)h[q];
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_debug_read_cycles(slslam_lba_batch* b, unsigned long long* out, long long n, long long* size) {
+  if (!b || !b->finalized || !size) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (b->part[0]) return slslam_debug_read_cycles(b->part[0], out, n, size);
+  if (!b->pol.debug_flags) return SLSLAM_ERR_STATE;
+  const long long words = (long long)std::max((size_t)32 * std::max(1, b->nchunk), (size_t)16 * std::max<size_t>(1, b->wins.size()));
+  *size = words;
+  if (!out || n <= 0) return SLSLAM_OK;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, b->d_dbg_cycles.p, (size_t)std::min(n, words) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return SLSLAM_OK;
 }
 

@@ -81,6 +81,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
   const int lane = threadIdx.x;
   SLS_K1_STAMP_INIT;
   const Chunk ck = p.chunks[blockIdx.x];
+  SLS_K1_WALL(30);
   const WinDesc wd = p.wins[ck.win];
   const LMState* st = p.state + ck.win;
   if (st->status != kRunning) return;
@@ -601,6 +602,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
     sc[kScFail] = any_fail ? 1.0 : 0.0;
   }
   SLS_K1_STAMP(8);
+  SLS_K1_WALL(31);
 }
 
 }  // namespace slslam

@@ -382,7 +382,7 @@ void k_eliminate_mfma(BatchPtrs p, Policy pol) {
     SLS_STAMP(9);
   }
   if (DBG && (dbg & 256) && lane == 0 && p.dbg_cycles) {
-    for (int i = 0; i < (DBG ? 10 : 1); ++i) p.dbg_cycles[((long long)blockIdx.x * NW + wave) * 16 + i] = tacc[i];
+    for (int i = 0; i < (DBG ? 10 : 1); ++i) p.dbg_cycles[((long long)ck.id * NW + wave) * 16 + i] = tacc[i];
   }
 
   // ---- write-out: accumulator tiles (coalesced 512-byte rows), camera records, scalars

@@ -616,11 +616,19 @@ __host__ __device__ inline int lds_doubles_linearise(int C, int n) {
 // of one chunk's sweep, summed over chunks into dbg_cycles[chunk * 32 + i]
 #if defined(SLSLAM_K1_TIMING) && SLSLAM_K1_TIMING
 #define SLS_K1_STAMP(i) do { unsigned long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
-    if (lane == 0 && p.dbg_cycles) p.dbg_cycles[(long long)blockIdx.x * 32 + (i)] += now_ - k1_t_; k1_t_ = now_; } while (0)
+    if (lane == 0 && p.dbg_cycles) p.dbg_cycles[(long long)ck.id * 32 + (i)] += now_ - k1_t_; k1_t_ = now_; } while (0)
 #define SLS_K1_STAMP_INIT unsigned long long k1_t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(k1_t_) :: "memory")
 #else
 #define SLS_K1_STAMP(i) do { } while (0)
 #define SLS_K1_STAMP_INIT do { } while (0)
+#endif
+// -DSLSLAM_K1_WALL=1 (with SLSLAM_DEBUG_ABLATE != 0): constant-clock time (s_memrealtime, 100 MHz) at which a chunk's wave starts
+// (word 30) / ends (word 31) its elimination sweep - the timeline of a launch, tools/chunk_timeline.py; no other stamp, so the sweep runs undisturbed
+#if defined(SLSLAM_K1_WALL) && SLSLAM_K1_WALL
+#define SLS_K1_WALL(slot) do { unsigned long long now_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+    if (lane == 0 && p.dbg_cycles) p.dbg_cycles[(long long)ck.id * 32 + (slot)] = now_; } while (0)
+#else
+#define SLS_K1_WALL(slot) do { } while (0)
 #endif
 template <bool INIT, int FRESH = -1>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearise_schur(BatchPtrs p, Policy pol) {
@@ -986,7 +994,7 @@ __global__ __launch_bounds__(256) void k_slab_reduce(BatchPtrs p) {
   const long long sstride = (long long)nsys + kSlabScalars;
   const int q = blockIdx.y * 256 + threadIdx.x;
   if (q >= nsys + kSlabScalars) return;
-  const double* src = p.slab + p.chunks[wd.chunk_off].slab_off + q;
+  const double* src = p.slab + wd.slab_off + q;
   const bool is_max = q == nsys + kScGradMaxLine || q == nsys + kScFail;
   double s = 0.0;
   for (int k0 = 0; k0 < wd.nchunks; k0 += 8) {
@@ -1059,7 +1067,7 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
   const bool image = presummed && p.slab_sum_image;                      // ... already in the layout of this kernel's LDS
   const int nsys_slab = mfma_slab ? kMfmaTiles * 256 + ncf * kMfmaRec : image ? N * ld + 6 * N : nsys;
   const double* slab_base = presummed ? p.slab_sum : p.slab;
-  const long long slab0 = presummed ? (long long)w * p.slab_sum_stride : (wd.nchunks > 0 ? p.chunks[wd.chunk_off].slab_off : 0);
+  const long long slab0 = presummed ? (long long)w * p.slab_sum_stride : (wd.nchunks > 0 ? wd.slab_off : 0);
   const long long sstride = (long long)nsys_slab + kSlabScalars;
   const int nchunks = presummed ? 1 : wd.nchunks;
   // (the first chunk scalars of every thread are requested ahead of the image / the zeroing, so that their round trip overlaps it)
@@ -1807,14 +1815,14 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     if (lane == 0) { red[4 * wave] = m; red[4 * wave + 1] = d; red[4 * wave + 2] = x; red[4 * wave + 3] = cs; }
     __syncthreads();
     if (tid == 0) {
-      double* bp = p.bs_part + (long long)blockIdx.x * kBsStride;
+      double* bp = p.bs_part + (long long)ck.id * kBsStride;
       bp[kBsModel] = red[0] + red[4]; bp[kBsDn2] = red[1] + red[5]; bp[kBsXn2] = red[2] + red[6];
-      p.cost_part[blockIdx.x] = red[3] + red[7];
+      p.cost_part[ck.id] = red[3] + red[7];
     }
   } else if (lane == 0) {
-    double* bp = p.bs_part + (long long)blockIdx.x * kBsStride;
+    double* bp = p.bs_part + (long long)ck.id * kBsStride;
     bp[kBsModel] = m; bp[kBsDn2] = d; bp[kBsXn2] = x;
-    p.cost_part[blockIdx.x] = cs;
+    p.cost_part[ck.id] = cs;
   }
   SLS_K1_STAMP(11);
 }
@@ -1898,7 +1906,7 @@ __global__ __launch_bounds__(64) void k_backsub_stream(BatchPtrs p, Policy pol) 
   }
   const double m = wave_sum(acc_model), d = wave_sum(acc_dn2), x = wave_sum(acc_xn2);
   if (lane == 0) {
-    double* bp = p.bs_part + (long long)blockIdx.x * kBsStride;
+    double* bp = p.bs_part + (long long)ck.id * kBsStride;
     bp[kBsModel] = m; bp[kBsDn2] = d; bp[kBsXn2] = x;
   }
 }
@@ -1967,7 +1975,7 @@ __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) 
     if (kept) acc += c;
   }
   const double s = wave_sum(acc);
-  if (lane == 0) p.cost_part[blockIdx.x] = s;
+  if (lane == 0) p.cost_part[ck.id] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1981,7 +1989,7 @@ __global__ __launch_bounds__(64) void k_lm_init(BatchPtrs p, Policy pol) {
   LMState* st = p.state + w;
   if (st->status != kRunning) return;
   const int n = wd.n, nsys = sys_doubles(n);
-  const long long slab0 = wd.nchunks > 0 ? p.chunks[wd.chunk_off].slab_off : 0;     // a window without lines has no chunk
+  const long long slab0 = wd.nchunks > 0 ? wd.slab_off : 0;     // a window without lines has no chunk
   const long long sstride = (long long)nsys + kSlabScalars;
   double cost = 0.0, fixed = 0.0, gmax = 0.0, xn2 = 0.0;
   for (int c = lane; c < wd.nchunks; c += 64) {

@@ -379,4 +379,23 @@ std::vector<int> chunk_boundaries(int ntiles, int tiles_per_chunk) {
   return b;
 }
 
+std::vector<int> chunk_boundaries_graded(int ntiles, int nchunks, const int* weights) {
+  std::vector<int> b(1, 0);
+  if (ntiles <= 0 || nchunks <= 0) return b;
+  long long total = 0;
+  for (int c = 0; c < nchunks; ++c) total += weights[c] > 0 ? weights[c] : 1;
+  if (ntiles < 2 * nchunks) return chunk_boundaries(ntiles, (ntiles + nchunks - 1) / nchunks);
+  // boundary c = round(ntiles * (w_0 + ... + w_{c-1}) / total), every chunk at least one tile
+  long long acc = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    acc += weights[c] > 0 ? weights[c] : 1;
+    int e = (int)((ntiles * acc + total / 2) / total);
+    const int lo = b.back() + 1, hi = ntiles - (nchunks - 1 - c);
+    if (e < lo) e = lo;
+    if (e > hi) e = hi;
+    b.push_back(c == nchunks - 1 ? ntiles : e);
+  }
+  return b;
+}
+
 }  // namespace slslam

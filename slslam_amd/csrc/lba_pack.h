@@ -54,6 +54,9 @@ int repack_window(const PackedWindow& P, int grouping, PackedWindow* out);
 
 // Splits ntiles into chunks of at most tiles_per_chunk tiles; returns boundaries [nchunks+1].
 std::vector<int> chunk_boundaries(int ntiles, int tiles_per_chunk);
+// `nchunks` chunks whose tile counts are in the proportions weights[0 .. nchunks) (graded sizes: a launch whose wave slots each run several chunks
+// ends with everybody's LAST chunk - the shorter that one is, the less the slots wait for the slowest); every chunk gets at least one tile
+std::vector<int> chunk_boundaries_graded(int ntiles, int nchunks, const int* weights);
 
 }  // namespace slslam
 #endif

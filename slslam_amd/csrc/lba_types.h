@@ -37,6 +37,7 @@ struct WinDesc {
   int sys_off;            // offset (doubles) of this window's y_c vector
   int nfree_params;       // 6 Cf + 4 (free lines with >= 1 kept block)
   int nkept;              // residual blocks in the reduced program
+  int slab_off;           // the window's first chunk slab (its chunks' slabs follow each other, in the order of their positions in the window)
   int map_off;            // this window's table in BatchPtrs.sys_map (entry of a chunk partial -> place in the reduced solve's LDS image)
 };
 
@@ -61,6 +62,8 @@ struct Chunk {
   int win;
   int tile_begin, tile_end;   // global tile indices
   int slab_off;               // doubles; slab = [S tri(n)] [b n] [g n] [hdiag n] [scalars]
+  int id;                     // WinDesc.chunk_off + position in the window: where the chunk's partial sums (bs_part, cost_part) go.  The ARRAY
+                              // of chunks is in dispatch order - the long chunks of every window first, see finalize - so blockIdx.x is not the id
 };
 
 // Levenberg-Marquardt state of one window (restates the locals of Ceres 1.7

@@ -19,7 +19,7 @@ b.solve(); b.download()
 its = sum(b.summary(i)["num_successful_steps"] + b.summary(i)["num_unsuccessful_steps"] for i in range(nwin))
 tiles = sum(b.counts_of(i)["tiles"] if hasattr(b, "counts_of") else 0 for i in range(nwin))
 ph = read()
-chunks = sum(b.window_chunks(i) for i in range(nwin))
+chunks = sum(abs(b.window_chunks(i)) % 1000 for i in range(nwin))
 print(json.dumps({"windows": nwin, "elim": elim, "chunks": chunks, "lm_iterations": its,
                   "s_memtime ticks per chunk sweep (100 MHz)": {nm: round(float(ph[i]) / (its / nwin * chunks), 1) for i, nm in enumerate(names)},
                   "share": {nm: round(float(ph[i] / ph[:10].sum()), 3) for i, nm in enumerate(names)}}))

@@ -18,7 +18,7 @@ for label, kw in (("W=10 house", dict(num_lines=74, num_kf=20, num_free=10, mean
     n = 5
     for _ in range(n): b.reset(); b.solve()
     b.download()
-    d = (read() - ph0) / (n * it * b.window_chunks(0))
+    d = (read() - ph0) / (n * it * (abs(b.window_chunks(0)) % 1000))
     print(json.dumps({"window": label, "chunks": b.window_chunks(0), "cycles_per_chunk_sweep": {nm: round(float(d[i])) for i, nm in enumerate(names) if nm != "-"},
                       "elimination total": round(float(d[:6].sum())), "back-substitution total": round(float(d[8:12].sum()))}))
     b.close()
