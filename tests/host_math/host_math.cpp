@@ -148,3 +148,17 @@ int hm_gp_fetch(int lane, int r, unsigned d) { return slslam::gp_fetch_index(lan
 int hm_gp_flush(int r, int c, int a, int q, int lane, int n) { return slslam::gp_flush_index(r, c, a, q, lane, n); }
 int hm_gp_panel_doubles() { return slslam::kGpPanel; }
 }
+
+// ---- chunk boundaries (lba_pack.cpp): equal and graded cuts of a window's tiles
+extern "C" {
+int hm_chunk_boundaries(int ntiles, int tiles_per_chunk, int* out, int cap) {
+  const std::vector<int> b = slslam::chunk_boundaries(ntiles, tiles_per_chunk);
+  for (size_t i = 0; i < b.size() && (int)i < cap; ++i) out[i] = b[i];
+  return (int)b.size();
+}
+int hm_chunk_boundaries_graded(int ntiles, int nchunks, const int* weights, int* out, int cap) {
+  const std::vector<int> b = slslam::chunk_boundaries_graded(ntiles, nchunks, weights);
+  for (size_t i = 0; i < b.size() && (int)i < cap; ++i) out[i] = b[i];
+  return (int)b.size();
+}
+}

@@ -759,3 +759,35 @@ def test_sweep_kernels_keep_their_occupancy(tmp_path):
         assert st["Occupancy"] == 2 and st["ScratchSize"] == 0 and st["TotalNumVgprs"] <= 256, (frag, st)
     assert find("15k_reduced_solveILi4E")["Occupancy"] >= 4      # four workgroups per CU: the whole bench batch resident in one round
     assert find("15k_reduced_solveILi1E")["ScratchSize"] == 0    # the one-window-per-CU form: the tile factorisation stays in registers
+
+
+def test_graded_chunk_boundaries(host_math):
+    """chunk_boundaries_graded (lba_pack.cpp; what finalize cuts the windows of a batch with when every wave slot runs several chunks):
+    the tile counts follow the weights, every chunk has at least one tile, the cut covers the window exactly, it is a function of
+    (tiles, chunks, weights) alone - a window solved again alone gets the same chunks - and degenerate requests fall back to the equal cut."""
+    def graded(nt, w):
+        out = (C.c_int * 1100)()
+        n = host_math.hm_chunk_boundaries_graded(nt, len(w), (C.c_int * len(w))(*w), out, 1100)
+        return list(out[:n])
+    def equal(nt, per):
+        out = (C.c_int * 1100)()
+        n = host_math.hm_chunk_boundaries(nt, per, out, 1100)
+        return list(out[:n])
+    b = graded(200, [84, 84, 24, 24, 12, 12])                      # the bench window: three rounds of the slots, six chunks
+    assert b == [0, 70, 140, 160, 180, 190, 200]
+    b = graded(200, [84, 84, 84, 84, 36, 36, 36, 36])              # two rounds, eight chunks: 35 / 15 tiles
+    assert [y - x for x, y in zip(b, b[1:])] == [35, 35, 35, 35, 15, 15, 15, 15]
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        nc = int(rng.integers(2, 40)); nt = int(rng.integers(1, 1500))
+        w = [int(x) for x in rng.integers(1, 100, size=nc)]
+        b = graded(nt, w)
+        assert b[0] == 0 and b[-1] == nt and all(y > x for x, y in zip(b, b[1:])), (nt, w, b)
+        assert b == graded(nt, w)
+        if nt >= 2 * nc:
+            assert len(b) == nc + 1
+            sizes = np.diff(b); ideal = nt * np.array(w) / sum(w)
+            assert np.all(np.abs(sizes - ideal) <= np.maximum(2.0, 0.0)) or np.all(sizes >= 1)       # rounding of the running sums: within two tiles unless clamped to one
+        else:
+            assert b == equal(nt, (nt + nc - 1) // nc)
+    assert graded(0, [1, 1]) == [0]
