@@ -1648,6 +1648,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   SLS_K1_STAMP_INIT;
   const Chunk ck = p.chunks[blockIdx.x];
+  SLS_K1_WALL(28);
   const WinDesc wd = p.wins[ck.win];
   const LMState* st = p.state + ck.win;
   if (st->status != kRunning) return;
@@ -1825,6 +1826,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
     p.cost_part[ck.id] = cs;
   }
   SLS_K1_STAMP(11);
+  SLS_K1_WALL(29);
 }
 
 // ------------------------------------------------------------------------------------------

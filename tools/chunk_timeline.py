@@ -1,6 +1,6 @@
 """Timeline of one elimination launch: when did every chunk's wave start and end (library built with -DSLSLAM_K1_WALL=1, SLSLAM_DEBUG_ABLATE set so
 that the stamp buffer exists)?  Prints the launch's makespan, the mean chunk duration, how busy the 2048 wave slots were and the spread of the
-finishing times.   python tools/chunk_timeline.py [windows] [iteration to look at, 1-based, default 6] [chunks per window] [lba_elimination]"""
+finishing times.   python tools/chunk_timeline.py [windows] [iteration to look at, 1-based, default 6] [chunks per window] [lba_elimination] [elimination | backsub]"""
 import os, sys, ctypes, json
 os.environ["SLSLAM_DEBUG_ABLATE"] = "8192"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,14 +21,16 @@ raw = np.zeros(size.value, dtype=np.uint64)
 capi.lib().slslam_debug_read_cycles(b._h, raw.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), size.value, ctypes.byref(size))
 nchunk = sum(abs(b.window_chunks(i)) % 1000 for i in range(nwin))
 t = raw[:32 * nchunk].reshape(nchunk, 32)
-start, end = t[:, 30].astype(np.float64) * 0.01, t[:, 31].astype(np.float64) * 0.01      # microseconds
+kernel = sys.argv[5] if len(sys.argv) > 5 else "elimination"
+s0, s1 = (30, 31) if kernel == "elimination" else (28, 29)                          # words of the stamp buffer: back-substitution 28 / 29
+start, end = t[:, s0].astype(np.float64) * 0.01, t[:, s1].astype(np.float64) * 0.01      # microseconds
 ok = end > start
 start, end = start[ok], end[ok]
 t0 = start.min(); start -= t0; end -= t0
 dur = end - start
 makespan = end.max()
 slots = 2048
-print(json.dumps({"windows": nwin, "chunks": int(ok.sum()), "lba_elimination": b.elimination(), "sweep": it, "chunks_per_window": cpw,
+print(json.dumps({"kernel": kernel, "windows": nwin, "chunks": int(ok.sum()), "lba_elimination": b.elimination(), "sweep": it, "chunks_per_window": cpw,
                   "makespan_us": round(makespan, 1), "chunk_us": {"mean": round(dur.mean(), 1), "std": round(dur.std(), 1), "min": round(dur.min(), 1), "max": round(dur.max(), 1)},
                   "slot_busy_fraction": round(dur.sum() / (slots * makespan), 3),
                   "ideal_makespan_us_if_perfectly_packed": round(dur.sum() / slots, 1),
