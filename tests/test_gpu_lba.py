@@ -551,6 +551,39 @@ def test_kept_jacobian_sweep_after_rejected_steps(hip, oracle):
     b.close()
 
 
+def test_graded_chunk_sizes(hip, oracle):
+    """chunks_per_window = -(1000 r + c): c chunks of graded sizes made for r rounds of the wave slots (what the automatic choice cuts the
+    windows of a chip-filling batch with, reported by slslam_lba_batch_window_chunks; long chunks first in the dispatch order).  Forced on
+    small windows: same LM decisions and results as the equal cut to round-off, parity with the oracle, bitwise reproducible, a window
+    in a batch equals the window alone with the same cut, both sweeps; malformed requests are refused."""
+    ws = [synth.make_window(60 + i, num_lines=n) for i, n in enumerate((500, 800, 650))]
+    for elim in (1, 4):
+        for cut in (-2004, -3006, -3007):
+            b = hip.LBABatch()
+            for w in ws:
+                b.add(w)
+            b.finalize(lba_elimination=elim, chunks_per_window=cut)
+            assert [b.window_chunks(i) for i in range(3)] == [cut] * 3
+            b.solve(); b.download()
+            first = [b.parameters(i).copy() for i in range(3)]
+            b.reset(); b.solve(); b.download()
+            for i, w in enumerate(ws):
+                assert np.array_equal(first[i], b.parameters(i))
+                xs, ss, ts = hip.lba_solve(w, lba_elimination=elim, chunks_per_window=cut)
+                assert np.array_equal(xs, first[i]) and ss == b.summary(i)
+                xe, se, te = hip.lba_solve(w, lba_elimination=elim, chunks_per_window=-cut % 1000)
+                for k in ("num_successful_steps", "num_unsuccessful_steps", "termination_type"):
+                    assert ss[k] == se[k]
+                assert abs(ss["final_cost"] - se["final_cost"]) <= 1e-9 * se["final_cost"] and np.abs(xs - xe).max() < 1e-7
+            b.close()
+    x0, s0, t0 = oracle.lba_solve(ws[0], linear_solver=1)
+    x1, s1, t1 = hip.lba_solve(ws[0], chunks_per_window=-3006)
+    _assert_trace_parity(t0, t1, n=3); _assert_summary_parity(s0, s1)
+    for bad in (-6, -1003, -2001):
+        with pytest.raises(hip.SlslamError):
+            hip.lba_solve(ws[0], chunks_per_window=bad)
+
+
 def test_non_finite_input_is_refused_at_the_boundary(hip):
     """ADVICE round 3 (lane_F / line_block rely on K = 0 for constant lines: 0 x inf would be NaN): non-finite observations or
     parameters never reach a kernel - slslam_pack_window / slslam_lba_solve / slslam_lba_batch_add return
