@@ -1007,7 +1007,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
       else LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_linearise_schur<false, 0>), g_chunk, blk64, b->lds_lin, s, p, pol));
     }
     if (b->slab_sum_stride)
-      LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)B, (unsigned)((b->slab_sum_stride + 255) / 256)), blk256, 0, s, p));   // windows on grid.x (no 65535 limit)
+      LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)B, (unsigned)((b->slab_sum_stride * kSlabReduceSub + 255) / 256)), blk256, 0, s, p));   // windows on grid.x (no 65535 limit)
     if (B <= b->num_cus) LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve<1>, g_win, blk256, b->lds_solve, s, p, pol));
     else LAUNCH(FAM_SOLVE, hipLaunchKernelGGL(k_reduced_solve<4>, g_win, blk256, b->lds_solve, s, p, pol));
     if (b->nchunk > 0) {

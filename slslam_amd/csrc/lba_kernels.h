@@ -984,6 +984,10 @@ __device__ __forceinline__ unsigned long long solve_clock() {
 // load bandwidth of its CU, ~10 B per cycle: 0.8 MB = 30 us on the latency path of every iteration).  One thread per entry,
 // partials added in chunk order (the sum k_reduced_solve would form); per-chunk scalars: cost / fixed cost / |x|^2 summed,
 // gradient norm and failure flag maxed.  Result: one slab per window in slab_sum, same layout.
+// kSlabReduceSub lanes share an entry: lane j adds the partials of the chunks j, j + kSlabReduceSub, ... in increasing order, then the
+// lanes' sums are added in lane order - a fixed association, so the result is reproducible (and the same whatever batch the window is
+// in); one thread walking 200 partials was 18 us of dependent round trips on the latency path of a 2000-line window.
+enum { kSlabReduceSub = 16 };
 __global__ __launch_bounds__(256) void k_slab_reduce(BatchPtrs p) {
   const int w = blockIdx.x;
   const WinDesc wd = p.wins[w];
@@ -992,18 +996,26 @@ __global__ __launch_bounds__(256) void k_slab_reduce(BatchPtrs p) {
   if (p.state[w].status != kRunning || wd.nchunks <= 8) return;
   const int nsys = p.elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n);
   const long long sstride = (long long)nsys + kSlabScalars;
-  const int q = blockIdx.y * 256 + threadIdx.x;
-  if (q >= nsys + kSlabScalars) return;
-  const double* src = p.slab + wd.slab_off + q;
+  const int t = blockIdx.y * 256 + threadIdx.x;
+  const int q = t / kSlabReduceSub, j = t - q * kSlabReduceSub;
+  const bool live = q < nsys + kSlabScalars;                  // (whole groups of lanes: the shuffles below want their partners)
+  const double* src = p.slab + wd.slab_off + (live ? q : 0);
   const bool is_max = q == nsys + kScGradMaxLine || q == nsys + kScFail;
   double s = 0.0;
-  for (int k0 = 0; k0 < wd.nchunks; k0 += 8) {
+  for (int k0 = j; k0 < wd.nchunks; k0 += 8 * kSlabReduceSub) {
     double v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (k0 + u < wd.nchunks) ? src[(k0 + u) * sstride] : 0.0;
+    for (int u = 0; u < 8; ++u) v[u] = (k0 + u * kSlabReduceSub < wd.nchunks) ? src[(long long)(k0 + u * kSlabReduceSub) * sstride] : 0.0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) s = is_max ? fmax(s, v[u]) : s + v[u];
   }
+  // the group's sums, in lane order
+  const int base = (threadIdx.x & 63) & ~(kSlabReduceSub - 1);
+  double tot = __shfl(s, base);
+#pragma unroll
+  for (int i = 1; i < kSlabReduceSub; ++i) { const double o = __shfl(s, base + i); tot = is_max ? fmax(tot, o) : tot + o; }
+  if (!live || j != 0) return;
+  s = tot;
   if (p.slab_sum_image) {
     // straight into the layout the reduced solve keeps in LDS: its first phase was a chain of dependent global reads (partials,
     // then the map, then the scalars: ~2 us each for a window alone on the chip) and is now one sweep of independent loads
