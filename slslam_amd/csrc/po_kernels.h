@@ -272,10 +272,24 @@ __global__ __launch_bounds__(256) void k_po_prepare(PoPtrs p, Policy pol, int fi
   if (first) {
     // initial evaluation (Ceres: cost, gradient, column norms at x0).  The host re-linearises with
     // the scale computed here, so nothing is damped or solved in this call.
-    if (tid == 0) {
-      double xn2 = 0.0;
+    // |x|^2 over the free poses: the workgroup's threads share the poses (one thread walking all of them was 56 us of dependent
+    // loads, once per solve), partial sums added in a fixed tree
+    {
       const double* X = p.x + (long long)st->cur * 6 * p.N;
-      for (int k = 0; k < p.N; ++k) if (p.slot[k] >= 0) for (int i = 0; i < 6; ++i) xn2 += X[6 * k + i] * X[6 * k + i];
+      double part = 0.0;
+      for (int k = tid; k < p.N; k += 256) {
+        const int sl = p.slot[k];
+        double v[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = X[6 * k + i];
+        if (sl >= 0) for (int i = 0; i < 6; ++i) part += v[i] * v[i];
+      }
+      red[tid] = part;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    }
+    if (tid == 0) {
+      const double xn2 = red[0];
       st->cost = p.scal[kPoCost]; st->fixed_cost = p.scal[kPoFixed];
       st->initial_cost = st->cost + st->fixed_cost; st->min_cost = st->initial_cost;
       st->x_norm = sqrt(xn2); st->grad_max = gm;
