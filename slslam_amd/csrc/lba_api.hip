@@ -417,13 +417,16 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     b->elim_waves = b->elim_mode == 0 ? 1 : (want == 3 ? 2 : 1);
     b->elim_grouped = b->elim_mode == 1 && (want == 4 || auto_grouped);
     b->pol.keep_jacobian = (b->elim_grouped && b->opt.lba_keep_jacobian && b->opt.max_num_iterations > 1) ? 1 : 0;
-    if (b->elim_grouped) {
+    {
       // the grouped sweep wants the lines of a window in the order of their first free camera: pack again (the default packing
-      // deals rows to the tiles by pair-item count, which this sweep has no use for)
+      // deals rows to the tiles by pair-item count, which this sweep has no use for).  Both directions: a batch whose finalize failed
+      // after this point keeps its windows as they are now, and a second attempt with another sweep must not read line descriptors in
+      // the other layout
+      const int want_grouping = b->elim_grouped ? 1 : 0;
       for (PackedWindow& P : b->wins) {
-        if (P.grouping == 1) continue;
+        if (P.grouping == want_grouping || P.big) continue;
         PackedWindow Q;
-        const int rc = repack_window(P, 1, &Q);
+        const int rc = repack_window(P, want_grouping, &Q);
         if (rc != SLSLAM_OK) return rc;
         P = std::move(Q);
       }

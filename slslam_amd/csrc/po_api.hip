@@ -9,6 +9,7 @@
 #include <cstring>
 #include <utility>
 #include <type_traits>
+#include <mutex>
 #include <vector>
 
 #include "../../include/slslam_hip.h"
@@ -158,7 +159,8 @@ void po_factor_dense(PoPtrs& pp, T* A, T* Lf, T* linv, int nb) {
       }
     }
     // (in place: the caller's substitution reads Lf)
-    (void)hipMemcpyAsync(Lf, A, sizeof(T) * (size_t)pp.n * pp.ld, hipMemcpyDeviceToDevice, 0);
+    // (row by row: A and Lf may be the junction block of a larger matrix - pitch ld, width n - and n * ld elements would run past both)
+    (void)hipMemcpy2DAsync(Lf, sizeof(T) * (size_t)pp.ld, A, sizeof(T) * (size_t)pp.ld, sizeof(T) * (size_t)pp.n, (size_t)pp.n, hipMemcpyDeviceToDevice, 0);
     return;
   }
   hipLaunchKernelGGL(k_po_potrf_diag<T>, dim3(1), dim3(256), 0, 0, pp, A, linv, 0, Lf);
@@ -168,12 +170,19 @@ void po_factor_dense(PoPtrs& pp, T* A, T* Lf, T* linv, int nb) {
   }
 }
 // (k_po_step keeps three 64 x 66 tiles in dynamic LDS: 101 KB of doubles - above the 64 KB a kernel gets without asking)
+// HIP function attributes are per DEVICE and slslam_po_solve runs on whatever device is current: the limit is raised once per device
+// (a bit per device id under a mutex; a process that solves on device 0 and then on device 1 raises it on both).
 hipError_t po_step_lds_attributes() {
-  static bool done = false;
-  if (done) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute((const void*)k_po_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPoStepLdsTiles * kNB * kLdT * sizeof(double)));
+  static std::mutex mu;
+  static unsigned long long done_mask = 0;          // devices 0..63; beyond that the attribute is set on every call (it is cheap)
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev >= 0 && dev < 64 && ((done_mask >> dev) & 1ull)) return hipSuccess;
+  e = hipFuncSetAttribute((const void*)k_po_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPoStepLdsTiles * kNB * kLdT * sizeof(double)));
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_po_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPoStepLdsTiles * kNB * kLdT * sizeof(float)));
-  done = e == hipSuccess;
+  if (e == hipSuccess && dev >= 0 && dev < 64) done_mask |= 1ull << dev;
   return e;
 }
 }  // namespace
@@ -248,6 +257,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   unsigned* d_tri_flags = nullptr;    // k_po_trisolve_wide: one progress word per 64-row block
   unsigned tri_epoch = 1;
   int num_cus = 0;
+  int wide_resident = 0;             // workgroups of k_po_trisolve_wide the device keeps resident together (0: not known - the one-workgroup substitution runs)
   LMState hst;
   std::vector<IterRec> htrace(kMaxTrace);
   std::vector<double> x2((size_t)12 * N), ones((size_t)(n > 0 ? n : 1), 1.0);
@@ -296,6 +306,15 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   PO_TRY(hipMemset(p.flags, 0, sizeof(int) * 2));
   PO_TRY(hipMemset(d_tri_flags, 0, sizeof(unsigned) * (size_t)(nblk + 1)));
   (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, arena_device);
+  // k_po_trisolve_wide spin-waits across workgroups: all of its nblk workgroups have to be resident together.  Ask the runtime how
+  // many fit (a CU mask or a compute partition shows up here); when it cannot tell, the one-workgroup substitution runs instead.
+  {
+    int per_cu = 0;
+    const hipError_t eo = f32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_po_trisolve_wide<float>, 256, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_po_trisolve_wide<double>, 256, 0);
+    if (eo == hipSuccess && per_cu > 0 && num_cus > 0) wide_resident = per_cu >= 1 ? num_cus : 0;   // (one workgroup per CU is all that is counted on)
+    else (void)hipGetLastError();
+  }
   p.p1 = d_p1; p.p2 = d_p2; p.cons = d_cons; p.slot = d_slot;
   p.N = N; p.E = E; p.n = n; p.ld = ld;
   pj = p;                                  // the junction block as a matrix of its own (same leading dimension)
@@ -347,7 +366,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
       else po_factor_dense<double>(p, p.H, d_Lf, d_linv, nblk);
     }
     if (structured) { /* solved above */ }
-    else if (nblk >= 4 && nblk <= num_cus && !std::getenv("SLSLAM_PO_LAUNCH_CHAIN")) {
+    else if (nblk >= 4 && nblk <= wide_resident && !std::getenv("SLSLAM_PO_LAUNCH_CHAIN")) {
       // one workgroup per 64-row block, all resident: the substitutions spread over the chip (k_po_trisolve_wide)
       if (f32) hipLaunchKernelGGL(k_po_trisolve_wide<float>, dim3((unsigned)nblk), dim3(256), 0, 0, p, (const float*)d_Lff, (const float*)d_linvf, d_tri_flags, tri_epoch);
       else hipLaunchKernelGGL(k_po_trisolve_wide<double>, dim3((unsigned)nblk), dim3(256), 0, 0, p, (const double*)d_Lf, (const double*)d_linv, d_tri_flags, tri_epoch);
