@@ -288,6 +288,69 @@ def time_batch(windows, device, steps, warmup, **opt):
     return its / dt, 1e3 * dt / steps
 
 
+def streamed_block(windows, device, resident_value, resident_params, batches_timed=8, depth=3, host_threads=0, **opt):
+    """BASELINE config 4 taken literally - a STREAM of windows: every window arrives as the five host arrays the reference builds per
+    window (src/slam.cpp:899-921) and its solved parameters go back into the caller's array (:957-972).  Inside the timed region, per
+    batch of len(windows) windows: packing on the host threads (the LBAProblem::build stage) straight into the pinned host image,
+    asynchronous upload, the same captured solve the resident headline replays, download, copy-out - `depth` batches in flight
+    (slslam_lba_stream_*).  Every batch is a fresh set of host arrays over the rank's windows, rotated so that every batch is laid out
+    differently; the first depth + 1 submits (batch builds, graph capture, pinned allocations) are warm-up.  Never the headline `value`:
+    it measures the host, PCIe and the GPU together."""
+    B = len(windows)
+    nsets = depth + 1 + batches_timed
+    sets = []
+    for k in range(nsets):
+        r = (k * 37) % B
+        sets.append(capi.WindowSet(windows[r:] + windows[:r]))
+    st = capi.LBAStream(device=device, depth=depth, host_threads=host_threads, **opt)
+    tick = []
+    for k in range(depth + 1):                      # warm-up: builds the slots' batches, then one refill
+        if k >= depth:
+            st.collect(tick[k - depth], want_summaries=False)
+        tick.append(st.submit(sets[k]))
+    for k in range(1, depth + 1):
+        st.collect(tick[k], want_summaries=False)
+    s0 = st.stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tick = []
+    for k in range(batches_timed):
+        if k >= depth:
+            st.collect(tick[k - depth], want_summaries=False)
+        tick.append(st.submit(sets[depth + 1 + k]))
+    for k in range(max(0, batches_timed - depth), batches_timed):
+        st.collect(tick[k], want_summaries=False)
+    dt = time.perf_counter() - t0
+    s1 = st.stats()
+    its = s1["lm_iterations"] - s0["lm_iterations"]
+    nwin = s1["windows"] - s0["windows"]
+    # the streamed results are the resident batch's results, byte for byte (same windows, same sweep, same cut)
+    equal, checked = True, 0
+    k = depth + 1 + batches_timed - 1
+    r = (k * 37) % B
+    for j in (0, 1, B // 2, B - 1):
+        i = (j + r) % B                              # window i of the rank sits at position j of set k
+        if i in resident_params:
+            checked += 1
+            equal = equal and bool(np.array_equal(sets[k].parameters(j), resident_params[i]))
+    m = sum(len(w["camera_index"]) for w in windows)
+    h2d = 8 * 8 * m + 4 * 2 * m + sum(8 * (6 * w["num_cameras"] + 4 * w["num_lines"]) + 40 * w["num_lines"] for w in windows)
+    out = {"value": its / dt, "unit": "LM iterations/s", "ms_per_batch": 1e3 * dt / batches_timed, "windows_per_batch": B,
+           "batches_timed": batches_timed, "depth": depth, "host_threads": s1["host_threads"],
+           "fraction_of_resident": (its / dt) / resident_value if resident_value else None,
+           "refills": s1["refills"] - s0["refills"], "rebuilds": s1["builds"] - s0["builds"],
+           "host_ms_per_window_wall": (s1["ms_submit"] - s0["ms_submit"]) / max(nwin, 1),
+           "host_thread_ms_per_window_upper_bound": (s1["ms_submit"] - s0["ms_submit"]) * s1["host_threads"] / max(nwin, 1),
+           "ms_per_batch_in_submit": (s1["ms_submit"] - s0["ms_submit"]) / batches_timed,
+           "ms_per_batch_waiting_in_collect": (s1["ms_collect_wait"] - s0["ms_collect_wait"]) / batches_timed,
+           "ms_per_batch_copying_results_out": (s1["ms_collect_copy"] - s0["ms_collect_copy"]) / batches_timed,
+           "approx_h2d_MB_per_batch": h2d / 1e6, "lm_iterations": its,
+           "bitwise_equal_to_resident_batch": equal if checked else None, "windows_compared": checked,
+           "timed_region": "per batch: pack (host threads) + pinned H2D + hipGraph solve + D2H + copy-out into the callers' arrays, %d batches in flight" % depth}
+    st.close()
+    return out
+
+
 def single_window_latency(lines, device, **shape):
     """The reference's call protocol (slam.cpp:924-944: one window per keyframe, each built from the result of the one
     before): ms per 10-iteration solve of ONE window resident in HBM (hipGraph replay) and through slslam_lba_solve
@@ -369,6 +432,9 @@ def main():
                     help="also all-gather the solved parameters of every rank inside the timed region (one RCCL all-gather per step)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the 500-line, latency and pose-graph blocks")
     ap.add_argument("--no-result-check", action="store_true", help="skip the cross-rank bitwise check of the results (outside the timed region)")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the streamed leg (config 4 as a stream of host-side windows)")
+    ap.add_argument("--stream-batches", type=int, default=8, help="timed batches of the streamed leg")
+    ap.add_argument("--host-threads", type=int, default=0, help="host threads of the streamed leg (0 = up to 16)")
     ap.add_argument("--streams", type=int, default=1,
                     help="the rank's windows are split into this many batches on separate HIP streams, so that the "
                          "latency-bound kernels of one batch (reduced solve, LM update) overlap the sweeps of the other")
@@ -654,6 +720,14 @@ def main():
             err = np.concatenate(err)
             out["traj_error_vs_oracle"] = {"rms_m": float(np.sqrt((err ** 2).mean())), "mean_m": float(err.mean()),
                                            "keyframes": int(err.size)}
+        if world == 1 and not args.no_streamed and ns == 1:
+            resident_params = {i: batches[where[i][0]].parameters(where[i][1]) for i in range(B)} if B <= 4096 else {}
+            try:
+                out["streamed"] = streamed_block(windows, local_rank, out["value"], resident_params, batches_timed=args.stream_batches,
+                                                 host_threads=args.host_threads, chunks_per_window=args.chunks, lba_elimination=args.elim,
+                                                 lba_keep_jacobian=args.keep_jacobian)
+            except capi.SlslamError as e:
+                out["streamed"] = {"error": str(e)}
         if world == 1 and not args.no_extra_configs:
             for bt in batches:           # release HBM before the extra measurements
                 bt.close()

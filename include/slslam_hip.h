@@ -101,6 +101,27 @@ typedef struct slslam_solver_options {
                                            a successful step.  Grouped sweep (lba_elimination 4) only; same results to round-off.
                                            Measured SLOWER on MI355X (the stores cost the linearising sweeps more than the replays
                                            save): kept as a tested alternative                              */
+  int    refill_headroom_percent;       /* 0 (default): the batch holds exactly its windows.  > 0: a batch for a STREAM of windows - its device
+                                           arrays get that much room beyond what the first windows need, a pinned host image of them is
+                                           kept, results come back through pinned buffers - so that slslam_lba_batch_refill can replace
+                                           all its windows without allocating, re-capturing the solve graph or synchronising          */
+  int    host_threads;                  /* host threads for the per-window host work of a batch (packing = the LBAProblem::build stage,
+                                           layout, result copies): 0 = automatic (up to 8 for batches of 64 windows or more), 1 = the
+                                           calling thread only                                                                         */
+  int    reproducible;                  /* 0 (default): the elimination sweep (lba_elimination = 0) and the cut of a window into chunks
+                                           (chunks_per_window = 0) are chosen for the BATCH - fastest, but a window's result bytes then
+                                           depend on its company (the sums run in another order).  1: both become functions of the window
+                                           alone - lba_elimination = 0 means 1, a requested matrix-core sweep the batch cannot take is
+                                           SLSLAM_ERR_UNSUPPORTED instead of a fallback, chunks of at most 34 tiles graded for three
+                                           rounds of the wave slots (what the automatic choice gives a batch that fills the chip) - so
+                                           that 1 / 2 / 4 / 8-rank runs and one-window batches return identical bytes with no caller
+                                           bookkeeping                                                                                  */
+  int    lba_precision;                 /* 0 (default): fp64 throughout, the reference's arithmetic.  1: MIXED - the per-observation
+                                           geometry, residuals and Jacobians of the elimination sweep in fp32, every accumulation (line
+                                           blocks, reduced camera system, gradients), the cost, the candidate evaluation and all
+                                           trust-region bookkeeping in fp64; observations whose line is badly conditioned in fp32
+                                           (|sin t| or the image-line normal's length small: reference src/lba_problem.h:63, :90) fall
+                                           back to fp64.  Opt-in; results within the tolerance stated in DESIGN.md of the fp64 path   */
 } slslam_solver_options;
 
 /* Fills every field with the configuration the reference runs (robust loss on, 10 iterations). */
@@ -167,7 +188,7 @@ void slslam_lba_batch_destroy(slslam_lba_batch* b);
 /* Replaces LBAProblem::build for one more window: validates, copies and reorders the arrays on
  * the host (observations grouped by line).  Returns the window's index in *index. */
 int  slslam_lba_batch_add(slslam_lba_batch* b, const slslam_lba_window* window, int* index);
-/* Uploads every added window to HBM; no windows can be added afterwards. */
+/* Uploads every added window to HBM; no windows can be added afterwards (all of them can be REPLACED: slslam_lba_batch_refill). */
 int  slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solver_options* opt);
 /* Replaces ceres::Solve for all windows: enqueues the complete LM solve on `stream`
  * (a hipStream_t passed as void*, NULL = default stream) and returns without synchronising. */
@@ -180,6 +201,20 @@ int  slslam_lba_batch_reset(slslam_lba_batch* b, void* stream);
 int  slslam_lba_batch_iterations(slslam_lba_batch* b, void* stream, long long* iterations, int clear);
 /* Blocks until the stream's work is done and copies parameters + summaries back to the host. */
 int  slslam_lba_batch_download(slslam_lba_batch* b, void* stream);
+/* The two halves of download: _async enqueues the export and the device-to-host copies on `stream` and returns; _wait blocks until
+ * they have arrived (results of a refillable batch land in pinned memory, so the copies overlap whatever else the host does). */
+int  slslam_lba_batch_download_async(slslam_lba_batch* b, void* stream);
+int  slslam_lba_batch_wait(slslam_lba_batch* b);
+/* Replaces LBAProblem::build for ALL windows of a finalized batch at once - the next `n` windows of a stream take the place of the
+ * present ones (reference: the five arrays a caller hands over per window, src/slam.cpp:899-921; n must equal the batch's window
+ * count).  The batch must have been finalized with refill_headroom_percent > 0.  Packs the windows on options.host_threads host
+ * threads straight into the batch's pinned host image, uploads the arrays with asynchronous copies on `stream`, rebuilds the tile
+ * contexts and the initial parameter buffers on the device and resets the LM state - no allocation, no synchronisation, the captured
+ * solve graph stays valid.  The windows are cut into chunks by the policy finalize resolved, so a refilled batch returns the bytes a
+ * fresh batch of the same windows returns.  SLSLAM_ERR_UNSUPPORTED (batch unchanged, still solvable): the windows do not fit the
+ * room the arrays have, or need another path / sweep - build a new batch then.
+ * Host arrays are read before the call returns; `stream` must be the stream the batch is solved on. */
+int  slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_window* windows, int n, void* stream);
 /* After download: solved parameters of window `index` in the caller's original layout. */
 int  slslam_lba_batch_get_parameters(const slslam_lba_batch* b, int index, double* parameters);
 int  slslam_lba_batch_get_summary(const slslam_lba_batch* b, int index, slslam_summary* summary);
@@ -223,6 +258,24 @@ int  slslam_lba_batch_kernel_times(const slslam_lba_batch* b, double ms[8], int 
  * residuals[4M], j_cam[24M] (row-major 4x6), j_line[16M] (row-major 4x4), cost[1]. */
 int  slslam_lba_batch_linearise(slslam_lba_batch* b, int index, double* residuals, double* j_cam,
                                 double* j_line, double* cost);
+
+/* ---- a STREAM of windows (BASELINE config 4: many independent windows arriving in host memory): `depth` refillable batches in
+ * flight on HIP streams of their own, so that packing (host threads), upload (copy engine), solve and download of consecutive
+ * batches overlap.  submit() = LBAProblem::build + ceres::Solve for `n` windows, asynchronous: it returns when the windows' arrays
+ * have been read (only `parameters` of each window must stay valid - it is written by collect); collect() waits for that submit's
+ * results and writes every window's solved parameters in place (the in/out contract of reference src/slam.cpp:957-972) and, when
+ * `summaries` is not NULL, summaries[0 .. n).  Tickets must be collected before their slot comes round again (every `depth` submits:
+ * SLSLAM_ERR_STATE otherwise).  options: as for a batch; host_threads (0 = up to 16) pack and copy; refill_headroom_percent 0 = 10. */
+typedef struct slslam_lba_stream slslam_lba_stream;
+int  slslam_lba_stream_create(int device, const slslam_solver_options* opt, int depth, slslam_lba_stream** out);
+void slslam_lba_stream_destroy(slslam_lba_stream* s);
+int  slslam_lba_stream_submit(slslam_lba_stream* s, const slslam_lba_window* windows, int n, int* ticket);
+int  slslam_lba_stream_collect(slslam_lba_stream* s, int ticket, slslam_summary* summaries);
+/* Host-side accounting since create: wall-clock ms the caller spent in submit (pack + layout + enqueue), waiting in collect, copying
+ * results out; submits served by a refill / by building a batch; windows submitted; trust-region steps (successful + unsuccessful, the
+ * count of reference src/slam.cpp:949-950) of the windows collected; host threads in use.  Any pointer may be NULL. */
+int  slslam_lba_stream_stats(const slslam_lba_stream* s, double* ms_submit, double* ms_collect_wait, double* ms_collect_copy,
+                             long long* refills, long long* builds, long long* windows, long long* lm_iterations, int* host_threads);
 
 /* ------------------------------------------------------------------ pose graph
  * Replaces: POProblem(size, n_iter) + set_pose_index_1/2 + set_constraints + set_parameters

@@ -36,7 +36,8 @@ class SolverOptions(C.Structure):
                 ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
                 ("jacobi_scaling", C.c_int), ("use_graph", C.c_int), ("chunks_per_window", C.c_int),
                 ("reuse_elimination", C.c_int), ("po_factor_fp32", C.c_int), ("po_dense_factor", C.c_int), ("lba_fused_motion_only", C.c_int),
-                ("lba_elimination", C.c_int), ("lba_keep_jacobian", C.c_int)]
+                ("lba_elimination", C.c_int), ("lba_keep_jacobian", C.c_int), ("refill_headroom_percent", C.c_int),
+                ("host_threads", C.c_int), ("reproducible", C.c_int), ("lba_precision", C.c_int)]
 
 
 class Summary(C.Structure):
@@ -80,7 +81,9 @@ class POGraph(C.Structure):
 EXPORTS = [
     "slslam_default_options", "slslam_lba_solve", "slslam_lba_batch_create", "slslam_lba_batch_destroy",
     "slslam_lba_batch_add", "slslam_lba_batch_finalize", "slslam_lba_batch_solve", "slslam_lba_batch_reset",
-    "slslam_lba_batch_download", "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
+    "slslam_lba_batch_download", "slslam_lba_batch_download_async", "slslam_lba_batch_wait", "slslam_lba_batch_refill",
+    "slslam_lba_stream_create", "slslam_lba_stream_destroy", "slslam_lba_stream_submit", "slslam_lba_stream_collect", "slslam_lba_stream_stats",
+    "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts", "slslam_lba_batch_window_chunks", "slslam_lba_batch_path", "slslam_lba_batch_elimination",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
     "slslam_po_solve", "slslam_po_structure", "slslam_po_set_profiling", "slslam_po_last_timing", "slslam_debug_phase_cycles", "slslam_debug_read_cycles", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_release_cached_memory", "slslam_version", "slslam_status_string",
@@ -110,6 +113,15 @@ def lib():
     L.slslam_lba_batch_solve.argtypes = [vp, vp]
     L.slslam_lba_batch_reset.argtypes = [vp, vp]
     L.slslam_lba_batch_download.argtypes = [vp, vp]
+    L.slslam_lba_batch_download_async.argtypes = [vp, vp]
+    L.slslam_lba_batch_wait.argtypes = [vp]
+    L.slslam_lba_batch_refill.argtypes = [vp, C.POINTER(LBAWindow), C.c_int, vp]
+    L.slslam_lba_stream_create.argtypes = [C.c_int, C.POINTER(SolverOptions), C.c_int, C.POINTER(vp)]
+    L.slslam_lba_stream_destroy.argtypes = [vp]
+    L.slslam_lba_stream_destroy.restype = None
+    L.slslam_lba_stream_submit.argtypes = [vp, C.POINTER(LBAWindow), C.c_int, ip]
+    L.slslam_lba_stream_collect.argtypes = [vp, C.c_int, C.POINTER(Summary)]
+    L.slslam_lba_stream_stats.argtypes = [vp, dp, dp, dp] + [C.POINTER(C.c_longlong)] * 4 + [ip]
     L.slslam_lba_batch_get_parameters.argtypes = [vp, C.c_int, dp]
     L.slslam_lba_batch_get_summary.argtypes = [vp, C.c_int, C.POINTER(Summary)]
     L.slslam_lba_batch_get_trace.argtypes = [vp, C.c_int, C.POINTER(Iteration), C.c_int, ip]
@@ -258,6 +270,18 @@ class LBABatch:
     def download(self, stream=None):
         _check(lib().slslam_lba_batch_download(self._h, C.c_void_p(stream or 0)), "slslam_lba_batch_download")
 
+    def download_async(self, stream=None):
+        _check(lib().slslam_lba_batch_download_async(self._h, C.c_void_p(stream or 0)), "slslam_lba_batch_download_async")
+
+    def wait(self):
+        _check(lib().slslam_lba_batch_wait(self._h), "slslam_lba_batch_wait")
+
+    def refill(self, windows, stream=None):
+        """Replaces every window of the finalized batch (slslam_lba_batch_refill); `windows`: a WindowSet or a list of window dicts."""
+        ws = windows if isinstance(windows, WindowSet) else WindowSet(windows)
+        _check(lib().slslam_lba_batch_refill(self._h, ws.c, len(ws), C.c_void_p(stream or 0)), "slslam_lba_batch_refill")
+        self.sizes = list(ws.sizes)
+
     def export_device(self, device_ptr, stream=None):
         _check(lib().slslam_lba_batch_export_device(self._h, C.c_void_p(device_ptr), C.c_void_p(stream or 0)),
                "slslam_lba_batch_export_device")
@@ -323,6 +347,64 @@ class LBABatch:
         r, jc, jl, c = np.zeros((m, 4)), np.zeros((m, 4, 6)), np.zeros((m, 4, 4)), np.zeros(1)
         _check(lib().slslam_lba_batch_linearise(self._h, i, _dp(r), _dp(jc), _dp(jl), _dp(c)), "slslam_lba_batch_linearise")
         return float(c[0]), r, jc, jl
+
+
+class WindowSet:
+    """A C array of slslam_lba_window over numpy buffers that stay alive with it (what a caller of the stream / refill entry points
+    holds: the five arrays of every window, reference src/slam.cpp:899-921)."""
+
+    def __init__(self, windows):
+        self.arrays = [_WindowArrays(w) for w in windows]
+        self.c = (LBAWindow * max(len(self.arrays), 1))(*[a.c for a in self.arrays])
+        self.sizes = [(int(w["num_cameras"]), int(w["num_lines"])) for w in windows]
+
+    def __len__(self):
+        return len(self.arrays)
+
+    def parameters(self, i):
+        return self.arrays[i].params
+
+
+class LBAStream:
+    """slslam_lba_stream_*: `depth` refillable batches in flight; submit(WindowSet) -> ticket, collect(ticket) -> summaries, the solved
+    parameters land in the WindowSet's parameter arrays."""
+
+    def __init__(self, device=-1, depth=3, **opt):
+        self._h = C.c_void_p()
+        o = default_options(**opt)
+        _check(lib().slslam_lba_stream_create(int(device), C.byref(o), int(depth), C.byref(self._h)), "slslam_lba_stream_create")
+        self._live = {}
+
+    def close(self):
+        if self._h:
+            lib().slslam_lba_stream_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, ws):
+        t = C.c_int(-1)
+        _check(lib().slslam_lba_stream_submit(self._h, ws.c, len(ws), C.byref(t)), "slslam_lba_stream_submit")
+        self._live[t.value] = ws
+        return t.value
+
+    def collect(self, ticket, want_summaries=True):
+        ws = self._live.pop(ticket)
+        sm = (Summary * max(len(ws), 1))() if want_summaries else None
+        _check(lib().slslam_lba_stream_collect(self._h, int(ticket), sm), "slslam_lba_stream_collect")
+        return [_summary_dict(sm[i]) for i in range(len(ws))] if want_summaries else None
+
+    def stats(self):
+        d = [C.c_double(0) for _ in range(3)]
+        q = [C.c_longlong(0) for _ in range(4)]
+        t = C.c_int(0)
+        _check(lib().slslam_lba_stream_stats(self._h, *[C.byref(x) for x in d], *[C.byref(x) for x in q], C.byref(t)), "slslam_lba_stream_stats")
+        return {"ms_submit": d[0].value, "ms_collect_wait": d[1].value, "ms_collect_copy": d[2].value,
+                "refills": q[0].value, "builds": q[1].value, "windows": q[2].value, "lm_iterations": q[3].value, "host_threads": t.value}
 
 
 def po_solve(g, params=None, trace_cap=64, **opt):

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +22,10 @@
 #include "device_cache.h"
 #include "lba_motion_only.h"
 #include "lba_pack.h"
+#include "host_pool.h"
+
+#include <memory>
+#include <thread>
 
 using namespace slslam;
 
@@ -57,6 +62,10 @@ extern "C" void slslam_default_options(slslam_solver_options* o) {
   o->lba_fused_motion_only = 1;
   o->lba_elimination = 0;
   o->lba_keep_jacobian = 0;
+  o->refill_headroom_percent = 0;
+  o->host_threads = 0;
+  o->reproducible = 0;
+  o->lba_precision = 0;
 }
 
 extern "C" void slslam_release_cached_memory(void) { DeviceBlockCache::drop(); }
@@ -97,26 +106,63 @@ struct DevBuf {
   void release() { if (p && !in_arena) (void)hipFree(p); p = nullptr; n = 0; in_arena = false; }
 };
 
+// Results on the host: pageable, or pinned for a batch that is refilled (its downloads are asynchronous copies).
+template <typename T>
+struct HostArr {
+  T* p = nullptr;
+  size_t n = 0;
+  bool pinned = false;
+  std::vector<T> v;
+  int alloc(size_t count, bool pin) {
+    release();
+    n = count; pinned = pin && count > 0;
+    if (pinned) { HIP_TRY(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault)); std::memset((void*)p, 0, count * sizeof(T)); }
+    else { v.assign(count, T()); p = v.data(); }
+    return SLSLAM_OK;
+  }
+  void release() { if (pinned && p) (void)hipHostFree(p); p = nullptr; n = 0; pinned = false; std::vector<T>().swap(v); }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+};
+
 // All device arrays of a batch in ONE allocation, everything the host fills in ONE host-to-device copy: the build of
 // a single window (slslam_lba_solve, the per-keyframe call of the reference) is dominated by per-call driver overheads
 // otherwise (~35 hipMalloc + ~20 synchronous hipMemcpy).
+// The uploaded arrays have a host IMAGE with the same offsets (`stage`): the batch build writes every window's slices straight into
+// it (fill_window, one window per host thread) and the image goes up in one copy.  A batch that is to be refilled
+// (slslam_solver_options.refill_headroom_percent > 0) keeps the image, in pinned memory: slslam_lba_batch_refill packs the next set of
+// windows into it and uploads the arrays with asynchronous copies on the caller's stream.
 struct DeviceArena {
-  struct Item { void** pp; size_t bytes; const void* host; int group; size_t off; };   // group 0 uploaded, 1 scratch, 2 zeroed
+  struct Item { void** pp; size_t bytes; const void* host; size_t host_bytes; int group; size_t off; };   // group 0 uploaded, 1 scratch, 2 zeroed
   std::vector<Item> items;
   char* base = nullptr;
   size_t bytes = 0;
   int device = 0;
   bool cached = false;              // one-shot solves: the block comes from / returns to the thread's DeviceBlockCache
+  char* stage = nullptr;            // host image of the uploaded arrays (offsets as on the device)
+  size_t stage_bytes = 0;
+  bool stage_pinned = false;        // hipHostMalloc'ed and kept for refills; otherwise a vector that lives until push()
+  bool keep_stage = false;
+  std::vector<char> stage_vec;
   template <typename T>
-  void add(DevBuf<T>& d, size_t count, const T* host, int group) {
+  void add(DevBuf<T>& d, size_t count, const T* host, size_t host_count, int group) {
     d.n = count; d.in_arena = true; d.p = nullptr;
-    items.push_back(Item{ (void**)&d.p, count * sizeof(T), host, group, 0 });
+    items.push_back(Item{ (void**)&d.p, count * sizeof(T), host, host_count * sizeof(T), group, 0 });
   }
-  template <typename T> void upload(DevBuf<T>& d, const std::vector<T>& h) { add(d, h.size(), h.data(), 0); }
-  template <typename T> void scratch(DevBuf<T>& d, size_t count) { add(d, count, (const T*)nullptr, 1); }
-  template <typename T> void zeroed(DevBuf<T>& d, size_t count) { add(d, count, (const T*)nullptr, 2); }
-  int commit() {
-    size_t off = 0, upload_end = 0, zero_begin = 0;
+  template <typename T> void upload(DevBuf<T>& d, const std::vector<T>& h) { add(d, h.size(), h.data(), h.size(), 0); }
+  // uploaded, `count` elements of room; the caller writes host_of(d) between layout() and push()
+  template <typename T> void staged(DevBuf<T>& d, size_t count) { add(d, count, (const T*)nullptr, 0, 0); }
+  template <typename T> void scratch(DevBuf<T>& d, size_t count) { add(d, count, (const T*)nullptr, 0, 1); }
+  template <typename T> void zeroed(DevBuf<T>& d, size_t count) { add(d, count, (const T*)nullptr, 0, 2); }
+  template <typename T> T* host_of(const DevBuf<T>& d) const { return reinterpret_cast<T*>(stage + ((char*)d.p - base)); }
+  size_t upload_end = 0, zero_begin = 0;
+  int layout() {
+    size_t off = 0;
+    upload_end = 0; zero_begin = 0;
     for (int group = 0; group < 3; ++group) {        // uploaded arrays first, then scratch, then the zero-initialised ones
       if (group == 2) zero_begin = off;
       for (Item& it : items) {
@@ -126,22 +172,38 @@ struct DeviceArena {
       }
       if (group == 0) upload_end = off;
     }
-    if (off == 0) return SLSLAM_OK;
     bytes = off;
+    if (off == 0) { items.clear(); return SLSLAM_OK; }
     if (cached) HIP_TRY(DeviceBlockCache::acquire(off, device, &base));
     else HIP_TRY(hipMalloc((void**)&base, off));
-    std::vector<char> stage(upload_end);
+    if (keep_stage) {
+      HIP_TRY(hipHostMalloc((void**)&stage, std::max<size_t>(upload_end, 256), hipHostMallocDefault));
+      stage_pinned = true;
+      std::memset(stage, 0, upload_end);
+    } else {
+      stage_vec.assign(upload_end, 0);
+      stage = stage_vec.data();
+    }
+    stage_bytes = upload_end;
     for (const Item& it : items) {
       *it.pp = base + it.off;
-      if (it.host && it.bytes) std::memcpy(stage.data() + it.off, it.host, it.bytes);
+      if (it.host && it.host_bytes) std::memcpy(stage + it.off, it.host, it.host_bytes);
     }
-    if (upload_end) HIP_TRY(hipMemcpy(base, stage.data(), upload_end, hipMemcpyHostToDevice));
-    if (off > zero_begin) HIP_TRY(hipMemset(base + zero_begin, 0, off - zero_begin));
     items.clear();
     return SLSLAM_OK;
   }
+  int push() {
+    if (bytes == 0) return SLSLAM_OK;
+    if (upload_end) HIP_TRY(hipMemcpy(base, stage, upload_end, hipMemcpyHostToDevice));
+    if (bytes > zero_begin) HIP_TRY(hipMemset(base + zero_begin, 0, bytes - zero_begin));
+    if (!stage_pinned) { std::vector<char>().swap(stage_vec); stage = nullptr; }
+    return SLSLAM_OK;
+  }
+  int commit() { const int rc = layout(); return rc != SLSLAM_OK ? rc : push(); }
   void release() {
     if (base) { if (cached) DeviceBlockCache::give_back(base, bytes, device); else (void)hipFree(base); }
+    if (stage_pinned && stage) (void)hipHostFree(stage);
+    stage = nullptr; stage_pinned = false; std::vector<char>().swap(stage_vec);
     base = nullptr; items.clear();
   }
 };
@@ -176,9 +238,22 @@ struct slslam_lba_batch {
   std::vector<WinDesc> h_wins;
   std::vector<long long> h_param_off;     // per window offset into the exported parameter vector
   long long total_params = 0;
-  std::vector<LMState> h_state0, h_state;
-  std::vector<IterRec> h_trace;
-  std::vector<double> h_params;
+  std::vector<LMState> h_state0;
+  HostArr<LMState> h_state;
+  HostArr<IterRec> h_trace;
+  HostArr<double> h_params;
+  // refills (slslam_lba_batch_refill): the device arrays have room for `refill_headroom_percent` more than the first windows needed; the
+  // kernels' view of the batch (BatchPtrs: pointers, strides, counts) and with it the captured graph never change
+  bool refillable = false;
+  long long used_ncam = 0, used_nline = 0, used_nobs = 0, used_tiles = 0, used_items = 0;   // of the room the device arrays have
+  int cap_maxC = 0, cap_maxn = 0;            // the LDS sizes of the launches were made for these
+  int auto_rounds = 0, auto_cpw = 0;         // the automatic chunk policy as finalize resolved it: a refill cuts its windows the same way
+  std::vector<int> sys_map_off_of_cf;        // per free-camera count: its table in d_sys_map, or -1
+  hipEvent_t ev_stage_free = nullptr;        // recorded behind the uploads of a refill: the host image may be written again
+  hipEvent_t ev_results = nullptr;           // recorded behind the copies of an asynchronous download
+  bool results_pending = false;
+  HostPool* ext_pool = nullptr;              // host threads lent by a stream object; else own_pool, made on demand
+  std::unique_ptr<HostPool> own_pool;
   std::vector<int> h_ob_orig_off;          // per window offset into d_ob_orig
   bool downloaded = false;
   // device
@@ -260,6 +335,9 @@ struct slslam_lba_batch {
     d_big_pair_col.release(); d_big_pair_desc.release(); d_big_flags.release(); d_big_J.release(); d_big_F.release(); d_big_cost.release();
     d_big_camtab.release(); d_big_line_acc.release(); d_big_sys.release(); d_big_scal.release(); d_big_linv.release(); d_big_sys_off.release();
     arena.release();
+    h_state.release(); h_trace.release(); h_params.release();
+    if (ev_stage_free) { (void)hipEventDestroy(ev_stage_free); ev_stage_free = nullptr; }
+    if (ev_results) { (void)hipEventDestroy(ev_results); ev_results = nullptr; }
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     if (capture_stream) { (void)hipStreamDestroy(capture_stream); capture_stream = nullptr; }
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -377,6 +455,238 @@ int on_both_parts(slslam_lba_batch* b, hipStream_t s, Fn fn) {
 }
 }  // namespace
 
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// The batch-wide layout of a set of packed windows.  plan_layout: where every window's slices go (prefix sums) and how its tiles are
+// cut into chunks - serial and cheap.  fill_window: the slices themselves, written into the host image of the device arrays; windows
+// are independent, one per host thread.  Used by slslam_lba_batch_finalize and by slslam_lba_batch_refill.
+struct LayoutPlan {
+  std::vector<WinDesc> wins;
+  std::vector<long long> param_off;             // per window: offset into the exported parameter vector
+  std::vector<int> ob_orig_off, item_base, win_graded;
+  std::vector<Chunk> chunks;                    // dispatch order
+  long long ncam = 0, nline = 0, nobs = 0, ntiles = 0, nitems = 0, sys = 0, slab = 0, params = 0;
+  int maxC = 1, maxn = 0, max_chunks = 0, max_sys = 0;
+};
+
+int plan_layout(slslam_lba_batch* b, const std::vector<PackedWindow>& wins, bool frozen, LayoutPlan* out) {
+  LayoutPlan& L = *out;
+  const int B = (int)wins.size();
+  long long total_tiles = 0;
+  for (const PackedWindow& P : wins) total_tiles += (long long)P.tiles.size();
+  if (!frozen) {
+    // the sweeps run 8 one-wave workgroups per CU (LDS): the same number of chunks for every window, chosen so that
+    // the batch fills whole rounds of the chip's wave slots with about 36 tiles per chunk at most
+    // (1024 bench windows: 6 chunks of 33 tiles = 6144 waves = 3 rounds of 256 CUs x 8)
+    const long long slots = (8LL / b->elim_waves) * b->num_cus;      // chunk workgroups resident per round
+    const long long per_round = 36LL * b->elim_waves * slots;
+    const long long rounds = std::max<long long>(1, (total_tiles + per_round - 1) / per_round);
+    b->auto_rounds = (int)std::min<long long>(rounds, 1 << 20);
+    b->auto_cpw = (int)std::min<long long>(std::max<long long>(1, (slots * rounds) / std::max(1, B)), 1 << 20);
+  }
+  L.wins.resize((size_t)B); L.param_off.resize((size_t)B); L.ob_orig_off.resize((size_t)B); L.item_base.resize((size_t)B);
+  L.win_graded.assign((size_t)B, 0);
+  std::vector<int> chunk_rank;           // per chunk (window-major): 0 dispatched in the first class, 1 in the second (graded sizes)
+  std::vector<Chunk> chunks;
+  for (int wi = 0; wi < B; ++wi) {
+    const PackedWindow& P = wins[wi];
+    WinDesc& wd = L.wins[wi];
+    std::memset(&wd, 0, sizeof(wd));
+    wd.C = P.C; wd.Cf = P.Cf; wd.L = P.L; wd.M = P.M;
+    wd.cam_off = (int)L.ncam; wd.line_off = (int)L.nline; wd.obs_off = (int)L.nobs;
+    wd.tile_off = (int)L.ntiles; wd.ntiles = (int)P.tiles.size();
+    wd.n = 6 * P.Cf; wd.sys_off = (int)L.sys; wd.nfree_params = P.nfree_params; wd.nkept = P.nkept;
+    L.maxC = std::max(L.maxC, P.C); L.maxn = std::max(L.maxn, wd.n);
+    L.param_off[wi] = L.params; L.params += 6LL * P.C + 4LL * P.L;
+    L.ob_orig_off[wi] = (int)L.nobs;
+    L.item_base[wi] = (int)L.nitems;
+    // chunks: runs of tiles handled by one wave.  Few long chunks keep the per-chunk partial of
+    // the reduced system (a slab in HBM) small against the observation stream; many short chunks
+    // fill the chip when the batch is small.
+    int per_chunk;
+    int graded_chunks = 0, graded_rounds = 0;             // > 0: graded chunk sizes (below)
+    if (b->opt.chunks_per_window < 0) {                   // the caller asks for the graded cut a batch reported (slslam_lba_batch_window_chunks < 0):
+      graded_rounds = (-b->opt.chunks_per_window) / 1000; graded_chunks = (-b->opt.chunks_per_window) % 1000;        // -(1000 rounds + chunks)
+      if (graded_rounds < 2 || graded_chunks < graded_rounds) return SLSLAM_ERR_INVALID_ARGUMENT;
+      per_chunk = 1;
+    } else
+    if (b->opt.chunks_per_window > 0) per_chunk = std::max(1, (wd.ntiles + b->opt.chunks_per_window - 1) / b->opt.chunks_per_window);
+    else {
+      // automatic: the batch-wide numbers above - or, with slslam_solver_options.reproducible, a function of the WINDOW alone (what the
+      // automatic choice gives the windows of a batch that fills the chip: chunks of at most 34 tiles, graded for three rounds of the
+      // wave slots), so that a window is cut the same way whatever batch it sits in
+      long long rounds = b->auto_rounds, cpw = b->auto_cpw;
+      if (b->opt.reproducible) { cpw = std::max(1, (wd.ntiles + 33) / 34); rounds = 3; }
+      // (down to ONE tile per wave when the chip has room: since the camera tables are shared through memory, the partials of a
+      // many-chunk window summed chip-wide (k_slab_reduce) and the first tile's loads requested ahead of the set-up, a second tile
+      // costs a resident window more than a second chunk does - 0.44 / 0.60 / 0.98 -> 0.38 / 0.50 / 0.89 ms at W = 5 / 10 / 20,
+      // round 4; rounds 2-3 kept at least two tiles per wave)
+      per_chunk = (int)std::max<long long>(b->elim_waves, (wd.ntiles + cpw - 1) / cpw);
+      // GRADED sizes when every wave slot runs several chunks (rounds >= 2) of many tiles.  A launch ends when the slowest slot has
+      // finished its LAST chunk; with equal chunks - exactly `rounds` per slot, so nothing is left to balance with - that wait was a
+      // fifth of the sweep (tools/chunk_timeline.py: 2048 slots 81 % busy, chunk durations 206-442 us around 297).  Now the chunks a
+      // window contributes to the first round of the slots carry 70 % of a slot's share of the tiles, those of the second round 20 %
+      // (30 % when there are only two), the rest what is left, and the chunk array - the dispatch order - lists the classes one after
+      // the other: a slot that is late with its long chunk takes fewer short ones.  The slab count per window - what the reduced
+      // solve reads - does not change.
+      if (rounds >= 2 && cpw >= rounds && cpw < 1000 && b->elim_waves == 1 && wd.ntiles >= 8 * cpw && !std::getenv("SLSLAM_EQUAL_CHUNKS")) {
+        graded_chunks = (int)cpw; graded_rounds = (int)rounds;
+      }
+    }
+    int weights[1000];
+    for (int c = 0; c < graded_chunks; ++c) {
+      const int q = (int)(((long long)c * graded_rounds) / graded_chunks);           // the round of the slots this chunk belongs to
+      weights[c] = q == 0 ? 84 : q == 1 ? (graded_rounds == 2 ? 36 : 24) : std::max(1, 12 / (graded_rounds - 2));
+    }
+    if (const char* ws = std::getenv("SLSLAM_CHUNK_WEIGHTS")) {           // (experiments: comma-separated weights of the window's chunks)
+      int c = 0;
+      for (const char* q = ws; *q && c < graded_chunks; ++c) { weights[c] = std::max(1, std::atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+    }
+    std::vector<int> bounds = graded_chunks > 0 ? chunk_boundaries_graded(wd.ntiles, graded_chunks, weights) : chunk_boundaries(wd.ntiles, per_chunk);
+    L.win_graded[wi] = (graded_chunks > 0 && (int)bounds.size() - 1 == graded_chunks) ? graded_rounds : 0;
+    if (b->big_mode) { bounds.assign(2, 0); }            // no tiles: one chunk per window carries its step statistics
+    wd.chunk_off = (int)chunks.size(); wd.nchunks = (int)bounds.size() - 1;
+    wd.slab_off = (int)L.slab;
+    const int nsys = b->elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n);
+    const long long slab_stride = (long long)nsys + kSlabScalars;
+    L.max_chunks = std::max(L.max_chunks, wd.nchunks); L.max_sys = std::max(L.max_sys, nsys);
+    for (int c = 0; c < wd.nchunks; ++c) {
+      Chunk ck; ck.win = wi; ck.tile_begin = wd.tile_off + bounds[c]; ck.tile_end = wd.tile_off + bounds[c + 1];
+      ck.slab_off = (int)L.slab; L.slab += slab_stride;
+      ck.id = (int)chunks.size();
+      chunks.push_back(ck);
+      chunk_rank.push_back(L.win_graded[wi] ? (int)(((long long)c * graded_rounds) / graded_chunks) : 0);
+    }
+    if (L.slab > 0x7fffffffLL) return SLSLAM_ERR_UNSUPPORTED;
+    L.ncam += P.C; L.nline += P.L; L.nobs += P.M; L.sys += wd.n;
+    L.ntiles += (long long)P.tiles.size(); L.nitems += (long long)(P.items.size() / 2);
+    if (L.nobs > 0x7fffffffLL || L.nitems > 0x7fffffffLL) return SLSLAM_ERR_UNSUPPORTED;
+  }
+  // dispatch order: the long chunks of the graded windows (and every chunk of the others) first, the short ones after them; inside a class
+  // the order of the ids (a stable partition: ids, slabs and partial sums keep their window-major places)
+  {
+    int max_rank = 0;
+    for (int r : chunk_rank) max_rank = std::max(max_rank, r);
+    L.chunks.clear(); L.chunks.reserve(chunks.size());
+    for (int r = 0; r <= max_rank; ++r) for (size_t i = 0; i < chunks.size(); ++i) if (chunk_rank[i] == r) L.chunks.push_back(chunks[i]);
+  }
+  return SLSLAM_OK;
+}
+
+// The host image of the uploaded arrays (DeviceArena::stage), by array.
+struct HostImage {
+  WinDesc* wins; Tile* tiles; Chunk* chunks; uint8_t* items; uint16_t* lane_map; uint32_t* line_desc;
+  double* cam_x0; int* cam_cf; int* cam_win;
+  double* line_u0; int* line_ptr; int* line_flags; int* line_win; int* line_orig;
+  double* ob; long long ob_stride; int* ob_cam; int* ob_orig;
+  long long* param_off;
+};
+HostImage host_image(slslam_lba_batch* b) {
+  const DeviceArena& ar = b->arena;
+  HostImage m;
+  m.wins = ar.host_of(b->d_wins); m.tiles = ar.host_of(b->d_tiles); m.chunks = ar.host_of(b->d_chunks); m.items = ar.host_of(b->d_items);
+  m.lane_map = ar.host_of(b->d_lane_map); m.line_desc = ar.host_of(b->d_line_desc);
+  m.cam_x0 = ar.host_of(b->d_cam_x0); m.cam_cf = ar.host_of(b->d_cam_cf); m.cam_win = ar.host_of(b->d_cam_win);
+  m.line_u0 = ar.host_of(b->d_line_x0); m.line_ptr = ar.host_of(b->d_line_ptr); m.line_flags = ar.host_of(b->d_line_flags);
+  m.line_win = ar.host_of(b->d_line_win); m.line_orig = ar.host_of(b->d_line_orig);
+  m.ob = ar.host_of(b->d_ob); m.ob_stride = (long long)(b->d_ob.n / 8); m.ob_cam = ar.host_of(b->d_ob_cam); m.ob_orig = ar.host_of(b->d_ob_orig);
+  m.param_off = ar.host_of(b->d_param_off);
+  return m;
+}
+
+// Window wi's slices of every uploaded array (hw: the windows' descriptors with their sys_map tables resolved).
+void fill_window(const slslam_lba_batch* b, const LayoutPlan& plan, const std::vector<PackedWindow>& wins, int wi, const HostImage& m, bool copy_observations) {
+  const PackedWindow& P = wins[(size_t)wi];
+  const WinDesc& wd = b->h_wins[(size_t)wi];
+  m.wins[wi] = wd;
+  m.param_off[wi] = plan.param_off[(size_t)wi];
+  const int item_base = plan.item_base[(size_t)wi];
+  for (size_t t = 0; t < P.tiles.size(); ++t) {
+    Tile x = P.tiles[t];
+    x.line_begin += wd.line_off; x.item_off += item_base;
+    m.tiles[(size_t)wd.tile_off + t] = x;
+  }
+  if (!P.items.empty()) std::memcpy(m.items + 2 * (size_t)item_base, P.items.data(), P.items.size());
+  if (!P.lane_map.empty()) std::memcpy(m.lane_map + 64 * (size_t)wd.tile_off, P.lane_map.data(), P.lane_map.size() * sizeof(uint16_t));
+  if (P.L > 0) {
+    std::memcpy(m.line_desc + wd.line_off, P.line_desc.data(), (size_t)P.L * sizeof(uint32_t));
+    std::memcpy(m.line_u0 + 4 * (size_t)wd.line_off, P.line_u.data(), (size_t)4 * P.L * sizeof(double));
+    std::memcpy(m.line_flags + wd.line_off, P.line_flags.data(), (size_t)P.L * sizeof(int));
+    std::memcpy(m.line_orig + wd.line_off, P.line_order.data(), (size_t)P.L * sizeof(int));
+    for (int s2 = 0; s2 < P.L; ++s2) { m.line_ptr[wd.line_off + s2] = wd.obs_off + P.line_ptr[s2]; m.line_win[wd.line_off + s2] = wi; }
+  }
+  for (int c = 0; c < P.C; ++c) {
+    for (int a = 0; a < 6; ++a) m.cam_x0[6 * (size_t)(wd.cam_off + c) + a] = P.cam_x[6 * (size_t)c + a];
+    m.cam_cf[wd.cam_off + c] = P.cam_cf[c]; m.cam_win[wd.cam_off + c] = wi;
+  }
+  if (P.M > 0) {
+    std::memcpy(m.ob_cam + wd.obs_off, P.ob_cam.data(), (size_t)P.M * sizeof(int));
+    std::memcpy(m.ob_orig + wd.obs_off, P.ob_orig.data(), (size_t)P.M * sizeof(int));
+    if (copy_observations)       // planes of (x,y) pairs, batch-wide: ob[(plane * ob_stride + o) * 2 + {0, 1}] (the packer's layout per window)
+      for (int pl = 0; pl < 4; ++pl)
+        std::memcpy(m.ob + ((size_t)pl * (size_t)m.ob_stride + (size_t)wd.obs_off) * 2, P.ob.data() + (size_t)pl * 2 * (size_t)P.M, sizeof(double) * 2 * (size_t)P.M);
+  }
+}
+
+// What is not a window's: the chunk array, the end of the line pointers, and the marks on the unused records (a record without a
+// window is skipped by the per-line / per-camera kernels: k_line_trig, k_export).
+void fill_tail(const slslam_lba_batch* b, const LayoutPlan& plan, const HostImage& m) {
+  if (!plan.chunks.empty()) std::memcpy(m.chunks, plan.chunks.data(), plan.chunks.size() * sizeof(Chunk));
+  for (size_t c = plan.chunks.size(); c < b->d_chunks.n && c < (size_t)b->nchunk; ++c) { Chunk z; z.win = -1; z.tile_begin = 0; z.tile_end = 0; z.slab_off = 0; z.id = 0; m.chunks[c] = z; }
+  m.line_ptr[plan.nline] = (int)plan.nobs;
+  for (size_t ls = (size_t)plan.nline; ls < b->d_line_win.n; ++ls) m.line_win[ls] = -1;
+  for (size_t c = (size_t)plan.ncam; c < b->d_cam_win.n; ++c) { m.cam_win[c] = -1; m.cam_cf[c] = -1; }
+  if (plan.ntiles == 0) for (int q = 0; q < 64; ++q) m.lane_map[q] = (uint16_t)0x00FF;
+  if (plan.nline == 0) m.line_flags[0] = 1;
+}
+
+HostPool* batch_pool(slslam_lba_batch* b, int threads) {
+  if (threads <= 1) return nullptr;
+  if (b->ext_pool) return b->ext_pool;
+  const int hw = (int)std::thread::hardware_concurrency();
+  if (hw > 0) threads = std::min(threads, hw);
+  if (threads <= 1) return nullptr;
+  if (!b->own_pool || b->own_pool->threads() != threads) b->own_pool.reset(new HostPool(threads));
+  return b->own_pool.get();
+}
+
+// One 16-byte record per lane and tile (BatchPtrs.lane_ctx): sorted line | first observation of the line | position in the run (bits 0-5),
+// run length (6-12), lane has a line (13), skew (14), the line's constant flag (15), the tile's flags (16-23), line slot (24-31) | the
+// tile's lane-th line descriptor - lane_map, line_ptr, line_flags and line_desc resolved once per batch.  thread <-> (tile, lane).
+__global__ __launch_bounds__(256) void k_build_lane_ctx(BatchPtrs p, int ntiles, int32_t* out) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (long long)ntiles * 64) return;
+  const int t = (int)(g >> 6), lane = (int)(g & 63);
+  const Tile tl = p.tiles[t];
+  const unsigned m = p.lane_map[g];
+  const unsigned tflags = ((unsigned)tl.flags & 0xffu) << 16;
+  unsigned misc = ((m & 0xffu) << 24) | (1u << 15) | tflags;            // slot | "constant" for an idle lane | the tile's flags
+  int r0 = 0, r1 = 0;
+  if ((m & 0xffu) != 0xffu) {
+    const int ls = tl.line_begin + (int)(m & 0xffu);
+    const int o0 = p.line_ptr[ls], k = p.line_ptr[ls + 1] - o0;
+    r0 = ls; r1 = o0;
+    misc = ((m >> 8) & 0x3fu) | ((unsigned)k & 0x7fu) << 6 | 1u << 13 | ((m >> 15) & 1u) << 14 | ((unsigned)p.line_flags[ls] & 1u) << 15 | tflags | (m & 0xffu) << 24;
+  }
+  const int r3 = lane < tl.nlines ? (int)p.line_desc[tl.line_begin + lane] : 0;
+  reinterpret_cast<int4*>(out)[g] = make_int4(r0, r1, (int)misc, r3);
+}
+
+// After the uploaded arrays are on the device: the tile contexts, and both parameter buffers of cameras and lines + the LM state from the
+// initial values (k_reset).  On `s`.
+int device_init_after_upload(slslam_lba_batch* b, hipStream_t s) {
+  const long long nt = b->used_tiles;
+  if (nt > 0 && !b->big_mode)
+    hipLaunchKernelGGL(k_build_lane_ctx, dim3((unsigned)((nt * 64 + 255) / 256)), dim3(256), 0, s, b->ptrs, (int)nt, b->d_lane_ctx.p);
+  const long long total = 6LL * b->ncam + 4LL * b->nline + b->ptrs.nwin;      // one thread per parameter / per window state
+  if (total > 0) hipLaunchKernelGGL(k_reset, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b->ptrs, b->pol);
+  HIP_TRY(hipGetLastError());
+  return SLSLAM_OK;
+}
+
+}  // namespace
+
 extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solver_options* opt) {
   if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (b->finalized) return SLSLAM_ERR_STATE;
@@ -412,7 +722,9 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     // (zeroing its 20 KB of accumulator tiles in memory, adding the group sums into them) is not worth it
     long long tiles_in_batch = 0;
     for (const PackedWindow& P : b->wins) tiles_in_batch += (long long)P.tiles.size();
-    const bool auto_grouped = want == 0 && mfma_ok && b->opt.chunks_per_window == 0 && tiles_in_batch >= 16LL * 8 * b->num_cus;
+    // (reproducible: no choice by the batch - 0 means the LDS-atomic sweep, and a requested matrix-core sweep is run or refused)
+    if (b->opt.reproducible && want >= 2 && !mfma_ok) return SLSLAM_ERR_UNSUPPORTED;
+    const bool auto_grouped = want == 0 && !b->opt.reproducible && mfma_ok && b->opt.chunks_per_window == 0 && tiles_in_batch >= 16LL * 8 * b->num_cus;
     b->elim_mode = ((want >= 2 || auto_grouped) && mfma_ok) ? 1 : 0;
     b->elim_waves = b->elim_mode == 0 ? 1 : (want == 3 ? 2 : 1);
     b->elim_grouped = b->elim_mode == 1 && (want == 4 || auto_grouped);
@@ -423,240 +735,111 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
       // after this point keeps its windows as they are now, and a second attempt with another sweep must not read line descriptors in
       // the other layout
       const int want_grouping = b->elim_grouped ? 1 : 0;
-      for (PackedWindow& P : b->wins) {
-        if (P.grouping == want_grouping || P.big) continue;
+      std::vector<int> todo;
+      for (int wi = 0; wi < B; ++wi) if (b->wins[(size_t)wi].grouping != want_grouping && !b->wins[(size_t)wi].big) todo.push_back(wi);
+      std::vector<int> st(todo.size(), SLSLAM_OK);
+      auto one = [&](int q) {
         PackedWindow Q;
-        const int rc = repack_window(P, want_grouping, &Q);
-        if (rc != SLSLAM_OK) return rc;
-        P = std::move(Q);
-      }
+        st[(size_t)q] = repack_window(b->wins[(size_t)todo[(size_t)q]], want_grouping, &Q);
+        if (st[(size_t)q] == SLSLAM_OK) b->wins[(size_t)todo[(size_t)q]] = std::move(Q);
+      };
+      HostPool* pool = batch_pool(b, (int)std::min<size_t>(todo.size(), b->opt.host_threads > 0 ? (size_t)b->opt.host_threads : (todo.size() >= 64 ? 8 : 1)));
+      if (pool) pool->run((int)todo.size(), one); else for (int q = 0; q < (int)todo.size(); ++q) one(q);
+      for (int r : st) if (r != SLSLAM_OK) return r;
     }
   }
 
-  // ---- global layout
-  std::vector<int> chunk_rank;           // per chunk (window-major): 0 dispatched in the first class, 1 in the second (graded sizes)
-  b->h_win_graded.assign((size_t)std::max(1, B), 0);
-  std::vector<Tile> tiles; std::vector<Chunk> chunks; std::vector<uint8_t> items; std::vector<uint16_t> lane_map; std::vector<uint32_t> line_desc;
-  std::vector<double> cam_x, line_x, ob, cam_x0, line_u0; std::vector<int> cam_cf, cam_win, line_ptr, line_flags, line_win, line_orig, ob_cam, ob_orig;
-  long long ncam = 0, nline = 0, nobs = 0, sys = 0, slab = 0, param_off = 0;
-  long long total_tiles = 0;
-  for (const PackedWindow& P : b->wins) total_tiles += (long long)P.tiles.size();
-  int maxC = 1, maxn = 0;
-  b->h_wins.resize(B); b->h_param_off.resize(B); b->h_ob_orig_off.resize(B);
-  for (const PackedWindow& P : b->wins) nobs += P.M;
+  // ---- global layout: where every window's slices go (serial: prefix sums and chunk cuts), then the slices themselves (fill_window)
+  LayoutPlan plan;
+  {
+    const int prc = plan_layout(b, b->wins, /*frozen=*/false, &plan);
+    if (prc != SLSLAM_OK) return prc;
+  }
+  const long long ncam = plan.ncam, nline = plan.nline, nobs = plan.nobs, sys = plan.sys, slab = plan.slab, param_off = plan.params;
+  const int maxC = plan.maxC, maxn = plan.maxn;
+  b->h_wins = plan.wins; b->h_param_off = plan.param_off; b->h_ob_orig_off = plan.ob_orig_off; b->h_win_graded = plan.win_graded;
+  if (b->h_win_graded.empty()) b->h_win_graded.assign(1, 0);
   b->nobs = nobs;
-  ob.resize((size_t)8 * (size_t)nobs);
-  long long obs_cursor = 0;
-  for (int wi = 0; wi < B; ++wi) {
-    const PackedWindow& P = b->wins[wi];
-    WinDesc& wd = b->h_wins[wi];
-    std::memset(&wd, 0, sizeof(wd));
-    wd.C = P.C; wd.Cf = P.Cf; wd.L = P.L; wd.M = P.M;
-    wd.cam_off = (int)ncam; wd.line_off = (int)nline; wd.obs_off = (int)obs_cursor;
-    wd.tile_off = (int)tiles.size(); wd.ntiles = (int)P.tiles.size();
-    wd.n = 6 * P.Cf; wd.sys_off = (int)sys; wd.nfree_params = P.nfree_params; wd.nkept = P.nkept;
-    maxC = std::max(maxC, P.C); maxn = std::max(maxn, wd.n);
-    b->h_param_off[wi] = param_off; param_off += 6LL * P.C + 4LL * P.L;
-    b->h_ob_orig_off[wi] = (int)obs_cursor;
-    // chunks: runs of tiles handled by one wave.  Few long chunks keep the per-chunk partial of
-    // the reduced system (a slab in HBM) small against the observation stream; many short chunks
-    // fill the chip when the batch is small.
-    int per_chunk;
-    int graded_chunks = 0, graded_rounds = 0;             // > 0: graded chunk sizes (below)
-    if (b->opt.chunks_per_window < 0) {                   // the caller asks for the graded cut a batch reported (slslam_lba_batch_window_chunks < 0):
-      graded_rounds = (-b->opt.chunks_per_window) / 1000; graded_chunks = (-b->opt.chunks_per_window) % 1000;        // -(1000 rounds + chunks)
-      if (graded_rounds < 2 || graded_chunks < graded_rounds) return SLSLAM_ERR_INVALID_ARGUMENT;
-      per_chunk = 1;
-    } else
-    if (b->opt.chunks_per_window > 0) per_chunk = std::max(1, (wd.ntiles + b->opt.chunks_per_window - 1) / b->opt.chunks_per_window);
-    else {
-      // the sweeps run 8 one-wave workgroups per CU (LDS): the same number of chunks for every window, chosen so that
-      // the batch fills whole rounds of the chip's wave slots with about 36 tiles per chunk at most
-      // (1024 bench windows: 6 chunks of 33 tiles = 6144 waves = 3 rounds of 256 CUs x 8)
-      const long long slots = (8LL / b->elim_waves) * b->num_cus;      // chunk workgroups resident per round
-      const long long per_round = 36LL * b->elim_waves * slots;
-      const long long rounds = std::max<long long>(1, (total_tiles + per_round - 1) / per_round);
-      const long long cpw = std::max<long long>(1, (slots * rounds) / std::max(1, B));
-      // (down to ONE tile per wave when the chip has room: since the camera tables are shared through memory, the partials of a
-      // many-chunk window summed chip-wide (k_slab_reduce) and the first tile's loads requested ahead of the set-up, a second tile
-      // costs a resident window more than a second chunk does - 0.44 / 0.60 / 0.98 -> 0.38 / 0.50 / 0.89 ms at W = 5 / 10 / 20,
-      // round 4; rounds 2-3 kept at least two tiles per wave)
-      per_chunk = (int)std::max<long long>(b->elim_waves, (wd.ntiles + cpw - 1) / cpw);
-      // GRADED sizes when every wave slot runs several chunks (rounds >= 2) of many tiles.  A launch ends when the slowest slot has
-      // finished its LAST chunk; with equal chunks - exactly `rounds` per slot, so nothing is left to balance with - that wait was a
-      // fifth of the sweep (tools/chunk_timeline.py: 2048 slots 81 % busy, chunk durations 206-442 us around 297).  Now the chunks a
-      // window contributes to the first round of the slots carry 70 % of a slot's share of the tiles, those of the second round 20 %
-      // (30 % when there are only two), the rest what is left, and the chunk array - the dispatch order - lists the classes one after
-      // the other: a slot that is late with its long chunk takes fewer short ones.  The slab count per window - what the reduced
-      // solve reads - does not change.
-      if (rounds >= 2 && cpw >= rounds && cpw < 1000 && b->elim_waves == 1 && wd.ntiles >= 8 * cpw && !std::getenv("SLSLAM_EQUAL_CHUNKS")) {
-        graded_chunks = (int)cpw; graded_rounds = (int)rounds;
-      }
-    }
-    int weights[1000];
-    for (int c = 0; c < graded_chunks; ++c) {
-      const int q = (int)(((long long)c * graded_rounds) / graded_chunks);           // the round of the slots this chunk belongs to
-      weights[c] = q == 0 ? 84 : q == 1 ? (graded_rounds == 2 ? 36 : 24) : std::max(1, 12 / (graded_rounds - 2));
-    }
-    if (const char* ws = std::getenv("SLSLAM_CHUNK_WEIGHTS")) {           // (experiments: comma-separated weights of the window's chunks)
-      int c = 0;
-      for (const char* q = ws; *q && c < graded_chunks; ++c) { weights[c] = std::max(1, std::atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-    }
-    std::vector<int> bounds = graded_chunks > 0 ? chunk_boundaries_graded(wd.ntiles, graded_chunks, weights) : chunk_boundaries(wd.ntiles, per_chunk);
-    b->h_win_graded[wi] = (graded_chunks > 0 && (int)bounds.size() - 1 == graded_chunks) ? graded_rounds : 0;
-    if (b->big_mode) { bounds.assign(2, 0); }            // no tiles: one chunk per window carries its step statistics
-    wd.chunk_off = (int)chunks.size(); wd.nchunks = (int)bounds.size() - 1;
-    wd.slab_off = (int)slab;
-    const long long slab_stride = (long long)(b->elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n)) + kSlabScalars;
-    for (int c = 0; c < wd.nchunks; ++c) {
-      Chunk ck; ck.win = wi; ck.tile_begin = wd.tile_off + bounds[c]; ck.tile_end = wd.tile_off + bounds[c + 1];
-      ck.slab_off = (int)slab; slab += slab_stride;
-      ck.id = (int)chunks.size();
-      chunks.push_back(ck);
-      chunk_rank.push_back(b->h_win_graded[wi] ? (int)(((long long)c * graded_rounds) / graded_chunks) : 0);
-    }
-    if (slab > 0x7fffffffLL) return SLSLAM_ERR_UNSUPPORTED;
-    const int item_base = (int)(items.size() / 2);
-    for (Tile t : P.tiles) { t.line_begin += (int)nline; t.item_off += item_base; tiles.push_back(t); }
-    items.insert(items.end(), P.items.begin(), P.items.end());
-    lane_map.insert(lane_map.end(), P.lane_map.begin(), P.lane_map.end());
-    line_desc.insert(line_desc.end(), P.line_desc.begin(), P.line_desc.end());
-    for (int c = 0; c < P.C; ++c) {
-      for (int buf = 0; buf < 2; ++buf) for (int a = 0; a < 6; ++a) cam_x.push_back(P.cam_x[6 * (size_t)c + a]);
-      for (int a = 0; a < 6; ++a) cam_x0.push_back(P.cam_x[6 * (size_t)c + a]);
-      cam_cf.push_back(P.cam_cf[c]); cam_win.push_back(wi);
-    }
-    {
-      line_u0.insert(line_u0.end(), P.line_u.begin(), P.line_u.end());
-      const size_t p0 = line_ptr.size();
-      line_ptr.resize(p0 + (size_t)P.L);
-      for (int s = 0; s < P.L; ++s) line_ptr[p0 + s] = (int)obs_cursor + P.line_ptr[s];
-      line_flags.insert(line_flags.end(), P.line_flags.begin(), P.line_flags.end());
-      line_win.insert(line_win.end(), (size_t)P.L, wi);
-      line_orig.insert(line_orig.end(), P.line_order.begin(), P.line_order.end());
-    }
-    ob_cam.insert(ob_cam.end(), P.ob_cam.begin(), P.ob_cam.end());
-    ob_orig.insert(ob_orig.end(), P.ob_orig.begin(), P.ob_orig.end());
-    for (int pl = 0; pl < 4 && P.M > 0; ++pl)     // planes of (x,y) pairs, batch-wide: ob[(plane * nobs + o) * 2 + {0, 1}] (the packer's layout per window)
-      std::memcpy(ob.data() + ((size_t)pl * (size_t)nobs + (size_t)obs_cursor) * 2, P.ob.data() + (size_t)pl * 2 * (size_t)P.M, sizeof(double) * 2 * (size_t)P.M);
-    ncam += P.C; nline += P.L; obs_cursor += P.M; sys += wd.n;
-  }
-  line_ptr.push_back((int)obs_cursor);
-  if (nobs > 0x7fffffffLL) return SLSLAM_ERR_UNSUPPORTED;
-  // reduced solve: where each entry of a chunk partial goes in its LDS image, one table per distinct system order
+  // a batch that is going to be refilled (slslam_lba_batch_refill) gets room beyond what its first windows need: the next windows'
+  // observation, line, tile and item counts differ a little
+  b->refillable = b->opt.refill_headroom_percent > 0 && !b->big_mode;
+  const long long pct = b->refillable ? std::min(b->opt.refill_headroom_percent, 400) : 0;
+  auto room = [&](long long used) -> size_t { return (size_t)(b->refillable ? used + (used * pct) / 100 + 64 : used); };
+  const size_t cap_cam = std::max<size_t>(1, room(ncam)), cap_line = std::max<size_t>(1, room(nline)), cap_obs = std::max<size_t>(1, room(nobs));
+  const size_t cap_tiles = std::max<size_t>(1, room(plan.ntiles)), cap_items = std::max<size_t>(1, room(plan.nitems));
+  if (cap_obs > 0x7fffffffULL || cap_line > 0x7fffffffULL) return SLSLAM_ERR_UNSUPPORTED;
+  // reduced solve: where each entry of a chunk partial goes in its LDS image, one table per distinct system order (a refillable batch:
+  // one per free-camera count up to the largest of its first windows - the next windows may have any of them)
   std::vector<uint16_t> sys_map(1, (uint16_t)0xFFFF);
-  {
-    std::vector<int> off_of_n((size_t)maxn / 6 + 1, -1);
-    for (WinDesc& wd : b->h_wins) {
-      int& off = off_of_n[wd.n / 6];
-      if (off < 0 && !b->big_mode) {
-        off = (int)sys_map.size();
-        sys_map.resize(sys_map.size() + (size_t)sys_doubles(wd.n));
-        sys_map_build(wd.n, sys_map.data() + off);
-      }
-      wd.map_off = off < 0 ? 0 : off;
+  b->sys_map_off_of_cf.assign((size_t)maxn / 6 + 1, -1);
+  if (!b->big_mode) {
+    for (int cf = 0; cf <= maxn / 6; ++cf) {
+      bool wanted = b->refillable;
+      for (const WinDesc& wd : b->h_wins) if (wd.n == 6 * cf) wanted = true;
+      if (!wanted) continue;
+      b->sys_map_off_of_cf[(size_t)cf] = (int)sys_map.size();
+      sys_map.resize(sys_map.size() + (size_t)sys_doubles(6 * cf));
+      sys_map_build(6 * cf, sys_map.data() + b->sys_map_off_of_cf[(size_t)cf]);
     }
   }
-  // dispatch order: the long chunks of the graded windows (and every chunk of the others) first, the short ones after them; inside a class
-  // the order of the ids (a stable partition: ids, slabs and partial sums keep their window-major places)
-  {
-    std::vector<Chunk> ordered; ordered.reserve(chunks.size());
-    int max_rank = 0;
-    for (int r : chunk_rank) max_rank = std::max(max_rank, r);
-    for (int r = 0; r <= max_rank; ++r) for (size_t i = 0; i < chunks.size(); ++i) if (chunk_rank[i] == r) ordered.push_back(chunks[i]);
-    chunks.swap(ordered);
-  }
-  b->total_params = param_off; b->nchunk = (int)chunks.size(); b->nline = (int)nline; b->ncam = (int)ncam;
+  for (WinDesc& wd : b->h_wins) { const int off = b->sys_map_off_of_cf[(size_t)wd.n / 6]; wd.map_off = off < 0 ? 0 : off; }
+  // (the chunk array too: a refill may cut its windows into a few more chunks; the launches cover the whole array, unused entries are marked)
+  b->total_params = param_off; b->nchunk = (int)room((long long)plan.chunks.size()); b->nline = (int)cap_line; b->ncam = (int)cap_cam;
+  b->used_ncam = ncam; b->used_nline = nline; b->used_nobs = nobs; b->used_tiles = plan.ntiles; b->used_items = plan.nitems;
+  b->cap_maxC = maxC; b->cap_maxn = maxn;
 
   // ---- initial LM state (Ceres: LevenbergMarquardtStrategy ctor)
   b->h_state0.assign(B, LMState());
   for (int wi = 0; wi < B; ++wi) {
-    LMState& s = b->h_state0[wi];
-    std::memset(&s, 0, sizeof(s));
-    s.radius = b->pol.initial_radius; s.decrease_factor = 2.0; s.status = kRunning; s.fresh = 1;
+    LMState& st = b->h_state0[wi];
+    std::memset(&st, 0, sizeof(st));
+    st.radius = b->pol.initial_radius; st.decrease_factor = 2.0; st.status = kRunning; st.fresh = 1;
   }
 
   // ---- one allocation, one upload
   int rc;
   DeviceArena& ar = b->arena;
   ar.device = b->device;
-  ar.upload(b->d_wins, b->h_wins);
+  ar.keep_stage = b->refillable;
+  ar.staged(b->d_wins, (size_t)std::max(1, B));
   ar.upload(b->d_sys_map, sys_map);
-  ar.upload(b->d_tiles, tiles);
-  ar.upload(b->d_chunks, chunks);
-  if (items.empty()) items.push_back(0);
-  ar.upload(b->d_items, items);
-  if (lane_map.empty()) lane_map.assign(64, (uint16_t)0x00FF);
-  ar.upload(b->d_lane_map, lane_map);
-  if (line_desc.empty()) line_desc.push_back(0u);
-  ar.upload(b->d_line_desc, line_desc);
-  // everything a lane has to know about its place in a tile, resolved once here (lba_kernels.h::fetch_tile): the sweeps get it with
-  // ONE 16-byte load whose address depends on the tile index only - no chain tile -> lane map -> line pointer inside their loops
-  std::vector<int32_t> lane_ctx((size_t)std::max<size_t>(1, tiles.size()) * 64 * 4, 0);
-  for (size_t t = 0; t < tiles.size(); ++t) {
-    const Tile& tl = tiles[t];
-    for (int lane = 0; lane < 64; ++lane) {
-      const unsigned m = lane_map[t * 64 + lane];
-      const bool ok = (m & 0xffu) != 0xffu;
-      int32_t* r = lane_ctx.data() + (t * 64 + lane) * 4;
-      const unsigned tflags = ((unsigned)tl.flags & 0xffu) << 16;
-      unsigned misc = ((m & 0xffu) << 24) | (1u << 15) | tflags;            // slot | "constant" for an idle lane | the tile's flags
-      if (ok) {
-        const int ls = tl.line_begin + (int)(m & 0xffu);
-        const int o0 = line_ptr[(size_t)ls], k = line_ptr[(size_t)ls + 1] - o0;
-        if (k > 127) return SLSLAM_ERR_UNSUPPORTED;
-        r[0] = ls; r[1] = o0;
-        misc = ((m >> 8) & 0x3fu) | (unsigned)k << 6 | 1u << 13 | ((m >> 15) & 1u) << 14 | ((unsigned)line_flags[(size_t)ls] & 1u) << 15 | tflags | (m & 0xffu) << 24;
-      }
-      r[2] = (int32_t)misc;
-      r[3] = (lane < tl.nlines && (size_t)(tl.line_begin + lane) < line_desc.size()) ? (int32_t)line_desc[(size_t)(tl.line_begin + lane)] : 0;
-    }
-  }
-  ar.upload(b->d_lane_ctx, lane_ctx);
-  if (cam_x.empty()) cam_x.assign(12, 0.0);
-  ar.upload(b->d_cam_x, cam_x);
-  if (cam_x0.empty()) cam_x0.assign(6, 0.0);
-  ar.upload(b->d_cam_x0, cam_x0);
-  ar.zeroed(b->d_cam_scale, std::max<size_t>(6, (size_t)6 * ncam));
+  ar.staged(b->d_tiles, cap_tiles);
+  ar.staged(b->d_chunks, (size_t)std::max(1, b->nchunk));
+  ar.staged(b->d_items, 2 * cap_items);
+  ar.staged(b->d_lane_map, 64 * cap_tiles);
+  ar.staged(b->d_line_desc, cap_line);
+  // everything a lane has to know about its place in a tile, resolved once per batch (lba_kernels.h::fetch_tile): the sweeps get it with
+  // ONE 16-byte load whose address depends on the tile index only - no chain tile -> lane map -> line pointer inside their loops.
+  // Built on the DEVICE from the lane maps (k_build_lane_ctx, round 5: the host loop and the upload of 1 KB per tile were a fifth of
+  // a batch build)
+  ar.scratch(b->d_lane_ctx, 64 * 4 * cap_tiles);
+  // both pose buffers and both line parameter buffers are filled on the device from the initial values (k_reset)
+  ar.scratch(b->d_cam_x, 12 * cap_cam);
+  ar.staged(b->d_cam_x0, 6 * cap_cam);
+  ar.zeroed(b->d_cam_scale, std::max<size_t>(6, (size_t)6 * cap_cam));
   // rotation / Jacobian tables of both pose buffers, shared by the chunks of a window (BatchPtrs.cam_tab); the default sweeps only:
   // the other paths (reuse_elimination, streamed F, matrix-core sweep) keep building their tables per sweep.  Small batches only:
   // there a chunk is a tile or two and the tables are a tenth of a sweep; in a batch that fills the chip a chunk is ~33 tiles, the
   // tables are nothing, and reading them would add 30 MB to a sweep's traffic
   const bool share_cam_tab = B <= b->num_cus && !b->big_mode && !b->fused_motion_only && b->elim_mode == 0 && !b->opt.reuse_elimination && !b->pol.store_f && b->opt.max_num_iterations > 0 && !(b->pol.debug_flags & 16384);
-  ar.zeroed(b->d_cam_tab, share_cam_tab ? std::max<size_t>(1, (size_t)2 * kCamTab * ncam) : 1);
-  if (cam_cf.empty()) { cam_cf.push_back(-1); cam_win.push_back(0); }
-  ar.upload(b->d_cam_cf, cam_cf);
-  ar.upload(b->d_cam_win, cam_win);
-  {
-    // both parameter buffers, buffer-major [2][nline][kLineRec]: (a, b, g, t) | sin/cos table (filled on the device)
-    const size_t nl = (size_t)std::max<long long>(1, nline);
-    line_x.assign(2 * nl * kLineRec, 0.0);
-    for (size_t ls = 0; ls < (size_t)nline; ++ls)
-      for (int buf = 0; buf < 2; ++buf)
-        for (int a = 0; a < 4; ++a) line_x[((size_t)buf * nl + ls) * kLineRec + a] = line_u0[4 * ls + a];
-  }
-  ar.upload(b->d_line_x, line_x);
-  if (line_u0.empty()) line_u0.assign(4, 0.0);
-  ar.upload(b->d_line_x0, line_u0);
-  ar.zeroed(b->d_line_scale, std::max<size_t>(4, (size_t)4 * nline));
-  ar.upload(b->d_line_ptr, line_ptr);
-  if (line_flags.empty()) { line_flags.push_back(1); line_win.push_back(0); line_orig.push_back(0); }
-  ar.upload(b->d_line_flags, line_flags);
-  ar.upload(b->d_line_win, line_win);
-  ar.upload(b->d_line_orig, line_orig);
-  if (ob.empty()) ob.assign(8, 0.0);
-  ar.upload(b->d_ob, ob);
-  if (ob_cam.empty()) { ob_cam.push_back(0); ob_orig.push_back(0); }
-  ar.upload(b->d_ob_cam, ob_cam);
-  ar.upload(b->d_ob_orig, ob_orig);
-  ar.scratch(b->d_slab, std::max<size_t>(1, (size_t)slab));
+  ar.zeroed(b->d_cam_tab, share_cam_tab ? std::max<size_t>(1, (size_t)2 * kCamTab * cap_cam) : 1);
+  ar.staged(b->d_cam_cf, cap_cam);
+  ar.staged(b->d_cam_win, cap_cam);
+  // both parameter buffers, buffer-major [2][nline][kLineRec]: (a, b, g, t) | sin/cos table (filled on the device)
+  ar.scratch(b->d_line_x, 2 * cap_line * kLineRec);
+  ar.staged(b->d_line_x0, 4 * cap_line);
+  ar.zeroed(b->d_line_scale, std::max<size_t>(4, (size_t)4 * cap_line));
+  ar.staged(b->d_line_ptr, cap_line + 1);
+  ar.staged(b->d_line_flags, cap_line);
+  ar.staged(b->d_line_win, cap_line);
+  ar.staged(b->d_line_orig, cap_line);
+  ar.staged(b->d_ob, 8 * cap_obs);
+  ar.staged(b->d_ob_cam, cap_obs);
+  ar.staged(b->d_ob_orig, cap_obs);
+  ar.scratch(b->d_slab, std::max<size_t>(1, room(slab)));
   {
     // windows cut into many chunks (small batches): their partials are summed by a kernel of their own, spread over the chip
-    int max_chunks = 0, max_sys = 0;
-    for (const WinDesc& wd : b->h_wins) {
-      max_chunks = std::max(max_chunks, wd.nchunks);
-      max_sys = std::max(max_sys, b->elim_mode == 1 ? sys_doubles_mfma(wd.n) : sys_doubles(wd.n));
-    }
+    const int max_chunks = plan.max_chunks, max_sys = plan.max_sys;
     b->slab_sum_stride = (max_chunks > 8 && !b->opt.reuse_elimination && !b->big_mode) ? (long long)max_sys + kSlabScalars : 0;
     // default sweeps: the sums go straight into the LDS image of the reduced solve (zeros where nothing is mapped: written
     // once, here)
@@ -671,16 +854,16 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   }
   ar.scratch(b->d_bs_part, std::max<size_t>(1, (size_t)b->nchunk * kBsStride));
   ar.scratch(b->d_cost_part, std::max<size_t>(1, (size_t)b->nchunk));
-  ar.scratch(b->d_ysys, std::max<size_t>(1, (size_t)sys));
-  ar.scratch(b->d_fstore, b->pol.keep_jacobian ? (size_t)(24 * 64) * std::max<size_t>(1, tiles.size())        // [tile][12][64] double2
-                          : b->opt.reuse_elimination ? (size_t)24 * (size_t)std::max<long long>(1, nobs) : 2);
-  ar.scratch(b->d_line_h, b->pol.keep_jacobian ? (size_t)10 * (size_t)std::max<long long>(1, nline) : 2);
+  ar.scratch(b->d_ysys, std::max<size_t>(1, room(sys)));
+  ar.scratch(b->d_fstore, b->pol.keep_jacobian ? (size_t)(24 * 64) * cap_tiles        // [tile][12][64] double2
+                          : b->opt.reuse_elimination ? (size_t)24 * cap_obs : 2);
+  ar.scratch(b->d_line_h, b->pol.keep_jacobian ? (size_t)10 * cap_line : 2);
   b->line_elim_stride = (b->opt.reuse_elimination || b->big_mode) ? kLineElim : kLeU;      // K g is kept for those two paths only
-  ar.scratch(b->d_line_elim, std::max<size_t>(1, (size_t)nline * b->line_elim_stride));
-  ar.scratch(b->d_params_out, std::max<size_t>(1, (size_t)param_off));
+  ar.scratch(b->d_line_elim, std::max<size_t>(1, cap_line * b->line_elim_stride));
+  ar.scratch(b->d_params_out, std::max<size_t>(1, room(param_off)));
   ar.upload(b->d_state, b->h_state0);
   ar.zeroed(b->d_trace, std::max<size_t>(1, (size_t)B * kMaxTrace));
-  ar.upload(b->d_param_off, b->h_param_off);
+  ar.staged(b->d_param_off, (size_t)std::max(1, B));
   std::vector<int> big_ob_line, big_cam_ptr, big_cam_obs, big_pair_ptr, big_pair_row, big_pair_col, big_pair_desc;
   if (b->big_mode) {
     // gather lists of the global-memory path (lba_big.h): per camera its observations, per (window, camera pair r >= c) the
@@ -778,7 +961,16 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.zeroed(b->d_iter_counter, 1);
   ar.zeroed(b->d_dbg_cycles, b->pol.debug_flags ? std::max((size_t)32 * std::max(1, b->nchunk), (size_t)16 * std::max(1, B)) : 1);
   ar.zeroed(b->d_active, 1);
-  if ((rc = ar.commit())) return rc;
+  if ((rc = ar.layout())) return rc;
+  {
+    // every window's slices into the host image, one window per host thread (they are independent), then ONE upload
+    HostImage img = host_image(b);
+    HostPool* pool = batch_pool(b, (int)std::min<long long>(B, b->opt.host_threads > 0 ? b->opt.host_threads : (B >= 64 ? 8 : 1)));
+    auto one = [&](int wi) { fill_window(b, plan, b->wins, wi, img, /*copy_observations=*/true); };
+    if (pool) pool->run(B, one); else for (int wi = 0; wi < B; ++wi) one(wi);
+    fill_tail(b, plan, img);
+  }
+  if ((rc = ar.push())) return rc;
 
   BatchPtrs& p = b->ptrs;
   p.wins = b->d_wins.p; p.tiles = b->d_tiles.p; p.chunks = b->d_chunks.p; p.items = b->d_items.p; p.lane_map = b->d_lane_map.p; p.lane_ctx = b->d_lane_ctx.p;
@@ -786,7 +978,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   p.cam_tab = share_cam_tab ? b->d_cam_tab.p : nullptr;
   p.line_x = b->d_line_x.p; p.line_scale = b->d_line_scale.p; p.line_ptr = b->d_line_ptr.p;
   p.line_flags = b->d_line_flags.p; p.line_win = b->d_line_win.p;
-  p.ob = b->d_ob.p; p.ob_cam = b->d_ob_cam.p; p.ob_stride = std::max<long long>(1, nobs);
+  p.ob = b->d_ob.p; p.ob_cam = b->d_ob_cam.p; p.ob_stride = (long long)cap_obs;
   p.slab_sum = b->slab_sum_stride ? b->d_slab_sum.p : nullptr; p.slab_sum_stride = b->slab_sum_stride; p.slab_sum_image = b->slab_sum_image ? 1 : 0;
   p.slab = b->d_slab.p; p.bs_part = b->d_bs_part.p; p.cost_part = b->d_cost_part.p; p.ysys = b->d_ysys.p;
   p.fstore = b->d_fstore.p; p.line_elim = b->d_line_elim.p; p.line_elim_stride = b->line_elim_stride; p.line_h = b->d_line_h.p;
@@ -835,9 +1027,12 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
     HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
   }
-  b->h_state.assign(B, LMState());
-  b->h_trace.assign((size_t)B * kMaxTrace, IterRec());
-  b->h_params.assign((size_t)param_off, 0.0);
+  // on the device: the tile contexts from the lane maps, both parameter buffers of cameras and lines from the initial values
+  if ((rc = device_init_after_upload(b, nullptr))) return rc;
+  if (!ar.cached) HIP_TRY(hipStreamSynchronize(nullptr));      // (a one-shot solve stays on the null stream: ordered behind this anyway)
+  if ((rc = b->h_state.alloc((size_t)B, b->refillable))) return rc;
+  if ((rc = b->h_trace.alloc((size_t)B * kMaxTrace, b->refillable))) return rc;
+  if ((rc = b->h_params.alloc(room(param_off), b->refillable))) return rc;
   b->finalized = true;
   return SLSLAM_OK;
 }
@@ -1132,29 +1327,143 @@ extern "C" int slslam_lba_batch_export_device(slslam_lba_batch* b, double* devic
   return SLSLAM_OK;
 }
 
-extern "C" int slslam_lba_batch_download(slslam_lba_batch* b, void* stream) {
+extern "C" int slslam_lba_batch_download_async(slslam_lba_batch* b, void* stream) {
   if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (!b->finalized) return SLSLAM_ERR_STATE;
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
+  b->downloaded = false;
   if (b->part[0]) {
-    int rc0 = slslam_lba_batch_download(b->part[0], stream);
-    if (rc0 == SLSLAM_OK) rc0 = slslam_lba_batch_download(b->part[1], stream);
-    b->downloaded = rc0 == SLSLAM_OK;
+    int rc0 = slslam_lba_batch_download_async(b->part[0], stream);
+    if (rc0 == SLSLAM_OK) rc0 = slslam_lba_batch_download_async(b->part[1], stream);
     return rc0;
   }
   int rc = slslam_lba_batch_export_device(b, b->d_params_out.p, stream);
   if (rc) return rc;
-  if (!b->h_params.empty())
-    HIP_TRY(hipMemcpyAsync(b->h_params.data(), b->d_params_out.p, b->h_params.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (b->total_params > 0)
+    HIP_TRY(hipMemcpyAsync(b->h_params.data(), b->d_params_out.p, (size_t)b->total_params * sizeof(double), hipMemcpyDeviceToHost, s));
   if (!b->h_state.empty()) {
     HIP_TRY(hipMemcpyAsync(b->h_state.data(), b->d_state.p, b->h_state.size() * sizeof(LMState), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(b->h_trace.data(), b->d_trace.p, b->h_trace.size() * sizeof(IterRec), hipMemcpyDeviceToHost, s));
   }
-  HIP_TRY(hipStreamSynchronize(s));
+  if (!b->ev_results) HIP_TRY(hipEventCreateWithFlags(&b->ev_results, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(b->ev_results, s));
+  b->results_pending = true;
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_wait(slslam_lba_batch* b) {
+  if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b->finalized) return SLSLAM_ERR_STATE;
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->part[0]) {
+    int rc0 = slslam_lba_batch_wait(b->part[0]);
+    if (rc0 == SLSLAM_OK) rc0 = slslam_lba_batch_wait(b->part[1]);
+    b->downloaded = rc0 == SLSLAM_OK;
+    return rc0;
+  }
+  if (!b->results_pending) return b->downloaded ? SLSLAM_OK : SLSLAM_ERR_STATE;
+  HIP_TRY(hipEventSynchronize(b->ev_results));
+  b->results_pending = false;
   if (b->profiling) b->harvest_events();
   b->downloaded = true;
   return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_batch_download(slslam_lba_batch* b, void* stream) {
+  const int rc = slslam_lba_batch_download_async(b, stream);
+  return rc != SLSLAM_OK ? rc : slslam_lba_batch_wait(b);
+}
+
+// ------------------------------------------------------------------------------------------
+// A batch for a stream of windows: every window replaced, nothing allocated, nothing captured again (include/slslam_hip.h).
+extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_window* windows, int n, void* stream) {
+  if (!b || (!windows && n > 0)) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (!b->finalized) return SLSLAM_ERR_STATE;
+  if (!b->refillable || b->part[0] || b->big_mode || b->fused_motion_only || b->opt.reuse_elimination) return SLSLAM_ERR_UNSUPPORTED;
+  const int B = (int)b->wins.size();
+  if (n != B) return SLSLAM_ERR_UNSUPPORTED;              // the launches of the captured solve were made for this many windows
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (b->ev_stage_free) HIP_TRY(hipEventSynchronize(b->ev_stage_free));      // the host image may still feed the previous refill's copies
+  if (b->results_pending) { HIP_TRY(hipEventSynchronize(b->ev_results)); b->results_pending = false; }
+  // ---- pack (the LBAProblem::build stage, one window per host thread), the observations straight into the host image: where a window's
+  // observations go only depends on the counts before it
+  std::vector<long long> obs_off((size_t)B + 1, 0);
+  for (int i = 0; i < B; ++i) {
+    if (windows[i].num_observations < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
+    obs_off[(size_t)i + 1] = obs_off[(size_t)i] + windows[i].num_observations;
+  }
+  const HostImage img = host_image(b);
+  if (obs_off[(size_t)B] > img.ob_stride) return SLSLAM_ERR_UNSUPPORTED;
+  const int grouping = b->elim_grouped ? 1 : 0;
+  std::vector<PackedWindow> wins((size_t)B);
+  std::vector<int> st((size_t)B, SLSLAM_OK);
+  HostPool* pool = batch_pool(b, (int)std::min<long long>(B, b->opt.host_threads > 0 ? b->opt.host_threads : (B >= 64 ? 8 : 1)));
+  auto pack_one = [&](int i) {
+    ObPlanes dest;
+    for (int q = 0; q < 4; ++q) dest.plane[q] = img.ob + ((size_t)q * (size_t)img.ob_stride + (size_t)obs_off[(size_t)i]) * 2;
+    st[(size_t)i] = pack_window(&windows[i], &wins[(size_t)i], grouping, &dest);
+  };
+  if (pool) pool->run(B, pack_one); else for (int i = 0; i < B; ++i) pack_one(i);
+  for (int r : st) if (r != SLSLAM_OK) return r;
+  for (const PackedWindow& P : wins) {
+    if (P.big) return SLSLAM_ERR_UNSUPPORTED;                                        // (would take the global-memory path)
+    if (b->elim_mode == 1 && (P.Cf > kMfmaMaxFree || P.dup_free_obs)) return SLSLAM_ERR_UNSUPPORTED;   // (the batch's sweep cannot take it)
+  }
+  // ---- layout, cut like the batch's first windows, and does it fit
+  LayoutPlan plan;
+  int rc = plan_layout(b, wins, /*frozen=*/true, &plan);
+  if (rc != SLSLAM_OK) return rc;
+  bool fits = (size_t)plan.ncam <= b->d_cam_cf.n && (size_t)plan.nline <= b->d_line_win.n && plan.nobs <= img.ob_stride &&
+              (size_t)plan.ntiles <= b->d_tiles.n && (size_t)plan.nitems * 2 <= b->d_items.n && (int)plan.chunks.size() <= b->nchunk &&
+              (size_t)plan.slab <= b->d_slab.n && (size_t)plan.sys <= b->d_ysys.n && (size_t)plan.params <= b->d_params_out.n &&
+              (size_t)plan.params <= b->h_params.size() && plan.maxC <= b->cap_maxC && plan.maxn <= b->cap_maxn;
+  if (b->slab_sum_stride) {
+    if (b->slab_sum_image) {
+      long long ext = 0;
+      for (const WinDesc& wd : plan.wins) { const int N = solve_pad(wd.n); ext = std::max<long long>(ext, (long long)N * solve_stride(wd.n) + 6LL * N); }
+      fits = fits && ((ext + kSlabScalars + 1) / 2) * 2 <= b->slab_sum_stride;
+    } else fits = fits && (long long)plan.max_sys + kSlabScalars <= b->slab_sum_stride;
+  } else fits = fits && plan.max_chunks <= 8;            // (more chunks per window would need k_slab_reduce in the captured solve)
+  for (WinDesc& wd : plan.wins) {
+    const int off = (size_t)(wd.n / 6) < b->sys_map_off_of_cf.size() ? b->sys_map_off_of_cf[(size_t)wd.n / 6] : -1;
+    if (off < 0) fits = false;
+    wd.map_off = off < 0 ? 0 : off;
+  }
+  if (!fits) return SLSLAM_ERR_UNSUPPORTED;
+  // ---- commit: the batch now IS the new windows
+  b->h_wins = plan.wins; b->h_param_off = plan.param_off; b->h_ob_orig_off = plan.ob_orig_off; b->h_win_graded = plan.win_graded;
+  if (b->h_win_graded.empty()) b->h_win_graded.assign(1, 0);
+  b->total_params = plan.params; b->nobs = plan.nobs;
+  b->used_ncam = plan.ncam; b->used_nline = plan.nline; b->used_nobs = plan.nobs; b->used_tiles = plan.ntiles; b->used_items = plan.nitems;
+  b->wins.swap(wins);
+  b->downloaded = false;
+  auto fill_one = [&](int wi) { fill_window(b, plan, b->wins, wi, img, /*copy_observations=*/false); };
+  if (pool) pool->run(B, fill_one); else for (int wi = 0; wi < B; ++wi) fill_one(wi);
+  fill_tail(b, plan, img);
+  // ---- upload what is used of every array, asynchronously from the pinned image
+  const DeviceArena& ar = b->arena;
+#define SLS_UP(buf, count) do { const size_t nb_ = (size_t)(count) * sizeof(*(buf).p); \
+    if (nb_) HIP_TRY(hipMemcpyAsync((void*)(buf).p, (const void*)ar.host_of(buf), nb_, hipMemcpyHostToDevice, s)); } while (0)
+  SLS_UP(b->d_wins, B); SLS_UP(b->d_tiles, plan.ntiles); SLS_UP(b->d_chunks, b->nchunk); SLS_UP(b->d_items, 2 * plan.nitems);
+  SLS_UP(b->d_lane_map, 64 * plan.ntiles); SLS_UP(b->d_line_desc, plan.nline);
+  SLS_UP(b->d_cam_x0, 6 * plan.ncam); SLS_UP(b->d_cam_cf, b->d_cam_cf.n); SLS_UP(b->d_cam_win, b->d_cam_win.n);
+  SLS_UP(b->d_line_x0, 4 * plan.nline); SLS_UP(b->d_line_ptr, plan.nline + 1); SLS_UP(b->d_line_flags, std::max<long long>(1, plan.nline));
+  SLS_UP(b->d_line_win, b->d_line_win.n); SLS_UP(b->d_line_orig, plan.nline);
+  for (int q = 0; q < 4 && plan.nobs > 0; ++q)
+    HIP_TRY(hipMemcpyAsync(b->d_ob.p + (size_t)q * (size_t)img.ob_stride * 2, img.ob + (size_t)q * (size_t)img.ob_stride * 2, (size_t)plan.nobs * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+  SLS_UP(b->d_ob_cam, plan.nobs); SLS_UP(b->d_ob_orig, plan.nobs); SLS_UP(b->d_param_off, B);
+#undef SLS_UP
+  if (!b->ev_stage_free) HIP_TRY(hipEventCreateWithFlags(&b->ev_stage_free, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(b->ev_stage_free, s));
+  // what a fresh batch finds zeroed
+  HIP_TRY(hipMemsetAsync(b->d_cam_scale.p, 0, b->d_cam_scale.n * sizeof(double), s));
+  HIP_TRY(hipMemsetAsync(b->d_line_scale.p, 0, b->d_line_scale.n * sizeof(double), s));
+  HIP_TRY(hipMemsetAsync(b->d_cam_tab.p, 0, b->d_cam_tab.n * sizeof(double), s));
+  if (b->slab_sum_image) HIP_TRY(hipMemsetAsync(b->d_slab_sum.p, 0, b->d_slab_sum.n * sizeof(double), s));
+  HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
+  return device_init_after_upload(b, s);
 }
 
 extern "C" int slslam_lba_batch_get_parameters(const slslam_lba_batch* b, int index, double* parameters) {
@@ -1340,4 +1649,141 @@ extern "C" int slslam_lba_solve(const slslam_lba_window* w, const slslam_solver_
   }
   slslam_lba_batch_destroy(b);
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// A STREAM of windows (BASELINE config 4 taken literally: every window arrives as the five host arrays the reference builds per
+// window, src/slam.cpp:899-921): `depth` refillable batches in flight, each on a HIP stream of its own - while the GPU solves batch k
+// and its copy engine uploads batch k + 1, the host threads pack batch k + 2.
+struct slslam_lba_stream {
+  int device = 0;
+  slslam_solver_options opt;
+  int depth = 3;
+  std::unique_ptr<HostPool> pool;
+  struct Slot {
+    slslam_lba_batch* batch = nullptr;
+    hipStream_t stream = nullptr;
+    int n = 0;                                  // windows of the batch in the slot
+    long long ticket = -1;
+    bool in_flight = false;
+    std::vector<double*> out_params;            // the callers' parameter arrays (solved in place, written by collect)
+  };
+  std::vector<Slot> slots;
+  long long next_ticket = 0;
+  // host-side accounting (ms, wall clock of the calling thread)
+  double ms_submit = 0, ms_collect_wait = 0, ms_collect_copy = 0;
+  long long n_refills = 0, n_builds = 0, n_windows = 0, n_iterations = 0;
+};
+
+extern "C" int slslam_lba_stream_create(int device, const slslam_solver_options* opt, int depth, slslam_lba_stream** out) {
+  if (!out) return SLSLAM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SLSLAM_ERR_NO_DEVICE;
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return SLSLAM_ERR_NO_DEVICE; }
+  if (device >= ndev || depth < 1 || depth > 8) return SLSLAM_ERR_INVALID_ARGUMENT;
+  slslam_lba_stream* st = new (std::nothrow) slslam_lba_stream();
+  if (!st) return SLSLAM_ERR_HIP;
+  st->device = device; st->depth = depth;
+  if (opt) st->opt = *opt; else slslam_default_options(&st->opt);
+  if (st->opt.refill_headroom_percent <= 0) st->opt.refill_headroom_percent = 10;
+  st->opt.use_graph = 1;
+  int threads = st->opt.host_threads;
+  if (threads <= 0) threads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+  st->opt.host_threads = threads;
+  st->pool.reset(new HostPool(threads));
+  st->slots.resize((size_t)depth);
+  if (hipSetDevice(device) != hipSuccess) { delete st; return SLSLAM_ERR_NO_DEVICE; }
+  for (auto& sl : st->slots)
+    if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) {
+      for (auto& x : st->slots) if (x.stream) (void)hipStreamDestroy(x.stream);
+      delete st;
+      return SLSLAM_ERR_HIP;
+    }
+  *out = st;
+  return SLSLAM_OK;
+}
+
+extern "C" void slslam_lba_stream_destroy(slslam_lba_stream* st) {
+  if (!st) return;
+  (void)hipSetDevice(st->device);
+  for (auto& sl : st->slots) {
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    if (sl.batch) { sl.batch->ext_pool = nullptr; slslam_lba_batch_destroy(sl.batch); }
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+  }
+  delete st;
+}
+
+extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_window* windows, int n, int* ticket) {
+  if (!st || !windows || n <= 0) return SLSLAM_ERR_INVALID_ARGUMENT;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto& sl = st->slots[(size_t)(st->next_ticket % st->depth)];
+  if (sl.in_flight) return SLSLAM_ERR_STATE;             // its results have not been collected
+  HIP_TRY(hipSetDevice(st->device));
+  int rc = SLSLAM_ERR_UNSUPPORTED;
+  if (sl.batch && sl.n == n) rc = slslam_lba_batch_refill(sl.batch, windows, n, (void*)sl.stream);
+  if (rc == SLSLAM_OK) ++st->n_refills;
+  else if (rc == SLSLAM_ERR_UNSUPPORTED) {
+    // the first batch of the slot, another number of windows, or windows that do not fit the room the slot's arrays have: a new batch
+    if (sl.batch) { HIP_TRY(hipStreamSynchronize(sl.stream)); sl.batch->ext_pool = nullptr; slslam_lba_batch_destroy(sl.batch); sl.batch = nullptr; }
+    slslam_lba_batch* b = nullptr;
+    if ((rc = slslam_lba_batch_create(st->device, &b)) != SLSLAM_OK) return rc;
+    b->ext_pool = st->pool.get();
+    b->wins.resize((size_t)n);
+    std::vector<int> ps((size_t)n, SLSLAM_OK);
+    st->pool->run(n, [&](int i) { ps[(size_t)i] = pack_window(&windows[i], &b->wins[(size_t)i]); });
+    for (int r : ps) if (r != SLSLAM_OK) rc = r;
+    if (rc == SLSLAM_OK) rc = slslam_lba_batch_finalize(b, &st->opt);
+    if (rc != SLSLAM_OK) { b->ext_pool = nullptr; slslam_lba_batch_destroy(b); return rc; }
+    sl.batch = b; sl.n = n;
+    ++st->n_builds;
+  } else return rc;
+  if ((rc = slslam_lba_batch_solve(sl.batch, (void*)sl.stream)) != SLSLAM_OK) return rc;
+  if ((rc = slslam_lba_batch_download_async(sl.batch, (void*)sl.stream)) != SLSLAM_OK) return rc;
+  sl.out_params.resize((size_t)n);
+  for (int i = 0; i < n; ++i) sl.out_params[(size_t)i] = windows[i].parameters;
+  sl.ticket = st->next_ticket; sl.in_flight = true;
+  if (ticket) *ticket = (int)st->next_ticket;
+  ++st->next_ticket; st->n_windows += n;
+  st->ms_submit += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_stream_collect(slslam_lba_stream* st, int ticket, slslam_summary* summaries) {
+  if (!st || ticket < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
+  auto& sl = st->slots[(size_t)(ticket % st->depth)];
+  if (!sl.in_flight || sl.ticket != ticket) return SLSLAM_ERR_STATE;
+  HIP_TRY(hipSetDevice(st->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = slslam_lba_batch_wait(sl.batch);
+  if (rc != SLSLAM_OK) return rc;
+  const auto t1 = std::chrono::steady_clock::now();
+  std::vector<int> rs((size_t)sl.n, SLSLAM_OK);
+  st->pool->run(sl.n, [&](int i) {
+    int r = slslam_lba_batch_get_parameters(sl.batch, i, sl.out_params[(size_t)i]);
+    if (r == SLSLAM_OK && summaries) r = slslam_lba_batch_get_summary(sl.batch, i, summaries + i);
+    rs[(size_t)i] = r;
+  });
+  for (int r : rs) if (r != SLSLAM_OK) rc = r;
+  for (int i = 0; i < sl.n; ++i) st->n_iterations += sl.batch->h_state[(size_t)i].n_success + sl.batch->h_state[(size_t)i].n_unsuccess;   // reference src/slam.cpp:949-950
+  sl.in_flight = false;
+  const auto t2 = std::chrono::steady_clock::now();
+  st->ms_collect_wait += std::chrono::duration<double, std::milli>(t1 - t0).count();
+  st->ms_collect_copy += std::chrono::duration<double, std::milli>(t2 - t1).count();
+  return rc;
+}
+
+extern "C" int slslam_lba_stream_stats(const slslam_lba_stream* st, double* ms_submit, double* ms_collect_wait, double* ms_collect_copy,
+                                       long long* refills, long long* builds, long long* windows, long long* lm_iterations, int* host_threads) {
+  if (!st) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (ms_submit) *ms_submit = st->ms_submit;
+  if (ms_collect_wait) *ms_collect_wait = st->ms_collect_wait;
+  if (ms_collect_copy) *ms_collect_copy = st->ms_collect_copy;
+  if (refills) *refills = st->n_refills;
+  if (builds) *builds = st->n_builds;
+  if (windows) *windows = st->n_windows;
+  if (lm_iterations) *lm_iterations = st->n_iterations;
+  if (host_threads) *host_threads = st->pool ? st->pool->threads() : 1;
+  return SLSLAM_OK;
 }

@@ -81,6 +81,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
   const int lane = threadIdx.x;
   SLS_K1_STAMP_INIT;
   const Chunk ck = p.chunks[blockIdx.x];
+  if (ck.win < 0) return;                              // an unused entry of a refillable batch's chunk array (lba_types.h)
   SLS_K1_WALL(30);
   const WinDesc wd = p.wins[ck.win];
   const LMState* st = p.state + ck.win;

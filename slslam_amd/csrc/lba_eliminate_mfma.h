@@ -133,6 +133,7 @@ void k_eliminate_mfma(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Chunk ck = p.chunks[blockIdx.x];
+  if (ck.win < 0) return;                              // an unused entry of a refillable batch's chunk array (lba_types.h)
   const WinDesc wd = p.wins[ck.win];
   const LMState* st = p.state + ck.win;
   if (st->status != kRunning && !(DBG && pol.debug_flags)) return;     // (timing experiments keep sweeping windows whose garbage results ended them)

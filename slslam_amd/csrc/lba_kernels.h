@@ -636,6 +636,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int lane = threadIdx.x;
   SLS_K1_STAMP_INIT;
   const Chunk ck = p.chunks[blockIdx.x];
+  if (ck.win < 0) return;                              // an unused entry of a refillable batch's chunk array (lba_types.h)
   const WinDesc wd = p.wins[ck.win];
   const LMState* st = p.state + ck.win;
   if (st->status != kRunning) return;
@@ -1660,6 +1661,7 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   SLS_K1_STAMP_INIT;
   const Chunk ck = p.chunks[blockIdx.x];
+  if (ck.win < 0) return;                              // an unused entry of a refillable batch's chunk array (lba_types.h)
   SLS_K1_WALL(28);
   const WinDesc wd = p.wins[ck.win];
   const LMState* st = p.state + ck.win;
@@ -1853,6 +1855,7 @@ __global__ __launch_bounds__(64) void k_backsub_stream(BatchPtrs p, Policy pol) 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const Chunk ck = p.chunks[blockIdx.x];
+  if (ck.win < 0) return;                              // an unused entry of a refillable batch's chunk array (lba_types.h)
   const WinDesc wd = p.wins[ck.win];
   const LMState* st = p.state + ck.win;
   if (st->status != kRunning) return;
@@ -1931,7 +1934,9 @@ __global__ __launch_bounds__(64) void k_backsub_stream(BatchPtrs p, Policy pol) 
 __global__ __launch_bounds__(256) void k_line_trig(BatchPtrs p, int which) {
   const int ls = blockIdx.x * blockDim.x + threadIdx.x;
   if (ls >= p.nline) return;
-  const LMState* st = p.state + p.line_win[ls];
+  const int lw = p.line_win[ls];
+  if (lw < 0) return;                                  // a record beyond the batch's lines (room for refills)
+  const LMState* st = p.state + lw;
   if (st->status != kRunning) return;
   const int buf = which ? 1 - st->cur : st->cur;
   double* rec = p.line_x + line_rec(p, ls, buf);
@@ -1948,6 +1953,7 @@ __global__ __launch_bounds__(64) void k_candidate_cost(BatchPtrs p, Policy pol) 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const Chunk ck = p.chunks[blockIdx.x];
+  if (ck.win < 0) return;                              // an unused entry of a refillable batch's chunk array (lba_types.h)
   const WinDesc wd = p.wins[ck.win];
   const LMState* st = p.state + ck.win;
   if (st->status != kRunning) return;
@@ -2229,6 +2235,7 @@ __global__ __launch_bounds__(256) void k_export(BatchPtrs p, const long long* wi
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < p.ncam) {
     const int w = cam_win[i];
+    if (w < 0) return;                                 // a record beyond the batch's cameras (room for refills)
     const WinDesc wd = p.wins[w];
     const int cur = p.state[w].cur;
     const double* x = p.cam_x + ((long long)i * 2 + cur) * kCamRec;
@@ -2237,6 +2244,7 @@ __global__ __launch_bounds__(256) void k_export(BatchPtrs p, const long long* wi
   } else if (i < p.ncam + p.nline) {
     const int ls = i - p.ncam;
     const int w = p.line_win[ls];
+    if (w < 0) return;
     const WinDesc wd = p.wins[w];
     const int cur = p.state[w].cur;
     const double* x = p.line_x + line_rec(p, ls, cur);

@@ -22,7 +22,7 @@ bool all_finite(const double* v, size_t n) {
 }
 }  // namespace
 
-int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping) {
+int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, const ObPlanes* ob_dest) {
   if (!w || !out) return SLSLAM_ERR_INVALID_ARGUMENT;
   const int C = w->num_cameras, L = w->num_lines, M = w->num_observations;
   if (C < 0 || L < 0 || M < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
@@ -244,10 +244,11 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping) {
     }
   }
   P.ob_cam.resize(M);
-  P.ob.resize((size_t)8 * M);
+  if (!ob_dest) P.ob.resize((size_t)8 * M);
   P.nkept = 0;
   {
     double* pl[4] = { P.ob.data(), P.ob.data() + 2 * (size_t)M, P.ob.data() + 4 * (size_t)M, P.ob.data() + 6 * (size_t)M };
+    if (ob_dest) for (int q = 0; q < 4; ++q) pl[q] = ob_dest->plane[q];
     for (int o = 0; o < M; ++o) {
       const int i = P.ob_orig[o];
       P.ob_cam[o] = w->camera_index[i];

@@ -48,7 +48,11 @@ struct PackedWindow {
 // FIRST free camera that sees them (a sliding window's lines are seen by runs of consecutive keyframes, so the reduced-system rows
 // a line touches, counted from its first camera, fit a few 16-row blocks), the lines whose camera range needs a fourth block
 // (more than 8 cameras) behind the others of their group; rows are bin-packed inside a group and fill the tiles in that order.
-int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping = 0);
+// ob_dest (optional): the four observation planes are written THERE (plane q: ob_dest->plane[q][2 o + {0, 1}], o = sorted position) instead of
+// into out->ob, which stays empty - a batch that is refilled from host buffers packs straight into its pinned staging image
+// (slslam_lba_batch_refill: one pass over the caller's observations, no second copy).
+struct ObPlanes { double* plane[4]; };
+int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping = 0, const ObPlanes* ob_dest = nullptr);
 // The same window packed again with another grouping (the caller's arrays are rebuilt from the packed ones).
 int repack_window(const PackedWindow& P, int grouping, PackedWindow* out);
 

