@@ -263,7 +263,19 @@ def cross_rank_result_check(batches, where, lo, B, rank, world, dev, local_rank,
             if not np.array_equal(got, mine):
                 equal = False
                 maxdiff = max(maxdiff, float(np.abs(got - mine).max()))
+    # ... and against the committed 1-rank record of the same window ids (tests/golden/bench_digest.json, tools/make_bench_digest.py): a
+    # window's bytes are a function of the window, the sweep and the cut, whatever the number of ranks
+    stored = None
+    try:
+        dg = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_digest.json")))
+        if dg["lines"] == lines and dg["windows_per_gpu"] == B and dg["lba_elimination"] == elim_eff and all(int(x) == dg["chunks_per_window"] for x in allm[:, 1:1 + k].reshape(-1)):
+            known = [(i, c) for i, c in zip(ids, crcs) if str(i) in dg["crc32"]]
+            if known:
+                stored = {"compared": len(known), "equal": all(dg["crc32"][str(i)] == c for i, c in known)}
+    except Exception:
+        stored = None
     return {"window_ids": ids, "crc32_of_gathered_parameters": crcs, "bitwise_equal_to_rank0_resolve": equal,
+            "equal_to_stored_1_rank_digest": stored,
             "max_abs_diff": maxdiff, "checked_per_rank": k, "lba_elimination": elim_eff,
             "how": "first %d windows of every rank's shard: parameters all-gathered on the device, rank 0 solves the same ids in "
                    "1-window batches with the same chunk count and compares bytes" % k}
@@ -351,6 +363,44 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
     return out
 
 
+def mixed_precision_block(windows, counts, device, resident_value, steps=5, warmup=2):
+    """The opt-in mixed-precision mode (slslam_solver_options.lba_precision = 1: float row gradients / Jacobians / four-term block products in
+    the steady elimination sweeps, double accumulation and bookkeeping) on the SAME resident windows: throughput (hipGraph
+    replay) and the elimination sweep's own roofline from an eager profiled pass.  Narrower arithmetic than the reference: an `extra`
+    block, never `value`; its tolerance against the double path is asserted by tests/test_gpu_lba.py::test_mixed_precision_solves."""
+    bt = capi.LBABatch(device=device)
+    for w in windows:
+        bt.add(w)
+    bt.finalize(use_graph=1, lba_precision=1)
+    for _ in range(max(warmup, 1)):
+        bt.reset(); bt.solve()
+    bt.iterations(clear=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bt.reset(); bt.solve()
+    its = bt.iterations()
+    dt = time.perf_counter() - t0
+    bt.set_profiling(True)
+    for _ in range(3):
+        bt.reset(); bt.solve()
+    torch.cuda.synchronize()
+    bt.download()
+    kt = bt.kernel_times()
+    ms, n = kt["linearise_schur"]
+    out = {"value": its / dt, "unit": "LM iterations/s", "ms_per_step": 1e3 * dt / steps, "vs_double_path": (its / dt) / resident_value if resident_value else None,
+           "lm_iterations": its, "lba_elimination": bt.elimination(), "dtype": "f32 Jacobians and block products / f64 geometry, residuals, accumulation",
+           "sum_final_cost": sum(bt.summary(i)["final_cost"] for i in range(len(windows)))}
+    if n > 0:
+        bytes_launch = algorithmic_bytes_linearise(counts)
+        ach = bytes_launch / (ms / n * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_eliminate_grouped<false, false, true> (9 of 10 launches; the first sweep of a solve is the double one)",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "avg_launch_ms": ms / n, "launches": n}
+    bt.close()
+    return out
+
+
 def single_window_latency(lines, device, **shape):
     """The reference's call protocol (slam.cpp:924-944: one window per keyframe, each built from the result of the one
     before): ms per 10-iteration solve of ONE window resident in HBM (hipGraph replay) and through slslam_lba_solve
@@ -432,8 +482,9 @@ def main():
                     help="also all-gather the solved parameters of every rank inside the timed region (one RCCL all-gather per step)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the 500-line, latency and pose-graph blocks")
     ap.add_argument("--no-result-check", action="store_true", help="skip the cross-rank bitwise check of the results (outside the timed region)")
+    ap.add_argument("--stream-depth", type=int, default=3, help="batches in flight in the streamed leg")
     ap.add_argument("--no-streamed", action="store_true", help="skip the streamed leg (config 4 as a stream of host-side windows)")
-    ap.add_argument("--stream-batches", type=int, default=8, help="timed batches of the streamed leg")
+    ap.add_argument("--stream-batches", type=int, default=16, help="timed batches of the streamed leg")
     ap.add_argument("--host-threads", type=int, default=0, help="host threads of the streamed leg (0 = up to 16)")
     ap.add_argument("--streams", type=int, default=1,
                     help="the rank's windows are split into this many batches on separate HIP streams, so that the "
@@ -724,7 +775,7 @@ def main():
             resident_params = {i: batches[where[i][0]].parameters(where[i][1]) for i in range(B)} if B <= 4096 else {}
             try:
                 out["streamed"] = streamed_block(windows, local_rank, out["value"], resident_params, batches_timed=args.stream_batches,
-                                                 host_threads=args.host_threads, chunks_per_window=args.chunks, lba_elimination=args.elim,
+                                                 host_threads=args.host_threads, depth=args.stream_depth, chunks_per_window=args.chunks, lba_elimination=args.elim,
                                                  lba_keep_jacobian=args.keep_jacobian)
             except capi.SlslamError as e:
                 out["streamed"] = {"error": str(e)}
@@ -732,6 +783,11 @@ def main():
             for bt in batches:           # release HBM before the extra measurements
                 bt.close()
             batches = []
+            try:
+                out["mixed_precision"] = mixed_precision_block(windows, counts, local_rank, out["value"])
+                out["mixed_precision"]["sum_final_cost_double_path"] = final_cost
+            except capi.SlslamError as e:
+                out["mixed_precision"] = {"error": str(e)}
             # BASELINE configs[1]: 10-keyframe / 500-line window
             nb = min(B, 512)
             w500 = [synth.make_window(2_000_000 + i, num_lines=500) for i in range(nb)]

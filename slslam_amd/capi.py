@@ -393,7 +393,10 @@ class LBAStream:
         return t.value
 
     def collect(self, ticket, want_summaries=True):
-        ws = self._live.pop(ticket)
+        ws = self._live.pop(ticket, None)
+        if ws is None:                                   # not a ticket in flight: the library says so
+            _check(lib().slslam_lba_stream_collect(self._h, int(ticket), None), "slslam_lba_stream_collect")
+            raise SlslamError(5, "slslam_lba_stream_collect")
         sm = (Summary * max(len(ws), 1))() if want_summaries else None
         _check(lib().slslam_lba_stream_collect(self._h, int(ticket), sm), "slslam_lba_stream_collect")
         return [_summary_dict(sm[i]) for i in range(len(ws))] if want_summaries else None

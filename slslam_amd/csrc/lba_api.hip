@@ -254,6 +254,7 @@ struct slslam_lba_batch {
   bool results_pending = false;
   HostPool* ext_pool = nullptr;              // host threads lent by a stream object; else own_pool, made on demand
   std::unique_ptr<HostPool> own_pool;
+  std::vector<PackedWindow> wins_spare;      // what a refill packs into; swapped with `wins` when the refill is accepted
   std::vector<int> h_ob_orig_off;          // per window offset into d_ob_orig
   bool downloaded = false;
   // device
@@ -263,6 +264,7 @@ struct slslam_lba_batch {
   DevBuf<uint32_t> d_line_desc;
   DevBuf<unsigned long long> d_dbg_cycles;
   int elim_mode = 0, elim_waves = 1;     // see BatchPtrs
+  bool elim_mixed = false;               // ... its steady sweeps in mixed precision (lba_precision = 1: k_eliminate_grouped<false, false, true>)
   bool elim_grouped = false;             // elim_mode 1 with group-local accumulators (lba_eliminate_grouped.h); the windows are packed with grouping = 1
   size_t lds_elim = 0;
   DevBuf<unsigned long long> d_iter_counter;
@@ -706,8 +708,14 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   {
     bool mfma_ok = !b->opt.reuse_elimination && b->opt.max_num_iterations > 0 && B > 0;
     for (const PackedWindow& P : b->wins) if (P.Cf > kMfmaMaxFree || P.dup_free_obs) mfma_ok = false;
-    const int want = b->opt.lba_elimination;
-    if (want < 0 || want > 4) return SLSLAM_ERR_INVALID_ARGUMENT;
+    int want = b->opt.lba_elimination;
+    if (want < 0 || want > 4 || b->opt.lba_precision < 0 || b->opt.lba_precision > 1) return SLSLAM_ERR_INVALID_ARGUMENT;
+    // mixed precision lives in the grouped matrix-core sweep: asked for, it is that sweep or nothing
+    b->elim_mixed = b->opt.lba_precision == 1;
+    if (b->elim_mixed) {
+      if (want == 0) want = 4;
+      if (want != 4 || b->opt.reuse_elimination || b->opt.max_num_iterations <= 0) return SLSLAM_ERR_UNSUPPORTED;
+    }
     // automatic = the LDS-atomic sweep: the matrix-core sweep measures slower on MI355X - not because of the matrix pipe (a wave
     // issues a v_mfma_f64_16x16x4_f64 every 64 cycles, tools/micro/mfma_f64_bench.hip) but because of its operand path through
     // LDS and its front end
@@ -716,6 +724,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     for (const PackedWindow& P : b->wins) if (P.big) { b->big_mode = true; ++nbig; }
     if (nbig > 0 && nbig < B && !b->opt.reuse_elimination) return finalize_mixed(b);       // oversize windows apart (see `part`)
     if (b->big_mode) { mfma_ok = false; if (b->opt.reuse_elimination) return SLSLAM_ERR_UNSUPPORTED; }
+    if (b->elim_mixed && !mfma_ok) return SLSLAM_ERR_UNSUPPORTED;
     // automatic (0): the grouped matrix-core sweep (lba_eliminate_grouped.h) for a batch that fills the chip with long chunks -
     // there it measures faster than the LDS-atomic sweep (1.20 against 1.27 ms per launch on the 1024 x 2000-line batch, DESIGN.md
     // section 7d); a small batch cuts its windows into chunks of a tile or two, for which the grouped sweep's per-chunk work
@@ -728,7 +737,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     b->elim_mode = ((want >= 2 || auto_grouped) && mfma_ok) ? 1 : 0;
     b->elim_waves = b->elim_mode == 0 ? 1 : (want == 3 ? 2 : 1);
     b->elim_grouped = b->elim_mode == 1 && (want == 4 || auto_grouped);
-    b->pol.keep_jacobian = (b->elim_grouped && b->opt.lba_keep_jacobian && b->opt.max_num_iterations > 1) ? 1 : 0;
+    b->pol.keep_jacobian = (b->elim_grouped && !b->elim_mixed && b->opt.lba_keep_jacobian && b->opt.max_num_iterations > 1) ? 1 : 0;
     {
       // the grouped sweep wants the lines of a window in the order of their first free camera: pack again (the default packing
       // deals rows to the tiles by pair-item count, which this sweep has no use for).  Both directions: a batch whose finalize failed
@@ -1022,6 +1031,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_grouped<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_grouped<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
     HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_grouped<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_eliminate_grouped<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_elim));
   }
   if (b->lds_solve > 48 * 1024 && !b->big_mode) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_reduced_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_solve));
@@ -1193,6 +1203,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     if (!capturing && ((it + 1) % 16) == 0) HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
     if (b->nchunk > 0) {
       if (b->elim_grouped && it == 0) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_eliminate_grouped<true>, g_chunk, blk64, b->lds_elim, s, p, pol));
+      else if (b->elim_grouped && b->elim_mixed) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_grouped<false, false, true>), g_chunk, blk64, b->lds_elim, s, p, pol));
       else if (b->elim_grouped && pol.keep_jacobian) LAUNCH(FAM_LIN, hipLaunchKernelGGL((k_eliminate_grouped<false, true>), g_chunk, blk64, b->lds_elim, s, p, pol));
       else if (b->elim_grouped) LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_eliminate_grouped<false>, g_chunk, blk64, b->lds_elim, s, p, pol));
       else if (b->elim_mode == 1 && pol.debug_flags) {          // timing experiments (SLSLAM_DEBUG_ABLATE)
@@ -1385,8 +1396,11 @@ extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_win
   if (n != B) return SLSLAM_ERR_UNSUPPORTED;              // the launches of the captured solve were made for this many windows
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
+  static const bool timing = std::getenv("SLSLAM_REFILL_TIMING") != nullptr;      // host-side split of a refill on stderr
+  const auto tt0 = std::chrono::steady_clock::now();
   if (b->ev_stage_free) HIP_TRY(hipEventSynchronize(b->ev_stage_free));      // the host image may still feed the previous refill's copies
   if (b->results_pending) { HIP_TRY(hipEventSynchronize(b->ev_results)); b->results_pending = false; }
+  const auto tt1 = std::chrono::steady_clock::now();
   // ---- pack (the LBAProblem::build stage, one window per host thread), the observations straight into the host image: where a window's
   // observations go only depends on the counts before it
   std::vector<long long> obs_off((size_t)B + 1, 0);
@@ -1397,7 +1411,8 @@ extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_win
   const HostImage img = host_image(b);
   if (obs_off[(size_t)B] > img.ob_stride) return SLSLAM_ERR_UNSUPPORTED;
   const int grouping = b->elim_grouped ? 1 : 0;
-  std::vector<PackedWindow> wins((size_t)B);
+  std::vector<PackedWindow>& wins = b->wins_spare;      // (the windows of the refill before last: their vectors are reused)
+  wins.resize((size_t)B);
   std::vector<int> st((size_t)B, SLSLAM_OK);
   HostPool* pool = batch_pool(b, (int)std::min<long long>(B, b->opt.host_threads > 0 ? b->opt.host_threads : (B >= 64 ? 8 : 1)));
   auto pack_one = [&](int i) {
@@ -1407,6 +1422,7 @@ extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_win
   };
   if (pool) pool->run(B, pack_one); else for (int i = 0; i < B; ++i) pack_one(i);
   for (int r : st) if (r != SLSLAM_OK) return r;
+  const auto tt2 = std::chrono::steady_clock::now();
   for (const PackedWindow& P : wins) {
     if (P.big) return SLSLAM_ERR_UNSUPPORTED;                                        // (would take the global-memory path)
     if (b->elim_mode == 1 && (P.Cf > kMfmaMaxFree || P.dup_free_obs)) return SLSLAM_ERR_UNSUPPORTED;   // (the batch's sweep cannot take it)
@@ -1442,6 +1458,7 @@ extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_win
   auto fill_one = [&](int wi) { fill_window(b, plan, b->wins, wi, img, /*copy_observations=*/false); };
   if (pool) pool->run(B, fill_one); else for (int wi = 0; wi < B; ++wi) fill_one(wi);
   fill_tail(b, plan, img);
+  const auto tt3 = std::chrono::steady_clock::now();
   // ---- upload what is used of every array, asynchronously from the pinned image
   const DeviceArena& ar = b->arena;
 #define SLS_UP(buf, count) do { const size_t nb_ = (size_t)(count) * sizeof(*(buf).p); \
@@ -1463,7 +1480,13 @@ extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_win
   HIP_TRY(hipMemsetAsync(b->d_cam_tab.p, 0, b->d_cam_tab.n * sizeof(double), s));
   if (b->slab_sum_image) HIP_TRY(hipMemsetAsync(b->d_slab_sum.p, 0, b->d_slab_sum.n * sizeof(double), s));
   HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
-  return device_init_after_upload(b, s);
+  rc = device_init_after_upload(b, s);
+  if (timing) {
+    const auto tt4 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+    std::fprintf(stderr, "slslam refill: wait %.2f  pack %.2f  plan+fill %.2f  enqueue %.2f ms  (%d windows, %d threads)\n", ms(tt0, tt1), ms(tt1, tt2), ms(tt2, tt3), ms(tt3, tt4), B, pool ? pool->threads() : 1);
+  }
+  return rc;
 }
 
 extern "C" int slslam_lba_batch_get_parameters(const slslam_lba_batch* b, int index, double* parameters) {

@@ -74,9 +74,15 @@ __device__ __forceinline__ void grouped_flush_tile(double* slab, const solve_acc
 // later launch is fresh); the compile-time form keeps the first sweep's extras out of the steady sweep's registers.
 // KEEP (lba_keep_jacobian, off by default - measured slower): the linearising sweep leaves its J blocks in memory
 // and the sweep after a rejected step replays them (second loop below); the plain instantiation carries none of it.
-template <bool FRESH, bool KEEP = false>
+// MIXED (slslam_solver_options.lba_precision = 1, steady sweeps only): the row gradients, both Jacobians and the per-observation block
+// products (J_l^T J_l, J_l^T r, J_c'^T J_l, J_c'^T J_c', J_c'^T r: sums of four terms) in float, converted to double where they are
+// ACCUMULATED - the segmented sums over a line's observations, the camera records, the F rows that feed the matrix cores; the
+// geometry, residuals, costs, the 4 x 4 factor and everything downstream stay double (lba_math.h::obs_linearise_raw_mixed).
+template <bool FRESH, bool KEEP = false, bool MIXED = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_eliminate_grouped(BatchPtrs p, Policy pol) {
+  static_assert(!(MIXED && (FRESH || KEEP)), "the mixed-precision form exists for the plain steady sweep only");
+  using JT = typename std::conditional<MIXED, float, double>::type;      // what Jacobian entries and their four-term products are held in
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   SLS_K1_STAMP_INIT;
@@ -306,7 +312,8 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
       // parked in the lane's own slab of the F panel (free until this tile's F rows are written) and come back when the
       // linearisation's operands are dead: the register peak of the sweep is here, and the group's accumulators sit on top of it
       SLS_PHASE("linearise");
-      double rs[4], Jl[16];
+      double rs[4];
+      JT Jl[16];
       double* slabF = panel + lane * kGpSlab;
       {
         const double* ct = camtab + pf.cam * kCamTabG;
@@ -316,11 +323,19 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
         tt[0] = ct[9]; tt[1] = ct[10]; tt[2] = ct[11];
 #pragma unroll
         for (int a = 0; a < 4; ++a) sl[a] = fresh ? 1.0 : pf.lsc[a];
-        obs_linearise_raw<double>(R, tt, pf.trig, sl, pf.ob, pol.baseline, pol.huber_delta, rs, Jl, &cost,
-          [&](int row, const double (&jc)[6]) {
-            double2* dst = reinterpret_cast<double2*>(slabF + 6 * row);
-            dst[0] = make_double2(jc[0], jc[1]); dst[1] = make_double2(jc[2], jc[3]); dst[2] = make_double2(jc[4], jc[5]);
-          });
+        if constexpr (MIXED) {
+          obs_linearise_raw_mixed(R, tt, pf.trig, sl, pf.ob, pol.baseline, pol.huber_delta, rs, Jl, &cost,
+            [&](int row, const float (&jc)[6]) {
+              float2* dst = reinterpret_cast<float2*>(slabF) + 3 * row;
+              dst[0] = make_float2(jc[0], jc[1]); dst[1] = make_float2(jc[2], jc[3]); dst[2] = make_float2(jc[4], jc[5]);
+            });
+        } else {
+          obs_linearise_raw<double>(R, tt, pf.trig, sl, pf.ob, pol.baseline, pol.huber_delta, rs, Jl, &cost,
+            [&](int row, const double (&jc)[6]) {
+              double2* dst = reinterpret_cast<double2*>(slabF + 6 * row);
+              dst[0] = make_double2(jc[0], jc[1]); dst[1] = make_double2(jc[2], jc[3]); dst[2] = make_double2(jc[4], jc[5]);
+            });
+        }
         if (kept) acc_cost += cost;
         if (fresh && valid && !kept) acc_fixed += cost;
       }
@@ -347,17 +362,20 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int b = 0; b <= a; ++b) {
-            double h = 0.0;
+            JT h = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) h += Jl[4 * r + a] * Jl[4 * r + b];
-            v[q++] = h;
+            v[q++] = (double)h;
           }
+        JT rsj[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rsj[r] = (JT)rs[r];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          double ga = 0.0;
+          JT ga = 0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ga += Jl[4 * r + a] * rs[r];
-          v[10 + a] = ga;
+          for (int r = 0; r < 4; ++r) ga += Jl[4 * r + a] * rsj[r];
+          v[10 + a] = (double)ga;
         }
         // (the run totals come back through ds_bpermute: this sweep's LDS pipe is lightly loaded - unlike the LDS-atomic sweep's, which
         // moves them on the VALU - and 28 of them are cheaper than four rounds of 28 selects; measured 1.235 -> 1.224 ms)
@@ -441,23 +459,32 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
       SLS_K1_STAMP(3);
       SLS_PHASE("f_rows");
       {
-        double Jc[24];
+        JT Jc[24];
         double2* hkeep = reinterpret_cast<double2*>(p.fstore) + ((long long)t * (12 * 64) + lane);
+        if constexpr (MIXED) {
 #pragma unroll
-        for (int q = 0; q < 12; ++q) { const double2 v2 = reinterpret_cast<const double2*>(slabF)[q]; Jc[2 * q] = v2.x; Jc[2 * q + 1] = v2.y; }
+          for (int q = 0; q < 12; ++q) { const float2 v2 = reinterpret_cast<const float2*>(slabF)[q]; Jc[2 * q] = v2.x; Jc[2 * q + 1] = v2.y; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 12; ++q) { const double2 v2 = reinterpret_cast<const double2*>(slabF)[q]; Jc[2 * q] = v2.x; Jc[2 * q + 1] = v2.y; }
+        }
+        JT rsj[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rsj[r] = (JT)rs[r];
         double* rec = diag + (cam_free ? cf : 0) * kDiagRec;
         // (no skewed adds here - the packer's flag for lanes of a row that share a camera, see the diagonal block of
         // k_linearise_schur: with a third of that sweep's LDS atomics left it measures neutral, 1.224 / 1.222 ms)
         auto emit = [&](int off, double val) { if (cam_free) lds_add_rec(rec + off, val); };
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-          double ga = 0.0, h[4] = { 0.0, 0.0, 0.0, 0.0 };
+          JT gaj = 0, hj[4] = { 0, 0, 0, 0 };
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            ga += Jc[6 * r + a] * rs[r];
+            gaj += Jc[6 * r + a] * rsj[r];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) h[b] += Jc[6 * r + a] * Jl[4 * r + b];
+            for (int b = 0; b < 4; ++b) hj[b] += Jc[6 * r + a] * Jl[4 * r + b];
           }
+          const double ga = (double)gaj, h[4] = { (double)hj[0], (double)hj[1], (double)hj[2], (double)hj[3] };
           const double f0 = h[0] * K[0];
           const double f1 = h[0] * K[1] + h[1] * K[2];
           const double f2 = h[0] * K[3] + h[1] * K[4] + h[2] * K[5];
@@ -474,10 +501,10 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
             emit(kDiagG + a, ga);
 #pragma unroll
             for (int b = 0; b <= a; ++b) {
-              double v = 0.0;
+              JT v = 0;
 #pragma unroll
               for (int r = 0; r < 4; ++r) v += Jc[6 * r + a] * Jc[6 * r + b];
-              emit(tri_index(a, b), v);
+              emit(tri_index(a, b), (double)v);
             }
           }
         }

@@ -30,10 +30,13 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
     return SLSLAM_ERR_INVALID_ARGUMENT;
   if ((C > 0 || L > 0) && !w->parameters) return SLSLAM_ERR_INVALID_ARGUMENT;
   PackedWindow& P = *out;
-  P = PackedWindow();
+  // (the vectors of `out` keep their capacity: a batch that is refilled packs into the windows of the refill before last)
+  P.Cf = 0; P.nfree_params = 0; P.nkept = 0; P.big = false; P.dup_free_obs = false;
+  P.tiles.clear(); P.lane_map.clear(); P.items.clear(); P.ob.clear();
   P.C = C; P.L = L; P.M = M; P.grouping = grouping ? 1 : 0;
   P.params0.assign(w->parameters, w->parameters + (size_t)6 * C + (size_t)4 * L);
-  if (!all_finite(P.params0.data(), P.params0.size()) || (M > 0 && !all_finite(w->observations, (size_t)8 * M))) return SLSLAM_ERR_INVALID_ARGUMENT;
+  // (the observations are tested where they are read anyway, in the gather below: one pass over them instead of two)
+  if (!all_finite(P.params0.data(), P.params0.size())) return SLSLAM_ERR_INVALID_ARGUMENT;
 
   // block constness: one flagged observation makes the block constant (lba_problem.cpp:88-91)
   std::vector<char> cam_const(C, 0), cam_used(C, 0), line_const(L, 0);
@@ -84,26 +87,28 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
   if (!P.big) {
     std::vector<int> by_len[17];
     bool carry_open = false;                         // grouping: the open rows survive from one call to the next
-    std::vector<int> open_keep[17];
+    struct OpenRow { int row; unsigned mask; };      // an open row with the free cameras of its lines (beside the id: the search below reads nothing else)
+    std::vector<OpenRow> open_keep[17];
     auto pack_rows = [&](int len_lo, int len_hi) {
       const int first = (int)rows.size();
-      std::vector<int> open_local[17];
-      std::vector<int>* open_by_room = carry_open ? open_keep : open_local;
+      std::vector<OpenRow> open_local[17];
+      std::vector<OpenRow>* open_by_room = carry_open ? open_keep : open_local;
       for (int len = len_hi; len >= len_lo; --len)
         for (int l : by_len[len]) {
           // the fullest open row that holds the line - and, among the rows of that fill, preferably one none of whose
           // lines shares a free camera with it: the lanes of one 16-lane row that add to the same camera record
           // serialise in the LDS (tools/micro/lds_atomic_bench.hip)
           int r = -1;
+          const unsigned fm = fmask[l];
           for (int pass = 0; pass < 2 && r < 0; ++pass)          // pass 0: rows without a common free camera only
             for (int room = len; room <= 16 && r < 0; ++room) {
-              std::vector<int>& cand = open_by_room[room];
+              std::vector<OpenRow>& cand = open_by_room[room];
               for (size_t c = cand.size(); c-- > 0 && cand.size() - c <= 32;)
-                if (pass == 1 || !(rows[cand[c]].mask & fmask[l])) { r = cand[c]; cand.erase(cand.begin() + c); break; }
+                if (pass == 1 || !(cand[c].mask & fm)) { r = cand[c].row; cand.erase(cand.begin() + c); break; }
             }
           if (r < 0) { r = (int)rows.size(); rows.push_back(Row{0, 0, -1, -1, 0u}); }
           append(r, l);
-          if (rows[r].used < 16) open_by_room[16 - rows[r].used].push_back(r);
+          if (rows[r].used < 16) open_by_room[16 - rows[r].used].push_back(OpenRow{ r, rows[r].mask });
         }
       return std::make_pair(first, (int)rows.size());
     };
@@ -138,26 +143,29 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
       // back-substitution's sin/cos rounds), each of them group after group, the rows filling the tiles in that order
       std::vector<int> lens[2][17];
       for (int len = 1; len <= 16; ++len) { lens[len < 4 ? 1 : 0][len].swap(by_len[len]); }
+      std::vector<int> key_of((size_t)L);
+      for (int l = 0; l < L; ++l) key_of[(size_t)l] = group_key(l);
       for (int cls = 0; cls < 2; ++cls) {
-        std::vector<int> keys;
-        for (int len = 1; len <= 16; ++len) for (int l : lens[cls][len]) keys.push_back(group_key(l));
-        std::sort(keys.begin(), keys.end());
-        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        // keys are 2 a + {0, 1} with a < 20, or 1000 (no elimination work): 42 buckets, each with its lines by length in their original order
+        enum { kBuckets = 42 };
+        auto bucket_of = [](int key) { return key >= 1000 ? kBuckets - 1 : key; };
+        std::vector<int> bucket[kBuckets][17];
+        bool present[kBuckets] = {};
+        for (int len = 1; len <= 16; ++len)
+          for (int l : lens[cls][len]) { const int bq = bucket_of(key_of[(size_t)l]); bucket[bq][len].push_back(l); present[bq] = true; }
         const size_t first_row = tile_rows.size();
         const int row0 = (int)rows.size();
         carry_open = true;                             // a group's lines may finish the open rows of the group before it
         for (int q = 0; q <= 16; ++q) open_keep[q].clear();
         int prev_first = row0;                         // first row the previous group opened
-        for (int key : keys) {
-          for (int len = 1; len <= 16; ++len) {
-            by_len[len].clear();
-            for (int l : lens[cls][len]) if (group_key(l) == key) by_len[len].push_back(l);
-          }
+        for (int bq = 0; bq < kBuckets; ++bq) {        // ascending keys
+          if (!present[bq]) continue;
+          for (int len = 1; len <= 16; ++len) by_len[len].swap(bucket[bq][len]);
           // (only the rows the previous group left open: an older row would put this group's line in the middle of another
           // group's tiles, and the sweep adds its accumulators to memory whenever the group changes)
           for (int q = 0; q <= 16; ++q) {
-            std::vector<int>& v = open_keep[q];
-            v.erase(std::remove_if(v.begin(), v.end(), [&](int r) { return r < prev_first; }), v.end());
+            std::vector<OpenRow>& v = open_keep[q];
+            v.erase(std::remove_if(v.begin(), v.end(), [&](const OpenRow& r) { return r.row < prev_first; }), v.end());
           }
           prev_first = (int)rows.size();
           pack_rows(1, 16);
@@ -168,9 +176,9 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
           // seam between the two groups
           std::vector<int> order((int)rows.size() - row0);
           std::iota(order.begin(), order.end(), row0);
-          auto mixed = [&](int r) { const int k0 = group_key(rows[r].head); for (int l = rows[r].head; l >= 0; l = next[l]) if (group_key(l) != k0) return 1; return 0; };
+          auto mixed = [&](int r) { const int k0 = key_of[(size_t)rows[r].head]; for (int l = rows[r].head; l >= 0; l = next[l]) if (key_of[(size_t)l] != k0) return 1; return 0; };
           std::vector<int> rk(rows.size(), 0);
-          for (int r : order) rk[r] = group_key(rows[r].head) * 2 + mixed(r);
+          for (int r : order) rk[r] = key_of[(size_t)rows[r].head] * 2 + mixed(r);
           std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rk[x] < rk[y]; });
           for (int r : order) tile_rows.push_back(r);
         }
@@ -231,7 +239,9 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
       const int s = line_pos[w->line_index[i]];
       P.ob_orig[P.line_ptr[s] + fill[s]++] = i;
     }
-    auto key = [&](int i) { const int c = w->camera_index[i]; return P.cam_cf[c] >= 0 ? P.cam_cf[c] : P.Cf + c; };
+    std::vector<int> cam_key((size_t)C);           // free cameras first (ascending free index), then the others by id
+    for (int c = 0; c < C; ++c) cam_key[(size_t)c] = P.cam_cf[c] >= 0 ? P.cam_cf[c] : P.Cf + c;
+    auto key = [&](int i) { return cam_key[(size_t)w->camera_index[i]]; };
     for (int s = 0; s < L; ++s) {                  // stable insertion sort of the (at most 64) observations of a line
       int* o = P.ob_orig.data() + P.line_ptr[s];
       const int k = P.line_ptr[s + 1] - P.line_ptr[s];
@@ -249,13 +259,20 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
   {
     double* pl[4] = { P.ob.data(), P.ob.data() + 2 * (size_t)M, P.ob.data() + 4 * (size_t)M, P.ob.data() + 6 * (size_t)M };
     if (ob_dest) for (int q = 0; q < 4; ++q) pl[q] = ob_dest->plane[q];
+    uint64_t nonfinite = 0;
     for (int o = 0; o < M; ++o) {
       const int i = P.ob_orig[o];
       P.ob_cam[o] = w->camera_index[i];
       const double* src = w->observations + 8 * (size_t)i;
       for (int q = 0; q < 4; ++q) { pl[q][2 * (size_t)o] = src[2 * q]; pl[q][2 * (size_t)o + 1] = src[2 * q + 1]; }
+      for (int q = 0; q < 8; ++q) {               // exponent field all ones <=> NaN / Inf (branch-free, as all_finite)
+        uint64_t x;
+        std::memcpy(&x, src + q, 8);
+        nonfinite |= ((x & 0x7ff0000000000000ull) + 0x0010000000000000ull) & 0x8000000000000000ull;
+      }
       if (!(cam_const[w->camera_index[i]] && line_const[w->line_index[i]])) ++P.nkept;
     }
+    if (nonfinite) return SLSLAM_ERR_INVALID_ARGUMENT;
   }
 
   // tiles, their lane maps and their off-diagonal camera-pair work items
@@ -263,8 +280,9 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
   if (!P.big) {
     int s = 0;
     P.tiles.reserve(tile_ptr.size());
+    // (the grouped matrix-core sweep has no pair phase: a window packed for it carries no work items)
     size_t items_total = 0;
-    for (int l = 0; l < L; ++l) items_total += (size_t)items_of(l);
+    for (int l = 0; l < L && !grouping; ++l) items_total += (size_t)items_of(l);
     P.items.resize(2 * items_total);
     uint8_t* item_w = P.items.data();                         // the items are written through a cursor (sized exactly above)
     P.lane_map.reserve(64 * tile_ptr.size());
@@ -292,7 +310,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
           min_lanes = std::min(min_lanes, run);
           max_run = std::max(max_run, std::min(run, 16));
           if (run > 16) multi = 1;
-          if (!(P.line_flags[s] & 1)) {
+          if (!(P.line_flags[s] & 1) && !grouping) {
             int kf = 0;                                      // free-camera observations come first
             while (kf < k && P.cam_cf[P.ob_cam[P.line_ptr[s] + kf]] >= 0) ++kf;
             for (int i = 0; i < kf; ++i)

@@ -1,0 +1,156 @@
+// slslam_amd/dist_c/dist_api.cpp — include/slslam_dist.h: the LBA fan-out over the GPUs of a node, one process per GPU, RCCL over xGMI.
+// Host C++ on the C ABI of libslslam_hip.so + two collectives; compiled with hipcc (host code only) against librccl.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/slslam_dist.h"
+
+static_assert(sizeof(ncclUniqueId) == SLSLAM_DIST_ID_BYTES, "ncclUniqueId size");
+
+#define DIST_HIP(expr)                                                                        \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      std::fprintf(stderr, "slslam_dist: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? SLSLAM_ERR_NO_DEVICE : SLSLAM_ERR_HIP; \
+    }                                                                                         \
+  } while (0)
+#define DIST_NCCL(expr)                                                                       \
+  do {                                                                                        \
+    ncclResult_t r_ = (expr);                                                                 \
+    if (r_ != ncclSuccess) {                                                                  \
+      std::fprintf(stderr, "slslam_dist: %s failed: %s (%s:%d)\n", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+      return SLSLAM_ERR_HIP;                                                                  \
+    }                                                                                         \
+  } while (0)
+
+struct slslam_dist {
+  int rank = 0, world = 1, device = 0;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  double* d_sums = nullptr;          // [3]
+  double* d_local = nullptr;         // this rank's parameters, `slot` doubles
+  double* d_all = nullptr;           // world * slot
+  long long* d_counts = nullptr;     // [world + 1]: all-gathered counts | this rank's count
+  long long slot = 0;
+};
+
+extern "C" int slslam_dist_unique_id(unsigned char id[SLSLAM_DIST_ID_BYTES]) {
+  if (!id) return SLSLAM_ERR_INVALID_ARGUMENT;
+  ncclUniqueId u;
+  DIST_NCCL(ncclGetUniqueId(&u));
+  std::memcpy(id, &u, sizeof(u));
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_dist_create(int rank, int world, int device, const unsigned char id[SLSLAM_DIST_ID_BYTES], slslam_dist** out) {
+  if (!out || !id || world < 1 || rank < 0 || rank >= world) return SLSLAM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SLSLAM_ERR_NO_DEVICE;
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return SLSLAM_ERR_NO_DEVICE; }
+  if (device >= ndev) return SLSLAM_ERR_INVALID_ARGUMENT;
+  DIST_HIP(hipSetDevice(device));
+  slslam_dist* d = new (std::nothrow) slslam_dist();
+  if (!d) return SLSLAM_ERR_HIP;
+  d->rank = rank; d->world = world; d->device = device;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  ncclResult_t r = ncclCommInitRank(&d->comm, world, u, rank);
+  if (r != ncclSuccess) { std::fprintf(stderr, "slslam_dist: ncclCommInitRank failed: %s\n", ncclGetErrorString(r)); delete d; return SLSLAM_ERR_HIP; }
+  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&d->d_sums, 3 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&d->d_counts, (size_t)(world + 1) * sizeof(long long)) != hipSuccess) {
+    slslam_dist_destroy(d);
+    return SLSLAM_ERR_HIP;
+  }
+  *out = d;
+  return SLSLAM_OK;
+}
+
+extern "C" void slslam_dist_destroy(slslam_dist* d) {
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  if (d->comm) (void)ncclCommDestroy(d->comm);
+  if (d->d_sums) (void)hipFree(d->d_sums);
+  if (d->d_local) (void)hipFree(d->d_local);
+  if (d->d_all) (void)hipFree(d->d_all);
+  if (d->d_counts) (void)hipFree(d->d_counts);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+
+extern "C" int slslam_dist_rank(const slslam_dist* d) { return d ? d->rank : -1; }
+extern "C" int slslam_dist_world(const slslam_dist* d) { return d ? d->world : 0; }
+
+extern "C" void slslam_dist_shard_range(long long n, int rank, int world, long long* lo, long long* hi) {
+  if (world < 1) world = 1;
+  const long long base = n / world, rem = n % world;            // the first `rem` ranks hold one window more (slslam_amd/dist.py::shard_range)
+  const long long a = rank * base + (rank < rem ? rank : rem);
+  if (lo) *lo = a;
+  if (hi) *hi = a + base + (rank < rem ? 1 : 0);
+}
+
+extern "C" int slslam_dist_solve(slslam_dist* d, const slslam_lba_window* w, int n, const slslam_solver_options* opt,
+                                 double sums[3], double* gathered, long long slot, long long* count_per_rank) {
+  if (!d || n < 0 || (n > 0 && !w) || !sums) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (gathered && slot <= 0) return SLSLAM_ERR_INVALID_ARGUMENT;
+  DIST_HIP(hipSetDevice(d->device));
+  // ---- this rank's shard: one batch, no collective on the data path
+  double local[3] = { 0.0, 0.0, 0.0 };
+  long long my_count = 0;
+  slslam_lba_batch* b = nullptr;
+  int rc = SLSLAM_OK;
+  if (n > 0) {
+    if ((rc = slslam_lba_batch_create(d->device, &b)) != SLSLAM_OK) return rc;
+    for (int i = 0; i < n && rc == SLSLAM_OK; ++i) { rc = slslam_lba_batch_add(b, &w[i], nullptr); my_count += 6LL * w[i].num_cameras + 4LL * w[i].num_lines; }
+    if (rc == SLSLAM_OK) rc = slslam_lba_batch_finalize(b, opt);
+    if (rc == SLSLAM_OK) rc = slslam_lba_batch_solve(b, (void*)d->stream);
+  }
+  // (a rank whose shard failed still takes part in the collectives - with zeros - so that the others do not hang; it reports its error)
+  if (gathered) {
+    if (my_count > slot) rc = rc == SLSLAM_OK ? SLSLAM_ERR_INVALID_ARGUMENT : rc;
+    if (d->slot < slot) {
+      if (d->d_local) (void)hipFree(d->d_local);
+      if (d->d_all) (void)hipFree(d->d_all);
+      d->d_local = d->d_all = nullptr;
+      DIST_HIP(hipMalloc((void**)&d->d_local, (size_t)slot * sizeof(double)));
+      DIST_HIP(hipMalloc((void**)&d->d_all, (size_t)slot * (size_t)d->world * sizeof(double)));
+      d->slot = slot;
+    }
+    DIST_HIP(hipMemsetAsync(d->d_local, 0, (size_t)slot * sizeof(double), d->stream));
+    if (b && rc == SLSLAM_OK) rc = slslam_lba_batch_export_device(b, d->d_local, (void*)d->stream);      // straight from the parameter buffers: no host round trip
+  }
+  if (b && rc == SLSLAM_OK) {
+    rc = slslam_lba_batch_download(b, (void*)d->stream);
+    for (int i = 0; i < n && rc == SLSLAM_OK; ++i) {
+      slslam_summary s;
+      rc = slslam_lba_batch_get_parameters(b, i, w[i].parameters);
+      if (rc == SLSLAM_OK) rc = slslam_lba_batch_get_summary(b, i, &s);
+      if (rc == SLSLAM_OK) { local[0] += s.num_successful_steps + s.num_unsuccessful_steps; local[1] += s.initial_cost; local[2] += s.final_cost; }
+    }
+  }
+  if (rc != SLSLAM_OK) { local[0] = local[1] = local[2] = 0.0; }
+  // ---- the ONE all-reduce of the run summary (reference src/slam.cpp:949-952) ...
+  DIST_HIP(hipMemcpyAsync(d->d_sums, local, sizeof(local), hipMemcpyHostToDevice, d->stream));
+  DIST_NCCL(ncclAllReduce(d->d_sums, d->d_sums, 3, ncclDouble, ncclSum, d->comm, d->stream));
+  DIST_HIP(hipMemcpyAsync(sums, d->d_sums, 3 * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+  // ---- ... and, when asked for, the ONE all-gather of the results (+ the counts, 8 bytes per rank)
+  if (gathered) {
+    const long long mine = rc == SLSLAM_OK ? my_count : 0;
+    DIST_HIP(hipMemcpyAsync(d->d_counts + d->world, &mine, sizeof(mine), hipMemcpyHostToDevice, d->stream));
+    DIST_NCCL(ncclAllGather(d->d_counts + d->world, d->d_counts, 1, ncclInt64, d->comm, d->stream));
+    DIST_NCCL(ncclAllGather(d->d_local, d->d_all, (size_t)slot, ncclDouble, d->comm, d->stream));
+    DIST_HIP(hipMemcpyAsync(gathered, d->d_all, (size_t)slot * (size_t)d->world * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    if (count_per_rank) DIST_HIP(hipMemcpyAsync(count_per_rank, d->d_counts, (size_t)d->world * sizeof(long long), hipMemcpyDeviceToHost, d->stream));
+  }
+  DIST_HIP(hipStreamSynchronize(d->stream));
+  if (b) slslam_lba_batch_destroy(b);
+  return rc;
+}

@@ -1,0 +1,92 @@
+// tests/host_cxx/dist_demo.cpp — the C-level fan-out (include/slslam_dist.h) as a C++ host would drive it: one process per GPU.
+//   dist_demo <rank> <world> <id_file> <windows.bin> <out.bin> [device]
+// rank 0 writes the communicator id to <id_file>, the other ranks wait for it (any launcher-side channel would do); every rank reads the
+// job's window list, solves its contiguous shard (slslam_dist_shard_range) in place and takes part in the one all-reduce + one
+// all-gather; rank 0 writes [sums(3) | slot | counts(world) | gathered(world * slot)] to <out.bin>.
+// What is fanned out is the reference's per-window call LBAProblem::build + ceres::Solve (src/slam.cpp:924-944); the sums are the ones
+// its caller accumulates at :949-952.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "slslam_dist.h"
+
+struct Win { std::vector<int> cam, line, fixed; std::vector<double> obs, par; slslam_lba_window c; };
+
+static void rd(FILE* f, void* p, size_t n) { if (n && fread(p, 1, n, f) != n) { std::fprintf(stderr, "short read\n"); std::exit(2); } }
+
+int main(int argc, char** argv) {
+  if (argc < 6) { std::fprintf(stderr, "usage: dist_demo rank world id_file windows.bin out.bin [device]\n"); return 2; }
+  const int rank = std::atoi(argv[1]), world = std::atoi(argv[2]);
+  const int device = argc > 6 ? std::atoi(argv[6]) : rank;
+  unsigned char id[SLSLAM_DIST_ID_BYTES];
+  if (rank == 0) {
+    int rc = slslam_dist_unique_id(id);
+    if (rc != SLSLAM_OK) { std::fprintf(stderr, "unique id: %s\n", slslam_status_string(rc)); return rc; }
+    std::string tmp = std::string(argv[3]) + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) return 2;
+    std::fclose(f);
+    std::rename(tmp.c_str(), argv[3]);                      // atomically: a waiting rank never reads half an id
+  } else {
+    FILE* f = nullptr;
+    for (int tries = 0; tries < 600 && !(f = std::fopen(argv[3], "rb")); ++tries) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    if (!f) { std::fprintf(stderr, "rank %d: no communicator id\n", rank); return 2; }
+    rd(f, id, sizeof(id));
+    std::fclose(f);
+  }
+  // the job's windows (every rank reads the list; only its shard is touched)
+  FILE* f = std::fopen(argv[4], "rb");
+  if (!f) return 2;
+  int K = 0;
+  rd(f, &K, sizeof(K));
+  std::vector<Win> wins((size_t)K);
+  long long max_params = 0;
+  for (Win& w : wins) {
+    int h[3];
+    rd(f, h, sizeof(h));
+    const size_t M = (size_t)h[2], np = (size_t)6 * h[0] + (size_t)4 * h[1];
+    w.cam.resize(M); w.line.resize(M); w.fixed.resize(2 * M); w.obs.resize(8 * M); w.par.resize(np);
+    rd(f, w.cam.data(), 4 * M); rd(f, w.line.data(), 4 * M); rd(f, w.fixed.data(), 8 * M); rd(f, w.obs.data(), 64 * M); rd(f, w.par.data(), 8 * np);
+    w.c.num_cameras = h[0]; w.c.num_lines = h[1]; w.c.num_observations = h[2];
+    w.c.camera_index = w.cam.data(); w.c.line_index = w.line.data(); w.c.fixed_index = w.fixed.data(); w.c.observations = w.obs.data(); w.c.parameters = w.par.data();
+  }
+  std::fclose(f);
+  slslam_dist* d = nullptr;
+  int rc = slslam_dist_create(rank, world, device, id, &d);
+  if (rc != SLSLAM_OK) { std::fprintf(stderr, "rank %d: create: %s\n", rank, slslam_status_string(rc)); return rc; }
+  long long lo = 0, hi = 0, slot = 1;
+  for (int r = 0; r < world; ++r) {                          // the bound every rank passes: the largest shard's parameter count
+    long long a, b, c = 0;
+    slslam_dist_shard_range(K, r, world, &a, &b);
+    for (long long i = a; i < b; ++i) c += (long long)wins[(size_t)i].par.size();
+    if (c > slot) slot = c;
+    (void)max_params;
+  }
+  slslam_dist_shard_range(K, rank, world, &lo, &hi);
+  std::vector<slslam_lba_window> mine;
+  for (long long i = lo; i < hi; ++i) mine.push_back(wins[(size_t)i].c);
+  slslam_solver_options opt;
+  slslam_default_options(&opt);
+  double sums[3] = { 0, 0, 0 };
+  std::vector<double> gathered((size_t)slot * (size_t)world, 0.0);
+  std::vector<long long> counts((size_t)world, 0);
+  rc = slslam_dist_solve(d, mine.data(), (int)mine.size(), &opt, sums, gathered.data(), slot, counts.data());
+  if (rc != SLSLAM_OK) std::fprintf(stderr, "rank %d: solve: %s\n", rank, slslam_status_string(rc));
+  std::printf("rank %d of %d: windows [%lld, %lld), job sums: %.0f LM iterations, cost %.9e -> %.9e\n", rank, world, lo, hi, sums[0], sums[1], sums[2]);
+  if (rank == 0 && rc == SLSLAM_OK) {
+    FILE* o = std::fopen(argv[5], "wb");
+    if (!o) return 2;
+    const double s = (double)slot;
+    fwrite(sums, 8, 3, o); fwrite(&s, 8, 1, o);
+    for (long long c : counts) { const double v = (double)c; fwrite(&v, 8, 1, o); }
+    fwrite(gathered.data(), 8, gathered.size(), o);
+    std::fclose(o);
+  }
+  slslam_dist_destroy(d);
+  return rc;
+}

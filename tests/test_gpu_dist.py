@@ -127,3 +127,59 @@ def test_bench_two_ranks_shared_gpu(hip):
     assert min(ids) == 0 and max(ids) >= windows and len(ids) == 2 * chk["checked_per_rank"]      # both shards: [0, 24) and [24, 48)
     assert chk["bitwise_equal_to_rank0_resolve"] is True, chk
     assert d["lm_iterations"] > 0 and d["value"] > 0
+
+
+def test_c_level_fan_out_through_rccl(tmp_path):
+    """include/slslam_dist.h: the fan-out a C++ host drives - libslslam_dist.so on libslslam_hip.so + librccl,
+    no Python, no torch - at world size 1 on the real device (RCCL refuses two ranks on one GPU and the box has one): communicator id
+    through a file, ncclCommInitRank, the shard solved as one batch, ONE ncclAllReduce of the three sums of reference src/slam.cpp:949-952,
+    ONE ncclAllGather of the solved parameters.  Results equal, to the byte, the same windows solved as a batch through the C ABI."""
+    from slslam_amd import capi, synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "slslam_amd", "dist_c")])
+    libdir = os.path.join(ROOT, "slslam_amd", "_lib")
+    demo = os.path.join(ROOT, "tests", "_build", "dist_demo")
+    os.makedirs(os.path.dirname(demo), exist_ok=True)
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", demo,
+                           os.path.join(ROOT, "tests", "host_cxx", "dist_demo.cpp"), "-L", libdir, "-lslslam_dist", "-lslslam_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    ws = [synth.make_window(700 + i, num_lines=n, num_kf=12, num_free=6) for i, n in enumerate(SIZES)]
+    with open(tmp_path / "wins.bin", "wb") as f:
+        np.array([len(ws)], dtype=np.int32).tofile(f)
+        for w in ws:
+            np.array([w["num_cameras"], w["num_lines"], len(w["camera_index"])], dtype=np.int32).tofile(f)
+            np.asarray(w["camera_index"], dtype=np.int32).tofile(f)
+            np.asarray(w["line_index"], dtype=np.int32).tofile(f)
+            np.asarray(w["fixed_index"], dtype=np.int32).tofile(f)
+            np.asarray(w["observations"], dtype=np.float64).tofile(f)
+            np.asarray(w["parameters"], dtype=np.float64).tofile(f)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([demo, "0", "1", str(tmp_path / "id.bin"), str(tmp_path / "wins.bin"), str(tmp_path / "out.bin"), "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = np.fromfile(tmp_path / "out.bin")
+    sums, slot, count = out[:3], int(out[3]), int(out[4])
+    gathered = out[5:5 + slot]
+    b = capi.LBABatch()
+    for w in ws:
+        b.add(w)
+    b.finalize()
+    b.solve(); b.download()
+    want = np.concatenate([b.parameters(i) for i in range(len(ws))])
+    summ = [b.summary(i) for i in range(len(ws))]
+    b.close()
+    assert count == want.size == slot
+    assert np.array_equal(gathered[:count], want)
+    assert sums[0] == sum(s["num_successful_steps"] + s["num_unsuccessful_steps"] for s in summ)
+    assert abs(sums[1] - sum(s["initial_cost"] for s in summ)) <= 1e-12 * sums[1]
+    assert abs(sums[2] - sum(s["final_cost"] for s in summ)) <= 1e-12 * sums[2]
+    # the shard rule is the Python layer's
+    import ctypes as C
+    from slslam_amd.dist import shard_range
+    L = C.CDLL(os.path.join(libdir, "libslslam_dist.so"))
+    L.slslam_dist_shard_range.argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.slslam_dist_shard_range.restype = None
+    for n, world in ((8192, 8), (10, 4), (3, 8), (0, 2), (1025, 3)):
+        for r in range(world):
+            lo, hi = C.c_longlong(), C.c_longlong()
+            L.slslam_dist_shard_range(n, r, world, C.byref(lo), C.byref(hi))
+            assert (lo.value, hi.value) == tuple(shard_range(n, r, world))

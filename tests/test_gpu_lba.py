@@ -546,6 +546,62 @@ def test_headline_path_matches_oracle(hip, oracle):
         assert np.array_equal(xs, got[i][0]) and ss == got[i][1]
 
 
+def test_mixed_precision_solves(hip, oracle):
+    """slslam_solver_options.lba_precision = 1 (VERDICT round 4, row *): the steady elimination sweeps form the row gradients, both
+    Jacobians and the four-term block products of an observation in float (packed fp32 on gfx950) and accumulate line blocks, reduced
+    camera system, gradients and costs in double; geometry, residuals, the candidate evaluation and the trust-region bookkeeping are the
+    double path's (reference arithmetic: src/lba_problem.h:46-118 on Jet<double>).  STATED TOLERANCE against the double path and against
+    the oracle, bench family (2000 / 500 / 150 lines) and a window of far lines: the same number of successful and unsuccessful steps,
+    final cost 1e-4 relative, camera poses 1e-4 (rad / m), line closest points 1e-3 m, every per-iteration cost 1e-4 relative.  Opt-in,
+    never the bench's `value`; asking for it where the grouped sweep cannot run is refused."""
+    ws = [synth.make_window(i, num_lines=n) for i, n in ((0, 2000), (1, 2000), (1234, 2000), (5, 500), (7, 500), (11, 150), (12, 150))]
+    ws.append(synth.make_window(75, num_lines=60, num_kf=24, num_free=10, mean_track=40.0))
+    worst = dict(final_cost=0.0, cam=0.0, cp=0.0, iter_cost=0.0)
+    same_decisions = 0
+    for w in ws:
+        x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+        xd, sd, td = hip.lba_solve(w, lba_elimination=4)
+        xm, sm, tm = hip.lba_solve(w, lba_precision=1)
+        nc = 6 * int(w["num_cameras"])
+        for ref_x, ref_s, ref_t in ((xd, sd, td), (x0, s0, t0)):
+            assert sm["num_successful_steps"] == ref_s["num_successful_steps"] and sm["num_unsuccessful_steps"] == ref_s["num_unsuccessful_steps"]
+            assert abs(sm["initial_cost"] - ref_s["initial_cost"]) <= 1e-12 * ref_s["initial_cost"]      # the first sweep is double
+            worst["final_cost"] = max(worst["final_cost"], abs(sm["final_cost"] - ref_s["final_cost"]) / ref_s["final_cost"])
+            worst["cam"] = max(worst["cam"], float(np.abs(xm[:nc] - ref_x[:nc]).max()))
+            cpm = np.array([synth.orth_to_av(u)[:3] for u in xm[nc:].reshape(-1, 4)])
+            cpr = np.array([synth.orth_to_av(u)[:3] for u in ref_x[nc:].reshape(-1, 4)])
+            near = np.linalg.norm(cpr, axis=1) < 10.0                # (SURVEY 8c: closest points at <= 10 m depth)
+            worst["cp"] = max(worst["cp"], float(np.abs(cpm - cpr)[near].max()))
+            assert len(tm) == len(ref_t)
+            for a, c in zip(ref_t, tm):
+                worst["iter_cost"] = max(worst["iter_cost"], abs(a["cost"] - c["cost"]) / abs(a["cost"]))
+        same_decisions += all(a["step_is_successful"] == c["step_is_successful"] for a, c in zip(td, tm))
+    print("mixed precision vs double / oracle: %s; identical accept / reject sequences on %d of %d windows" % (worst, same_decisions, len(ws)))
+    assert worst["final_cost"] <= 1e-4 and worst["cam"] <= 1e-4 and worst["cp"] <= 1e-3 and worst["iter_cost"] <= 1e-4
+    assert same_decisions == len(ws)
+    # a batch in mixed precision: reproducible bit for bit, equal to its windows alone
+    b = hip.LBABatch()
+    for w in ws[3:7]:
+        b.add(w)
+    b.finalize(lba_precision=1)
+    assert b.elimination() == 4
+    b.solve(); b.download()
+    first = [b.parameters(i).copy() for i in range(4)]
+    b.reset(); b.solve(); b.download()
+    for i in range(4):
+        assert np.array_equal(first[i], b.parameters(i))
+        xs, _, _ = hip.lba_solve(ws[3 + i], lba_precision=1)
+        assert np.abs(xs - first[i]).max() < 1e-6
+    b.close()
+    wide = synth.make_window(41, num_lines=60, num_kf=30, num_free=14)
+    for bad in (dict(lba_precision=1, lba_elimination=1), dict(lba_precision=2)):
+        with pytest.raises(hip.SlslamError):
+            hip.lba_solve(ws[5], **bad)
+    with pytest.raises(hip.SlslamError) as e:
+        hip.lba_solve(wide, lba_precision=1)               # 14 free cameras: the grouped sweep cannot take it
+    assert e.value.status == 4
+
+
 def test_batched_motion_only(hip, oracle):
     """motion_only_ba (reference src/slam.cpp:578-675) batched over frames.  Same
     kernels, degenerate shape: one free camera, every line constant, 6x6 reduced system."""

@@ -1,0 +1,55 @@
+"""The streamed leg alone (bench.py::streamed_block's loop) with per-call host timings: where a batch period goes - submit (pack + layout +
+enqueue), waiting in collect, copying out - batch by batch.  Run under `rocprofv3 --kernel-trace --memory-copy-trace` to see whether
+uploads, solves and downloads of consecutive batches overlap on the device."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from slslam_amd import capi, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--windows", type=int, default=1024)
+    ap.add_argument("--lines", type=int, default=2000)
+    ap.add_argument("--batches", type=int, default=8)
+    ap.add_argument("--depth", type=int, default=3)
+    ap.add_argument("--host-threads", type=int, default=0)
+    args = ap.parse_args()
+    B = args.windows
+    windows = [synth.make_window(i, num_lines=args.lines) for i in range(B)]
+    nsets = args.depth + 1 + args.batches
+    sets = [capi.WindowSet(windows[(k * 37) % B:] + windows[:(k * 37) % B]) for k in range(nsets)]
+    st = capi.LBAStream(depth=args.depth, host_threads=args.host_threads)
+    tick = []
+    for k in range(args.depth + 1):
+        if k >= args.depth:
+            st.collect(tick[k - args.depth], want_summaries=False)
+        tick.append(st.submit(sets[k]))
+    for k in range(1, args.depth + 1):
+        st.collect(tick[k], want_summaries=False)
+    rows, tick = [], []
+    t00 = time.perf_counter()
+    for k in range(args.batches):
+        tw = 0.0
+        if k >= args.depth:
+            a = time.perf_counter(); st.collect(tick[k - args.depth], want_summaries=False); tw = time.perf_counter() - a
+        a = time.perf_counter(); tick.append(st.submit(sets[args.depth + 1 + k])); ts = time.perf_counter() - a
+        rows.append((k, 1e3 * tw, 1e3 * ts))
+    for k in range(max(0, args.batches - args.depth), args.batches):
+        a = time.perf_counter(); st.collect(tick[k], want_summaries=False); rows.append((k, 1e3 * (time.perf_counter() - a), 0.0))
+    dt = time.perf_counter() - t00
+    for r in rows:
+        print("batch %2d  collect %.2f ms  submit %.2f ms" % r)
+    print(json.dumps({"ms_per_batch": 1e3 * dt / args.batches, "stats": st.stats()}))
+    st.close()
+
+
+if __name__ == "__main__":
+    main()
