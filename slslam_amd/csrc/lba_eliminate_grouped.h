@@ -74,15 +74,18 @@ __device__ __forceinline__ void grouped_flush_tile(double* slab, const solve_acc
 // later launch is fresh); the compile-time form keeps the first sweep's extras out of the steady sweep's registers.
 // KEEP (lba_keep_jacobian, off by default - measured slower): the linearising sweep leaves its J blocks in memory
 // and the sweep after a rejected step replays them (second loop below); the plain instantiation carries none of it.
-// MIXED (slslam_solver_options.lba_precision = 1, steady sweeps only): the row gradients, both Jacobians and the per-observation block
-// products (J_l^T J_l, J_l^T r, J_c'^T J_l, J_c'^T J_c', J_c'^T r: sums of four terms) in float, converted to double where they are
-// ACCUMULATED - the segmented sums over a line's observations, the camera records, the F rows that feed the matrix cores; the
-// geometry, residuals, costs, the 4 x 4 factor and everything downstream stay double (lba_math.h::obs_linearise_raw_mixed).
+// MIXED (slslam_solver_options.lba_precision = 1, steady sweeps only): the camera Jacobian J_c' of an observation is FORMED in float
+// (lba_math.h::obs_linearise_raw_mixed: packed fp32; geometry, residuals and the line Jacobian in double - why exactly this split is
+// measured there), parked in LDS as floats and widened to double when it comes back; every product and every sum is the double path's.
+// Products of two floats are exact in double, so the camera-side blocks the sweep builds are those of a least-squares problem whose
+// camera Jacobian is the float one - a consistent system, i.e. a Gauss-Newton step with a J_c' that is off by ~1e-6.  (A first form
+// that also took the line Jacobian and the four-term block products in float was measured and dropped: 11 of 28 windows changed an
+// accept / reject decision, final costs moved by up to 2e-2, profiles/round5_mixed_precision_study.txt.)
 template <bool FRESH, bool KEEP = false, bool MIXED = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_eliminate_grouped(BatchPtrs p, Policy pol) {
   static_assert(!(MIXED && (FRESH || KEEP)), "the mixed-precision form exists for the plain steady sweep only");
-  using JT = typename std::conditional<MIXED, float, double>::type;      // what Jacobian entries and their four-term products are held in
+  using JT = double;                                                     // Jacobian entries once they are formed (widened in the MIXED form)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   SLS_K1_STAMP_INIT;
@@ -325,7 +328,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
         for (int a = 0; a < 4; ++a) sl[a] = fresh ? 1.0 : pf.lsc[a];
         if constexpr (MIXED) {
           obs_linearise_raw_mixed(R, tt, pf.trig, sl, pf.ob, pol.baseline, pol.huber_delta, rs, Jl, &cost,
-            [&](int row, const float (&jc)[6]) {
+            [&](int row, const float (&jc)[6]) {          // parked as floats (half the LDS traffic), widened when they come back
               float2* dst = reinterpret_cast<float2*>(slabF) + 3 * row;
               dst[0] = make_float2(jc[0], jc[1]); dst[1] = make_float2(jc[2], jc[3]); dst[2] = make_float2(jc[4], jc[5]);
             });
@@ -463,7 +466,7 @@ void k_eliminate_grouped(BatchPtrs p, Policy pol) {
         double2* hkeep = reinterpret_cast<double2*>(p.fstore) + ((long long)t * (12 * 64) + lane);
         if constexpr (MIXED) {
 #pragma unroll
-          for (int q = 0; q < 12; ++q) { const float2 v2 = reinterpret_cast<const float2*>(slabF)[q]; Jc[2 * q] = v2.x; Jc[2 * q + 1] = v2.y; }
+          for (int q = 0; q < 12; ++q) { const float2 v2 = reinterpret_cast<const float2*>(slabF)[q]; Jc[2 * q] = (double)v2.x; Jc[2 * q + 1] = (double)v2.y; }
         } else {
 #pragma unroll
           for (int q = 0; q < 12; ++q) { const double2 v2 = reinterpret_cast<const double2*>(slabF)[q]; Jc[2 * q] = v2.x; Jc[2 * q + 1] = v2.y; }

@@ -291,14 +291,19 @@ SLS_HD void obs_linearise_raw(const T R[9], const T t[3], const T trig[7], const
 
 // MIXED precision (slslam_solver_options.lba_precision = 1; the steady elimination sweeps only - the first sweep of a solve, which is also
 // Ceres' initial evaluation, stays double): the same observation with
-//   * the geometry in DOUBLE - the line's frame in camera coordinates, P = R cp + t, the image-line normals n = P x dc of the stereo
-//     pair, 1 / sqrt(n0^2 + n1^2), the four signed distances rho and the Huber factor: everything costs and gradients are made of, and
-//     the two places where float loses the problem (d = cos t / sin t of reference src/lba_problem.h:63 for far lines - P is a
-//     difference of terms of size |d| - and the normal's length of :90 for a line through the principal point);
-//   * the row gradients q, gP, gD and BOTH Jacobians in FLOAT (relative error ~1e-6 per entry: a Jacobian only has to point the
-//     step), two rows at a time - the two endpoints of one camera of the stereo pair share everything but (x, y, rho) - on 2-wide
-//     vectors, which gfx950 executes as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two flops per lane and instruction).
-// rs comes back in double; Jl (row-major 4 x 4) and the rows of J_c' in float.
+//   * the geometry, the residuals, the Huber factor, the row gradients q, gP, gD and the LINE Jacobian J_l in DOUBLE, exactly as above;
+//   * the CAMERA Jacobian J_c' = [tau | gP] in FLOAT, two rows at a time - the two endpoints of one camera of the stereo pair share
+//     everything but q - on 2-wide vectors, which gfx950 executes as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32).
+// Why only J_c': measured, not assumed (profiles/round5_mixed_precision_study.txt).  With BOTH Jacobians in float 8 of 28 bench-family
+// windows change an accept / reject decision and final costs move by up to 2e-2: a window holds a few depth-degenerate lines (seen
+// under a few degrees of parallax: an eigenvalue of their 4 x 4 block ~1e-8 of the others), and a line Jacobian that is off by 1e-6 of its
+// row's largest entry moves their step by percents.  J_l in double and J_c' in float: 28 of 28 windows take the same decisions, final cost
+// within 7e-5, poses within 2e-6 - camera blocks sum ~600 observations each and are well conditioned.  (The other way round is as bad
+// as both; only the depth column of J_l in double does not help.)
+// tau = Q x gP + dc x gD with gP = dc x q, gD = q x P_k, P_k = Q + t_k: for a far line (|Q| = |d| large, reference src/lba_problem.h:63)
+// the two products cancel to the size of q - in float the rotation part of J_c' would lose its digits there.  By the Jacobi identity
+// Q x (dc x q) + dc x (q x Q) = q x (dc x Q), so tau = q x W + dc x (q x t_k) with W = dc x Q (formed in double, once per
+// observation): nothing cancels any more.
 #if defined(__HIPCC__)
 typedef float sls_f2 __attribute__((ext_vector_type(2)));
 #else
@@ -306,7 +311,7 @@ typedef float sls_f2 __attribute__((vector_size(8)));
 #endif
 template <typename Sink>
 SLS_HD void obs_linearise_raw_mixed(const double R[9], const double t[3], const double trig[7], const double sl[4], const double ob[8],
-                                    double baseline, double huber_delta, double rs[4], float Jl[16], double* cost, Sink&& jc_row) {
+                                    double baseline, double huber_delta, double rs[4], double Jl[16], double* cost, Sink&& jc_row) {
   const double s1 = trig[0], c1 = trig[1], s2 = trig[2], c2 = trig[3], s3 = trig[4], c3 = trig[5], d = trig[6];
   const double col0[3] = { c2 * c3, c2 * s3, -s2 };
   const double col1[3] = { s1 * s2 * c3 - c1 * s3, s1 * s2 * s3 + c1 * c3, s1 * c2 };
@@ -319,6 +324,19 @@ SLS_HD void obs_linearise_raw_mixed(const double R[9], const double t[3], const 
     Q[i] = -d * e2[i];
     P[i] = Q[i] + t[i];
   }
+  const double r3[3] = { R[2], R[5], R[8] };
+  double Mp[4][3], Md[3][3];
+  {
+    const double k0 = d * sl[0], k1p = -d * c1 * sl[1], k1d = s1 * sl[1], k2p = -d * sl[2], k3 = (1.0 + d * d) * sl[3];
+    const double x2[3] = { r3[1] * e2[2] - r3[2] * e2[1], r3[2] * e2[0] - r3[0] * e2[2], r3[0] * e2[1] - r3[1] * e2[0] };
+    const double x1[3] = { r3[1] * dc[2] - r3[2] * dc[1], r3[2] * dc[0] - r3[0] * dc[2], r3[0] * dc[1] - r3[1] * dc[0] };
+    for (int i = 0; i < 3; ++i) {
+      Mp[0][i] = k0 * dc[i];  Md[0][i] = sl[0] * e2[i];
+      Mp[1][i] = k1p * e0[i]; Md[1][i] = k1d * e0[i];
+      Mp[2][i] = k2p * x2[i]; Md[2][i] = sl[2] * x1[i];
+      Mp[3][i] = k3 * e2[i];
+    }
+  }
   double m[2][2], is[2], rho[4], px[2] = { P[0], P[0] - baseline };
   for (int k = 0; k < 2; ++k) {
     const double n0 = P[1] * dc[2] - P[2] * dc[1];
@@ -330,53 +348,41 @@ SLS_HD void obs_linearise_raw_mixed(const double R[9], const double t[3], const 
     for (int e = 0; e < 2; ++e) rho[2 * k + e] = ob[4 * k + 2 * e] * m[k][0] + ob[4 * k + 2 * e + 1] * m[k][1] + m2;
   }
   const double sr = huber_scale<double>(rho[0] * rho[0] + rho[1] * rho[1] + rho[2] * rho[2] + rho[3] * rho[3], huber_delta, cost);
-  for (int r = 0; r < 4; ++r) rs[r] = -rho[r] * sr;
-  // ---- from here on float
-  const float df = (float)d, c1f = (float)c1, s1f = (float)s1;
-  float e0f[3], dcf[3], e2f[3], Pf[3], r3f[3] = { (float)R[2], (float)R[5], (float)R[8] }, slf[4];
-  for (int i = 0; i < 3; ++i) { e0f[i] = (float)e0[i]; dcf[i] = (float)dc[i]; e2f[i] = (float)e2[i]; Pf[i] = (float)P[i]; }
+  // what the float part needs of the observation, narrowed once
+  float dcf[3];
+  for (int i = 0; i < 3; ++i) dcf[i] = (float)dc[i];
   const float Wf[3] = { (float)(dc[1] * Q[2] - dc[2] * Q[1]), (float)(dc[2] * Q[0] - dc[0] * Q[2]), (float)(dc[0] * Q[1] - dc[1] * Q[0]) };
   const float tkf[2][3] = { { (float)t[0], (float)t[1], (float)t[2] }, { (float)(t[0] - baseline), (float)t[1], (float)t[2] } };
-  for (int a = 0; a < 4; ++a) slf[a] = (float)sl[a];
-  float Mp[4][3], Md[3][3];
-  {
-    const float k0 = df * slf[0], k1p = -df * c1f * slf[1], k1d = s1f * slf[1], k2p = -df * slf[2], k3 = (1.0f + df * df) * slf[3];
-    const float x2[3] = { r3f[1] * e2f[2] - r3f[2] * e2f[1], r3f[2] * e2f[0] - r3f[0] * e2f[2], r3f[0] * e2f[1] - r3f[1] * e2f[0] };
-    const float x1[3] = { r3f[1] * dcf[2] - r3f[2] * dcf[1], r3f[2] * dcf[0] - r3f[0] * dcf[2], r3f[0] * dcf[1] - r3f[1] * dcf[0] };
-    for (int i = 0; i < 3; ++i) {
-      Mp[0][i] = k0 * dcf[i];  Md[0][i] = slf[0] * e2f[i];
-      Mp[1][i] = k1p * e0f[i]; Md[1][i] = k1d * e0f[i];
-      Mp[2][i] = k2p * x2[i];  Md[2][i] = slf[2] * x1[i];
-      Mp[3][i] = k3 * e2f[i];
-    }
-  }
   for (int k = 0; k < 2; ++k) {
-    const float iss = (float)(is[k] * sr), m0 = (float)m[k][0], m1 = (float)m[k][1], pxf = (float)px[k];
-    const sls_f2 x = { (float)ob[4 * k], (float)ob[4 * k + 2] }, y = { (float)ob[4 * k + 1], (float)ob[4 * k + 3] };
-    const sls_f2 rh = { (float)rho[2 * k], (float)rho[2 * k + 1] };
-    const sls_f2 q0 = (rh * m0 - x) * iss, q1 = (rh * m1 - y) * iss;
-    const float q2 = -iss;
+    const double iss = is[k] * sr;
+    double qd[2][3];
+    for (int e = 0; e < 2; ++e) {
+      const int row = 2 * k + e;
+      const double x = ob[4 * k + 2 * e], y = ob[4 * k + 2 * e + 1];
+      rs[row] = -rho[row] * sr;
+      const double q0 = -(x - rho[row] * m[k][0]) * iss, q1 = -(y - rho[row] * m[k][1]) * iss, q2 = -iss;
+      qd[e][0] = q0; qd[e][1] = q1; qd[e][2] = q2;
+      const double gP[3] = { dc[1] * q2 - dc[2] * q1, dc[2] * q0 - dc[0] * q2, dc[0] * q1 - dc[1] * q0 };
+      const double gD[3] = { q1 * P[2] - q2 * P[1], q2 * px[k] - q0 * P[2], q0 * P[1] - q1 * px[k] };
+      double* jl = Jl + 4 * row;
+      for (int j = 0; j < 3; ++j)
+        jl[j] = gP[0] * Mp[j][0] + gP[1] * Mp[j][1] + gP[2] * Mp[j][2] + gD[0] * Md[j][0] + gD[1] * Md[j][1] + gD[2] * Md[j][2];
+      jl[3] = gP[0] * Mp[3][0] + gP[1] * Mp[3][1] + gP[2] * Mp[3][2];
+    }
+    // ---- J_c' of the two rows of this camera, in float
+    const sls_f2 q0 = { (float)qd[0][0], (float)qd[1][0] }, q1 = { (float)qd[0][1], (float)qd[1][1] };
+    const float q2 = (float)qd[0][2];
     const sls_f2 gP[3] = { dcf[1] * q2 - q1 * dcf[2], q0 * dcf[2] - dcf[0] * q2, q1 * dcf[0] - q0 * dcf[1] };
-    const sls_f2 gD[3] = { q1 * Pf[2] - q2 * Pf[1], q2 * pxf - q0 * Pf[2], q0 * Pf[1] - q1 * pxf };
-    // tau = Q x gP + dc x gD with gP = dc x q, gD = q x P_k, P_k = Q + t_k: for a far line (|Q| = |d| large) the two products
-    // cancel to the size of q - in float that is where the rotation part of J_c' would lose its digits.  By the Jacobi identity
-    // Q x (dc x q) + dc x (q x Q) = q x (dc x Q), so tau = q x W + dc x (q x t_k) with W = dc x Q (formed in double, once per
-    // observation): nothing cancels any more.
     const sls_f2 u[3] = { q1 * tkf[k][2] - q2 * tkf[k][1], q2 * tkf[k][0] - q0 * tkf[k][2], q0 * tkf[k][1] - q1 * tkf[k][0] };
     sls_f2 jc[6];
     jc[0] = q1 * Wf[2] - q2 * Wf[1] + u[2] * dcf[1] - u[1] * dcf[2];
     jc[1] = q2 * Wf[0] - q0 * Wf[2] + u[0] * dcf[2] - u[2] * dcf[0];
     jc[2] = q0 * Wf[1] - q1 * Wf[0] + u[1] * dcf[0] - u[0] * dcf[1];
     jc[3] = gP[0]; jc[4] = gP[1]; jc[5] = gP[2];
-    sls_f2 jl[4];
-    for (int j = 0; j < 3; ++j)
-      jl[j] = gP[0] * Mp[j][0] + gP[1] * Mp[j][1] + gP[2] * Mp[j][2] + gD[0] * Md[j][0] + gD[1] * Md[j][1] + gD[2] * Md[j][2];
-    jl[3] = gP[0] * Mp[3][0] + gP[1] * Mp[3][1] + gP[2] * Mp[3][2];
     for (int e = 0; e < 2; ++e) {
       float row[6];
       for (int a = 0; a < 6; ++a) row[a] = jc[a][e];
       jc_row(2 * k + e, row);
-      for (int a = 0; a < 4; ++a) Jl[4 * (2 * k + e) + a] = jl[a][e];
     }
   }
 }

@@ -262,6 +262,9 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
     uint64_t nonfinite = 0;
     for (int o = 0; o < M; ++o) {
       const int i = P.ob_orig[o];
+      // (a stream of windows reads every observation from memory exactly once, here, in the order of the sorted lines: ask for the lines a
+      // few observations ahead - 16 threads packing cold windows were waiting on these loads, tools/pack_bench2.cpp)
+      if (o + 16 < M) { const double* nx = w->observations + 8 * (size_t)P.ob_orig[o + 16]; __builtin_prefetch(nx); __builtin_prefetch(nx + 7); }
       P.ob_cam[o] = w->camera_index[i];
       const double* src = w->observations + 8 * (size_t)i;
       for (int q = 0; q < 4; ++q) { pl[q][2 * (size_t)o] = src[2 * q]; pl[q][2 * (size_t)o + 1] = src[2 * q + 1]; }

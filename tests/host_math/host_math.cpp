@@ -63,16 +63,14 @@ void hm_obs_linearise_raw(const double* cam, const double* line, const double* o
   slslam::obs_linearise_raw<double>(R, cam + 3, trig, sl, obs, baseline, huber_delta, rs, jl, cost,
                                     [&](int row, const double (&j)[6]) { for (int a = 0; a < 6; ++a) jc[6 * row + a] = j[a]; });
 }
-// The mixed-precision form of the same (lba_precision = 1): residuals and cost in double, both Jacobians in float (returned widened)
+// The mixed-precision form of the same (lba_precision = 1): residuals, cost and J_l in double, J_c' in float (returned widened)
 void hm_obs_linearise_raw_mixed(const double* cam, const double* line, const double* obs, double baseline, double huber_delta,
                                 const double* sl, double* rs, double* jc, double* jl, double* cost) {
   double R[9], trig[7];
-  float jlf[16];
   slslam::cam_rotation<double>(cam, R);
   slslam::line_trig<double>(line, trig);
-  slslam::obs_linearise_raw_mixed(R, cam + 3, trig, sl, obs, baseline, huber_delta, rs, jlf, cost,
+  slslam::obs_linearise_raw_mixed(R, cam + 3, trig, sl, obs, baseline, huber_delta, rs, jl, cost,
                                   [&](int row, const float (&j)[6]) { for (int a = 0; a < 6; ++a) jc[6 * row + a] = (double)j[a]; });
-  for (int q = 0; q < 16; ++q) jl[q] = (double)jlf[q];
 }
 }
 

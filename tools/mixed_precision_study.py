@@ -32,10 +32,13 @@ def main():
                          steps_mixed=[sm["num_successful_steps"], sm["num_unsuccessful_steps"]], first_different_decision=first_diff,
                          iter_cost_rel_until_then=iter_cost, final_cost_rel=abs(sm["final_cost"] - sd["final_cost"]) / sd["final_cost"],
                          cam=float(np.abs(xm[:nc] - xd[:nc]).max()), cp_near=float(np.abs(cpm - cpd)[near].max()),
+                         cp_near_p99=float(np.percentile(np.abs(cpm - cpd)[near].max(axis=1), 99)), cp_near_median=float(np.median(np.abs(cpm - cpd)[near].max(axis=1))),
+                         lines_beyond_1mm=int((np.abs(cpm - cpd)[near].max(axis=1) > 1e-3).sum()), lines_near=int(near.sum()),
                          rho_at_split=(td[first_diff]["relative_decrease"], tm[first_diff]["relative_decrease"]) if first_diff is not None else None))
         print(json.dumps(rows[-1]))
     print("windows with identical decisions: %d of %d" % (sum(r["first_different_decision"] is None for r in rows), len(rows)))
-    for k in ("iter_cost_rel_until_then", "final_cost_rel", "cam", "cp_near"):
+    print("lines within 10 m whose closest point moved by more than 1 mm: %d of %d" % (sum(r["lines_beyond_1mm"] for r in rows), sum(r["lines_near"] for r in rows)))
+    for k in ("iter_cost_rel_until_then", "final_cost_rel", "cam", "cp_near", "cp_near_p99", "cp_near_median"):
         print("worst %-26s %.3e   median %.3e" % (k, max(r[k] for r in rows), float(np.median([r[k] for r in rows]))))
 
 
