@@ -1111,9 +1111,9 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
       for (int k0 = 0; k0 < nchunks; k0 += 8) {
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < nchunks) ? src[(k0 + u) * sstride] : 0.0;
+        for (int u = 0; u < 8; ++u) v[u] = src[(k0 + u < nchunks ? k0 + u : nchunks - 1) * sstride];      // (no load under a condition: all eight in flight together)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 8; ++u) s += (k0 + u < nchunks) ? v[u] : 0.0;
       }
       const int cf = q / kMfmaRec, e = q - cf * kMfmaRec;
       if (e < 21) {
@@ -1171,9 +1171,9 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
       for (int k0 = 0; k0 < nchunks; k0 += 8) {
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < nchunks) ? src[(k0 + u) * sstride] : 0.0;
+        for (int u = 0; u < 8; ++u) v[u] = src[(k0 + u < nchunks ? k0 + u : nchunks - 1) * sstride];      // (no load under a condition: all eight in flight together)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 8; ++u) s += (k0 + u < nchunks) ? v[u] : 0.0;
       }
       A[row * ld + col] -= s;
     }

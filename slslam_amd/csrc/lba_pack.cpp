@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -89,6 +90,8 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
     bool carry_open = false;                         // grouping: the open rows survive from one call to the next
     struct OpenRow { int row; unsigned mask; };      // an open row with the free cameras of its lines (beside the id: the search below reads nothing else)
     std::vector<OpenRow> open_keep[17];
+    static const bool no_disjoint = std::getenv("SLSLAM_PACK_NO_DISJOINT") != nullptr;       // (experiment: the camera-disjoint preference off for the grouped packing)
+    const int first_pass = (grouping && no_disjoint) ? 1 : 0;
     auto pack_rows = [&](int len_lo, int len_hi) {
       const int first = (int)rows.size();
       std::vector<OpenRow> open_local[17];
@@ -100,7 +103,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
           // serialise in the LDS (tools/micro/lds_atomic_bench.hip)
           int r = -1;
           const unsigned fm = fmask[l];
-          for (int pass = 0; pass < 2 && r < 0; ++pass)          // pass 0: rows without a common free camera only
+          for (int pass = first_pass; pass < 2 && r < 0; ++pass)          // pass 0: rows without a common free camera only
             for (int room = len; room <= 16 && r < 0; ++room) {
               std::vector<OpenRow>& cand = open_by_room[room];
               for (size_t c = cand.size(); c-- > 0 && cand.size() - c <= 32;)
