@@ -8,6 +8,17 @@
 #include <cstring>
 #include <numeric>
 
+// host-side phase clock of pack_window (tools/pack_bench.cpp -DSLS_PACK_TIMING): where a window's pack time goes
+#if defined(SLS_PACK_TIMING)
+#include <chrono>
+namespace slslam { double g_pack_phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; }
+#define SLS_PACK_T0 auto pk_t_ = std::chrono::steady_clock::now()
+#define SLS_PACK_MARK(i) do { const auto n_ = std::chrono::steady_clock::now(); slslam::g_pack_phase_ms[i] += std::chrono::duration<double, std::milli>(n_ - pk_t_).count(); pk_t_ = n_; } while (0)
+#else
+#define SLS_PACK_T0 do {} while (0)
+#define SLS_PACK_MARK(i) do {} while (0)
+#endif
+
 namespace slslam {
 
 namespace {
@@ -31,6 +42,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
     return SLSLAM_ERR_INVALID_ARGUMENT;
   if ((C > 0 || L > 0) && !w->parameters) return SLSLAM_ERR_INVALID_ARGUMENT;
   PackedWindow& P = *out;
+  SLS_PACK_T0;
   // (the vectors of `out` keep their capacity: a batch that is refilled packs into the windows of the refill before last)
   P.Cf = 0; P.nfree_params = 0; P.nkept = 0; P.big = false; P.dup_free_obs = false;
   P.tiles.clear(); P.lane_map.clear(); P.items.clear(); P.ob.clear();
@@ -42,13 +54,32 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
   // block constness: one flagged observation makes the block constant (lba_problem.cpp:88-91)
   std::vector<char> cam_const(C, 0), cam_used(C, 0), line_const(L, 0);
   std::vector<int> line_cnt(L, 0);
-  for (int i = 0; i < M; ++i) {
-    const int c = w->camera_index[i], l = w->line_index[i];
-    if (c < 0 || c >= C || l < 0 || l >= L) return SLSLAM_ERR_INVALID_ARGUMENT;
-    cam_used[c] = 1; line_cnt[l]++;
-    if (w->fixed_index[2 * i]) cam_const[c] = 1;
-    if (w->fixed_index[2 * i + 1]) line_const[l] = 1;
+  // (at most 64 cameras - every window of the tiled sweeps: the cameras that see a line as a 64-bit mask, gathered in this pass, give the
+  // free-camera masks and counts below without a second pass over the observations; `twice`: some camera sees some line more than once)
+  const bool small_c = C <= 64;
+  std::vector<uint64_t> cmask(small_c ? (size_t)L : 0, 0ull);
+  uint64_t twice = 0;
+  if (small_c) {
+    for (int i = 0; i < M; ++i) {
+      const int c = w->camera_index[i], l = w->line_index[i];
+      if (c < 0 || c >= C || l < 0 || l >= L) return SLSLAM_ERR_INVALID_ARGUMENT;
+      const uint64_t bit = 1ull << c;
+      twice |= cmask[(size_t)l] & bit;
+      cmask[(size_t)l] |= bit;
+      cam_used[c] = 1; line_cnt[l]++;
+      if (w->fixed_index[2 * i]) cam_const[c] = 1;
+      if (w->fixed_index[2 * i + 1]) line_const[l] = 1;
+    }
+  } else {
+    for (int i = 0; i < M; ++i) {
+      const int c = w->camera_index[i], l = w->line_index[i];
+      if (c < 0 || c >= C || l < 0 || l >= L) return SLSLAM_ERR_INVALID_ARGUMENT;
+      cam_used[c] = 1; line_cnt[l]++;
+      if (w->fixed_index[2 * i]) cam_const[c] = 1;
+      if (w->fixed_index[2 * i + 1]) line_const[l] = 1;
+    }
   }
+  SLS_PACK_MARK(0);
   P.cam_cf.assign(C, -1);
   for (int c = 0; c < C; ++c) if (cam_used[c] && !cam_const[c]) P.cam_cf[c] = P.Cf++;
   // windows beyond what the tiled sweeps hold on chip take the global-memory path (lba_big.h): no tiles are built for them
@@ -65,6 +96,24 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
   //     back-substitution) are kept in tiles of their own.
   std::vector<int> kfree(L, 0);
   std::vector<unsigned> fmask(L, 0u);            // free cameras that see the line
+  if (!P.big && small_c && !twice) {
+    // no camera sees a line twice: a line's free-camera mask is its camera mask with every free camera's bit moved to its free index, its
+    // free observations are as many as the mask has bits
+    // (byte by byte through a table: tab[b][v] = free-index bits of the cameras 8 b + {bits of v})
+    const int nbytes = (C + 7) / 8;
+    std::vector<unsigned> tab((size_t)nbytes * 256, 0u);
+    for (int b = 0; b < nbytes; ++b)
+      for (int v = 1; v < 256; ++v) {
+        const int c = 8 * b + __builtin_ctz((unsigned)v), cf = c < C ? P.cam_cf[c] : -1;
+        tab[(size_t)b * 256 + v] = tab[(size_t)b * 256 + (v & (v - 1))] | (cf >= 0 ? 1u << cf : 0u);
+      }
+    for (int l = 0; l < L; ++l) {
+      unsigned fm = 0u;
+      const uint64_t m = cmask[(size_t)l];
+      for (int b = 0; b < nbytes; ++b) fm |= tab[(size_t)b * 256 + ((m >> (8 * b)) & 255u)];
+      fmask[l] = fm; kfree[l] = __builtin_popcount(fm);
+    }
+  } else
   for (int i = 0; i < M && !P.big; ++i)        // (oversize windows have up to 64 free cameras and no tiles: no masks, no work items)
     if (P.cam_cf[w->camera_index[i]] >= 0) {
       const unsigned bit = 1u << P.cam_cf[w->camera_index[i]];
@@ -81,44 +130,47 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
     if (rows[r].head < 0) rows[r].head = l; else next[rows[r].tail] = l;
     rows[r].tail = l; rows[r].used += lanes_of(l); rows[r].items += items_of(l); rows[r].mask |= fmask[l];
   };
-  // best fit over lines of decreasing length (counting sort by length, original order inside a length): a line goes to
-  // the fullest open row that still holds it, else it opens a row.  Returns the range of row ids created.
   std::vector<int> tile_rows;                      // row ids, tile after tile
   std::vector<int> tile_ptr(1, 0);
   if (!P.big) {
-    std::vector<int> by_len[17];
-    bool carry_open = false;                         // grouping: the open rows survive from one call to the next
-    struct OpenRow { int row; unsigned mask; };      // an open row with the free cameras of its lines (beside the id: the search below reads nothing else)
-    std::vector<OpenRow> open_keep[17];
     static const bool no_disjoint = std::getenv("SLSLAM_PACK_NO_DISJOINT") != nullptr;       // (experiment: the camera-disjoint preference off for the grouped packing)
     const int first_pass = (grouping && no_disjoint) ? 1 : 0;
-    auto pack_rows = [&](int len_lo, int len_hi) {
-      const int first = (int)rows.size();
-      std::vector<OpenRow> open_local[17];
-      std::vector<OpenRow>* open_by_room = carry_open ? open_keep : open_local;
-      for (int len = len_hi; len >= len_lo; --len)
-        for (int l : by_len[len]) {
-          // the fullest open row that holds the line - and, among the rows of that fill, preferably one none of whose
-          // lines shares a free camera with it: the lanes of one 16-lane row that add to the same camera record
-          // serialise in the LDS (tools/micro/lds_atomic_bench.hip)
-          int r = -1;
-          const unsigned fm = fmask[l];
-          for (int pass = first_pass; pass < 2 && r < 0; ++pass)          // pass 0: rows without a common free camera only
-            for (int room = len; room <= 16 && r < 0; ++room) {
-              std::vector<OpenRow>& cand = open_by_room[room];
-              for (size_t c = cand.size(); c-- > 0 && cand.size() - c <= 32;)
-                if (pass == 1 || !(cand[c].mask & fm)) { r = cand[c].row; cand.erase(cand.begin() + c); break; }
-            }
-          if (r < 0) { r = (int)rows.size(); rows.push_back(Row{0, 0, -1, -1, 0u}); }
-          append(r, l);
-          if (rows[r].used < 16) open_by_room[16 - rows[r].used].push_back(OpenRow{ r, rows[r].mask });
-        }
-      return std::make_pair(first, (int)rows.size());
+    // open rows by the lanes they have left, with the free cameras of their lines (beside the id: the search below reads nothing else).
+    // and_mask[room]: a subset of the cameras EVERY row of that list holds (the AND of the masks pushed since the list was last empty -
+    // rows leave, so the true AND can only have more bits): a line that shares one of them shares a camera with every row of the list,
+    // and the camera-disjoint pass skips the list without reading it.  (The lines of one group all see the group's first camera: for
+    // the grouped packing that pass found nothing in list after list, 2 x 16 x 32 mask tests per line.)
+    struct OpenRow { int row; unsigned mask; };
+    struct OpenLists {
+      std::vector<OpenRow> by_room[17];
+      unsigned and_mask[17];
+      void clear() { for (int q = 0; q <= 16; ++q) { by_room[q].clear(); and_mask[q] = ~0u; } }
+      void push(int room, OpenRow r) { std::vector<OpenRow>& v = by_room[room]; and_mask[room] = v.empty() ? r.mask : (and_mask[room] & r.mask); v.push_back(r); }
+    } open;
+    // best fit over lines of decreasing length (the caller hands them over in that order, original order inside a length): a line goes to
+    // the fullest open row that still holds it, else it opens a row
+    auto pack_rows = [&](const int* lb, const int* le) {
+      for (; lb != le; ++lb) {
+        const int l = *lb, len = lanes_of(l);
+        // the fullest open row that holds the line - and, among the rows of that fill, preferably one none of whose
+        // lines shares a free camera with it: the lanes of one 16-lane row that add to the same camera record
+        // serialise in the LDS (tools/micro/lds_atomic_bench.hip)
+        int r = -1;
+        const unsigned fm = fmask[l];
+        for (int pass = first_pass; pass < 2 && r < 0; ++pass)          // pass 0: rows without a common free camera only
+          for (int room = len; room <= 16 && r < 0; ++room) {
+            std::vector<OpenRow>& cand = open.by_room[room];
+            if (cand.empty() || (pass == 0 && (open.and_mask[room] & fm))) continue;
+            for (size_t c = cand.size(); c-- > 0 && cand.size() - c <= 32;)
+              if (pass == 1 || !(cand[c].mask & fm)) { r = cand[c].row; cand.erase(cand.begin() + c); break; }
+          }
+        if (r < 0) { r = (int)rows.size(); rows.push_back(Row{0, 0, -1, -1, 0u}); }
+        append(r, l);
+        if (rows[r].used < 16) open.push(16 - rows[r].used, OpenRow{ r, rows[r].mask });
+      }
     };
     std::vector<int> big;
-    for (int l = 0; l < L; ++l) {
-      if (line_cnt[l] > 16) big.push_back(l); else by_len[lanes_of(l)].push_back(l);
-    }
+    for (int l = 0; l < L; ++l) if (line_cnt[l] > 16) big.push_back(l);
     {
       int used_rows = 4;
       std::stable_sort(big.begin(), big.end(), [&](int x, int y) { return line_cnt[x] > line_cnt[y]; });
@@ -141,39 +193,47 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
       const int a = __builtin_ctz(m), hi = 31 - __builtin_clz(m);
       return 2 * a + ((hi - a + 1) > 8 ? 0 : 1);       // (the wide lines first: the lanes they leave free in their rows go to lines of their own group)
     };
+    // The lines of at most 16 lanes in the order the rows are built from them - one counting sort (stable: original order inside a
+    // cell): class (0: at least 4 lanes; 1: fewer, which need more than one sin/cos round per lane in the back-substitution and are kept in
+    // tiles of their own), then - grouped packing - the group bucket (keys 2 a + {0, 1} with a < 20, or the last one: no elimination work),
+    // then the length, longest first.
+    enum { kBuckets = 42 };
+    const int nb = grouping ? kBuckets : 1;
+    std::vector<int> key_of;
+    if (grouping) { key_of.resize((size_t)L); for (int l = 0; l < L; ++l) key_of[(size_t)l] = group_key(l); }
+    auto cell_of = [&](int l) {
+      const int len = lanes_of(l), cls = len < 4 ? 1 : 0;
+      const int bq = grouping ? (key_of[(size_t)l] >= 1000 ? kBuckets - 1 : key_of[(size_t)l]) : 0;
+      return (cls * nb + bq) * 16 + (16 - len);
+    };
+    std::vector<int> cell_ptr((size_t)2 * nb * 16 + 1, 0), seq;
+    for (int l = 0; l < L; ++l) if (line_cnt[l] <= 16) ++cell_ptr[(size_t)cell_of(l) + 1];
+    for (size_t q = 1; q < cell_ptr.size(); ++q) cell_ptr[q] += cell_ptr[q - 1];
+    seq.resize((size_t)cell_ptr.back());
+    {
+      std::vector<int> cur(cell_ptr.begin(), cell_ptr.end() - 1);
+      for (int l = 0; l < L; ++l) if (line_cnt[l] <= 16) seq[(size_t)cur[(size_t)cell_of(l)]++] = l;
+    }
+    auto bucket_range = [&](int cls, int bq) { return std::make_pair(seq.data() + cell_ptr[(size_t)(cls * nb + bq) * 16], seq.data() + cell_ptr[(size_t)(cls * nb + bq + 1) * 16]); };
     if (grouping) {
-      // the two length classes of the default packing are kept (lines with fewer than 4 lanes in tiles of their own: the
-      // back-substitution's sin/cos rounds), each of them group after group, the rows filling the tiles in that order
-      std::vector<int> lens[2][17];
-      for (int len = 1; len <= 16; ++len) { lens[len < 4 ? 1 : 0][len].swap(by_len[len]); }
-      std::vector<int> key_of((size_t)L);
-      for (int l = 0; l < L; ++l) key_of[(size_t)l] = group_key(l);
+      // the two length classes of the default packing are kept, each of them group after group, the rows filling the tiles in that order
       for (int cls = 0; cls < 2; ++cls) {
-        // keys are 2 a + {0, 1} with a < 20, or 1000 (no elimination work): 42 buckets, each with its lines by length in their original order
-        enum { kBuckets = 42 };
-        auto bucket_of = [](int key) { return key >= 1000 ? kBuckets - 1 : key; };
-        std::vector<int> bucket[kBuckets][17];
-        bool present[kBuckets] = {};
-        for (int len = 1; len <= 16; ++len)
-          for (int l : lens[cls][len]) { const int bq = bucket_of(key_of[(size_t)l]); bucket[bq][len].push_back(l); present[bq] = true; }
         const size_t first_row = tile_rows.size();
         const int row0 = (int)rows.size();
-        carry_open = true;                             // a group's lines may finish the open rows of the group before it
-        for (int q = 0; q <= 16; ++q) open_keep[q].clear();
+        open.clear();                                  // (a group's lines may finish the open rows of the group before it: the lists live through the class)
         int prev_first = row0;                         // first row the previous group opened
         for (int bq = 0; bq < kBuckets; ++bq) {        // ascending keys
-          if (!present[bq]) continue;
-          for (int len = 1; len <= 16; ++len) by_len[len].swap(bucket[bq][len]);
+          const std::pair<const int*, const int*> rg = bucket_range(cls, bq);
+          if (rg.first == rg.second) continue;
           // (only the rows the previous group left open: an older row would put this group's line in the middle of another
           // group's tiles, and the sweep adds its accumulators to memory whenever the group changes)
           for (int q = 0; q <= 16; ++q) {
-            std::vector<OpenRow>& v = open_keep[q];
+            std::vector<OpenRow>& v = open.by_room[q];
             v.erase(std::remove_if(v.begin(), v.end(), [&](const OpenRow& r) { return r.row < prev_first; }), v.end());
           }
           prev_first = (int)rows.size();
-          pack_rows(1, 16);
+          pack_rows(rg.first, rg.second);
         }
-        carry_open = false;
         {
           // rows in the order of the group of their FIRST line; a row that another group finished sits last among them, at the
           // seam between the two groups
@@ -190,7 +250,11 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
       }
     } else {
     {
-      const std::pair<int, int> rr = pack_rows(4, 16);
+      const int r_first = (int)rows.size();
+      open.clear();
+      const std::pair<const int*, const int*> rg = bucket_range(0, 0);
+      pack_rows(rg.first, rg.second);
+      const std::pair<int, int> rr(r_first, (int)rows.size());
       std::vector<int> order(rr.second - rr.first);
       std::iota(order.begin(), order.end(), rr.first);
       std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rows[x].items > rows[y].items; });
@@ -206,7 +270,11 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
       }
     }
     {
-      const std::pair<int, int> rr = pack_rows(1, 3);
+      const int r_first = (int)rows.size();
+      open.clear();
+      const std::pair<const int*, const int*> rg = bucket_range(1, 0);
+      pack_rows(rg.first, rg.second);
+      const std::pair<int, int> rr(r_first, (int)rows.size());
       for (int r = rr.first; r < rr.second; ++r) {
         tile_rows.push_back(r);
         if ((r - rr.first) % 4 == 3 || r + 1 == rr.second) tile_ptr.push_back((int)tile_rows.size());
@@ -214,6 +282,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
     }
     }
   }
+  SLS_PACK_MARK(1);
   P.line_order.clear();
   P.line_order.reserve(L);
   if (P.big) { for (int l = 0; l < L; ++l) P.line_order.push_back(l); }
@@ -234,28 +303,34 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
   }
   P.nfree_params = 6 * P.Cf + 4 * free_lines;
 
+  SLS_PACK_MARK(2);
   // observations grouped by line; inside a line: free cameras first (ascending free index)
   P.ob_orig.assign(M, 0);
   {
-    std::vector<int> fill(L, 0);
-    for (int i = 0; i < M; ++i) {
-      const int s = line_pos[w->line_index[i]];
-      P.ob_orig[P.line_ptr[s] + fill[s]++] = i;
-    }
+    // one 64-bit key per observation, camera key << 32 | original index, dropped into its line's range in the order of the caller's
+    // arrays (ascending index): sorting the keys of a line IS the stable sort of its observations by camera - and a line whose
+    // observations arrive in camera order (the reference's packer emits them so, src/slam.cpp:848-882) costs one comparison each
+    std::vector<int> fill(P.line_ptr.begin(), P.line_ptr.end() - 1);
     std::vector<int> cam_key((size_t)C);           // free cameras first (ascending free index), then the others by id
     for (int c = 0; c < C; ++c) cam_key[(size_t)c] = P.cam_cf[c] >= 0 ? P.cam_cf[c] : P.Cf + c;
-    auto key = [&](int i) { return cam_key[(size_t)w->camera_index[i]]; };
-    for (int s = 0; s < L; ++s) {                  // stable insertion sort of the (at most 64) observations of a line
-      int* o = P.ob_orig.data() + P.line_ptr[s];
+    std::vector<uint64_t> okey((size_t)M);
+    for (int i = 0; i < M; ++i) {
+      const int s = line_pos[w->line_index[i]];
+      okey[(size_t)fill[(size_t)s]++] = (uint64_t)(uint32_t)cam_key[(size_t)w->camera_index[i]] << 32 | (uint32_t)i;
+    }
+    for (int s = 0; s < L; ++s) {                  // insertion sort of the (at most 64, or - oversize windows - any number of) observations of a line
+      uint64_t* o = okey.data() + P.line_ptr[s];
       const int k = P.line_ptr[s + 1] - P.line_ptr[s];
       for (int a = 1; a < k; ++a) {
-        const int v = o[a], kv = key(v);
+        const uint64_t v = o[a];
         int b = a;
-        while (b > 0 && key(o[b - 1]) > kv) { o[b] = o[b - 1]; --b; }
+        while (b > 0 && o[b - 1] > v) { o[b] = o[b - 1]; --b; }
         o[b] = v;
       }
     }
+    for (int o = 0; o < M; ++o) P.ob_orig[(size_t)o] = (int)(uint32_t)okey[(size_t)o];
   }
+  SLS_PACK_MARK(3);
   P.ob_cam.resize(M);
   if (!ob_dest) P.ob.resize((size_t)8 * M);
   P.nkept = 0;
@@ -281,6 +356,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
     if (nonfinite) return SLSLAM_ERR_INVALID_ARGUMENT;
   }
 
+  SLS_PACK_MARK(4);
   // tiles, their lane maps and their off-diagonal camera-pair work items
   P.line_desc.assign(L, 0u);
   if (!P.big) {
@@ -328,13 +404,15 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
             // free index) | first lane of the run << 10 | tile t = (I, J), J <= I, touched (both 16-row blocks hold a row of
             // one of the line's cameras; camera cf owns rows 6 cf .. 6 cf + 5) << (16 + t)
             const uint32_t m = (P.line_flags[s] & 1) ? 0u : (fmask[P.line_order[s]] & 0x3ffu);
-            bool blk[4] = { false, false, false, false };
-            for (int cf = 0; cf < 10; ++cf)
-              if ((m >> cf) & 1u) { blk[(6 * cf) / 16] = true; blk[(6 * cf + 5) / 16] = true; }
-            uint32_t tiles_touched = 0;
-            for (int I = 0, t = 0; I < 4; ++I)
-              for (int J = 0; J <= I; ++J, ++t) if (blk[I] && blk[J]) tiles_touched |= 1u << t;
-            P.line_desc[s] = m | ((uint32_t)lane << 10) | (tiles_touched << 16);
+            if (!grouping) {
+              bool blk[4] = { false, false, false, false };
+              for (int cf = 0; cf < 10; ++cf)
+                if ((m >> cf) & 1u) { blk[(6 * cf) / 16] = true; blk[(6 * cf + 5) / 16] = true; }
+              uint32_t tiles_touched = 0;
+              for (int I = 0, t = 0; I < 4; ++I)
+                for (int J = 0; J <= I; ++J, ++t) if (blk[I] && blk[J]) tiles_touched |= 1u << t;
+              P.line_desc[s] = m | ((uint32_t)lane << 10) | (tiles_touched << 16);
+            }
             if (grouping) {
               // grouped sweep: the rows of the line's cameras counted from its first one, a = lowest bit of m: 6 (hi - a + 1) rows
               // = that many 16-row blocks
@@ -357,8 +435,14 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
         // the grouped sweep walks a tile's descriptors, not its lanes (a descriptor names its first lane): group after group,
         // inside a group by the number of blocks, lines without elimination work last (the walk ends at the first of them)
         auto key = [](uint32_t d) { return gp_mask(d) ? (int)(gp_group(d) * 8u + gp_blocks(d)) : 1 << 20; };
-        std::stable_sort(P.line_desc.begin() + t.line_begin, P.line_desc.begin() + t.line_begin + nl,
-                         [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
+        uint32_t* d = P.line_desc.data() + t.line_begin;       // (a stable insertion sort: at most 64 descriptors, mostly in order already)
+        for (int a = 1; a < nl; ++a) {
+          const uint32_t v = d[a];
+          const int kv = key(v);
+          int b = a;
+          while (b > 0 && key(d[b - 1]) > kv) { d[b] = d[b - 1]; --b; }
+          d[b] = v;
+        }
       }
       const int rounds_log2 = min_lanes >= 4 ? 0 : min_lanes >= 2 ? 1 : 2;
       t.nlines = (int16_t)nl;
@@ -369,6 +453,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
     }
     P.items.resize((size_t)(item_w - P.items.data()));
   }
+  SLS_PACK_MARK(5);
   return SLSLAM_OK;
 }
 
