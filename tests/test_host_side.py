@@ -853,3 +853,27 @@ def test_graded_chunk_boundaries(host_math):
         else:
             assert b == equal(nt, (nt + nc - 1) // nc)
     assert graded(0, [1, 1]) == [0]
+
+
+def test_packer_layout_matches_the_golden_digest(host_math):
+    """Everything pack_window emits for a fixed family of windows (bench shapes, wide tracks, 20 free cameras, motion-only, scrambled order
+    with holes and constant lines), both packings, against tests/golden/packer_digest.json (made by tests/golden/make_packer_digest.py): a
+    window's solved bytes are a function of its packed layout, so host-side work on the packer (round 5: the same layout 37 % faster) must
+    not move a byte of it."""
+    import importlib.util
+    import json
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_packer_digest", os.path.join(gold_dir, "make_packer_digest.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = json.load(open(os.path.join(gold_dir, "packer_digest.json")))
+    seen = 0
+    for name, w in mod.family().items():
+        for g in (0, 1):
+            rc, P = _pack(host_math, w, grouping=g)
+            assert rc == 0
+            ref = gold["%s/grouping%d" % (name, g)]
+            assert (P["ntiles"], P["nitems"]) == (ref["tiles"], ref["items"]), (name, g)
+            assert mod.digest(P) == ref["crc32"], (name, g)
+            seen += 1
+    assert seen == len(gold) == 12
