@@ -97,9 +97,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise SlslamError(2, "libslslam_hip.so not built (run __graft_entry__.build())")
-    L = C.CDLL(LIB_PATH)
+    # SLSLAM_HIP_LIBRARY: a variant build of the same library (kernel experiments, tools/variant_lib.sh); still a HIP library - no fallback
+    path = os.environ.get("SLSLAM_HIP_LIBRARY") or LIB_PATH
+    if not os.path.exists(path):
+        raise SlslamError(2, "libslslam_hip.so not built (run __graft_entry__.build()): " + path)
+    L = C.CDLL(path)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
     L.slslam_default_options.argtypes = [C.POINTER(SolverOptions)]
     L.slslam_default_options.restype = None

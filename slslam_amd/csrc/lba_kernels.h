@@ -626,7 +626,10 @@ __host__ __device__ inline int lds_doubles_linearise(int C, int n) {
 // (word 30) / ends (word 31) its elimination sweep - the timeline of a launch, tools/chunk_timeline.py; no other stamp, so the sweep runs undisturbed
 #if defined(SLSLAM_K1_WALL) && SLSLAM_K1_WALL
 #define SLS_K1_WALL(slot) do { unsigned long long now_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
-    if (lane == 0 && p.dbg_cycles) p.dbg_cycles[(long long)ck.id * 32 + (slot)] = now_; } while (0)
+    if (lane == 0 && p.dbg_cycles) { p.dbg_cycles[(long long)ck.id * 32 + (slot)] = now_; \
+      /* where the wave ran (word slot - 4: XCC_ID << 32 | HW_ID - wave, SIMD, CU, SH, SE): tools/chunk_classes.py groups the durations by it */ \
+      unsigned hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xcc_)); \
+      p.dbg_cycles[(long long)ck.id * 32 + (slot) - 4] = ((unsigned long long)xcc_ << 32) | hw_; } } while (0)
 #else
 #define SLS_K1_WALL(slot) do { } while (0)
 #endif
