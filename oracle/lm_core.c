@@ -41,6 +41,7 @@ void oracle_lm_default_options(oracle_lm_options* o) {
   o->parameter_tolerance = 1e-8;
   o->jacobi_scaling = 1;
   o->linear_solver = 0;
+  o->policy_variant = 0;
 }
 
 int oracle_dense_cholesky(double* a, int n) {
@@ -113,6 +114,7 @@ int oracle_lm_minimize(oracle_nlls* P, const oracle_lm_options* opt, double* x_m
   double last_gradient_max_norm = 0.0;
   double initial_gradient_max_norm = 0.0, absolute_gradient_tolerance = 0.0;
   int num_consecutive_invalid_steps = 0;
+  int pending_termination = -1;            /* policy_variant bit 1 */
   if (!P->evaluate(P->ctx, x, &cost, 1, gradient)) {
     summary->termination_type = ORACLE_NUMERICAL_FAILURE; rc = 1; goto done;
   }
@@ -127,7 +129,7 @@ int oracle_lm_minimize(oracle_nlls* P, const oracle_lm_options* opt, double* x_m
   it.gradient_max_norm = vec_maxabs(gradient, n);
   it.trust_region_radius = radius;
   initial_gradient_max_norm = it.gradient_max_norm > 1e-12 ? it.gradient_max_norm : 1e-12;
-  absolute_gradient_tolerance = opt->gradient_tolerance * initial_gradient_max_norm;
+  absolute_gradient_tolerance = (opt->policy_variant & 1) ? opt->gradient_tolerance : opt->gradient_tolerance * initial_gradient_max_norm;
   if (it.gradient_max_norm <= absolute_gradient_tolerance) {
     summary->termination_type = ORACLE_GRADIENT_TOLERANCE;
     goto done;
@@ -194,15 +196,16 @@ int oracle_lm_minimize(oracle_nlls* P, const oracle_lm_options* opt, double* x_m
       for (int i = 0; i < n; ++i) { const double d = x[i] - x_plus[i]; sn += d * d; }
       it.step_norm = sqrt(sn);
       const double step_size_tolerance = opt->parameter_tolerance * (x_norm + opt->parameter_tolerance);
+      const int late_tests = (opt->policy_variant & 2) != 0;      /* sweep variant: decide after the step has been applied */
       if (it.step_norm <= step_size_tolerance) {
-        summary->termination_type = ORACLE_PARAMETER_TOLERANCE;
-        goto done;
+        if (!late_tests) { summary->termination_type = ORACLE_PARAMETER_TOLERANCE; goto done; }
+        pending_termination = ORACLE_PARAMETER_TOLERANCE;
       }
       it.cost_change = cost - new_cost;
       const double absolute_function_tolerance = opt->function_tolerance * cost;
       if (fabs(it.cost_change) < absolute_function_tolerance) {
-        summary->termination_type = ORACLE_FUNCTION_TOLERANCE;
-        goto done;
+        if (!late_tests) { summary->termination_type = ORACLE_FUNCTION_TOLERANCE; goto done; }
+        if (pending_termination < 0) pending_termination = ORACLE_FUNCTION_TOLERANCE;
       }
       it.relative_decrease = it.cost_change / model_cost_change;
       it.step_is_successful = it.relative_decrease > opt->min_relative_decrease;
@@ -253,6 +256,10 @@ int oracle_lm_minimize(oracle_nlls* P, const oracle_lm_options* opt, double* x_m
     push_trace(trace, trace_cap, &tl, &it);
     last_iteration = it.iteration;
     last_gradient_max_norm = it.gradient_max_norm;
+    if (pending_termination >= 0) {
+      if (it.step_is_successful) { summary->termination_type = pending_termination; goto done; }
+      pending_termination = -1;
+    }
   }
 
 done:

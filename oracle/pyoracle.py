@@ -39,7 +39,8 @@ class LMOptions(C.Structure):
                 ("gradient_tolerance", C.c_double),
                 ("parameter_tolerance", C.c_double),
                 ("jacobi_scaling", C.c_int),
-                ("linear_solver", C.c_int)]
+                ("linear_solver", C.c_int),
+                ("policy_variant", C.c_int)]
 
 
 class Summary(C.Structure):

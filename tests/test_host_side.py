@@ -853,6 +853,15 @@ def test_graded_chunk_boundaries(host_math):
         else:
             assert b == equal(nt, (nt + nc - 1) // nc)
     assert graded(0, [1, 1]) == [0]
+    #  the fallback of a graded request on a small window is reported as a POSITIVE chunk count m (slslam_lba_batch_window_chunks);
+    # handed back as chunks_per_window = m it must cut the window the same way: per' = ceil(nt / m) with m = ceil(nt / per), per = ceil(nt / nc)
+    for nt in range(1, 260):
+        for nc in range(2, 41):
+            if nt >= 2 * nc:
+                continue
+            b = graded(nt, [1] * nc)
+            m = len(b) - 1
+            assert b == equal(nt, (nt + m - 1) // m), (nt, nc, b)
 
 
 def test_packer_layout_matches_the_golden_digest(host_math):
