@@ -116,12 +116,15 @@ typedef struct slslam_solver_options {
                                            rounds of the wave slots (what the automatic choice gives a batch that fills the chip) - so
                                            that 1 / 2 / 4 / 8-rank runs and one-window batches return identical bytes with no caller
                                            bookkeeping                                                                                  */
-  int    lba_precision;                 /* 0 (default): fp64 throughout, the reference's arithmetic.  1: MIXED - the per-observation
-                                           geometry, residuals and Jacobians of the elimination sweep in fp32, every accumulation (line
-                                           blocks, reduced camera system, gradients), the cost, the candidate evaluation and all
-                                           trust-region bookkeeping in fp64; observations whose line is badly conditioned in fp32
-                                           (|sin t| or the image-line normal's length small: reference src/lba_problem.h:63, :90) fall
-                                           back to fp64.  Opt-in; results within the tolerance stated in DESIGN.md of the fp64 path   */
+  int    lba_precision;                 /* 0 (default): fp64 throughout, the reference's arithmetic.  1: MIXED - the steady elimination
+                                           sweeps form the CAMERA Jacobian of an observation in packed fp32 (and park it as floats);
+                                           geometry, residuals, the LINE Jacobian, every block product and accumulation (line blocks,
+                                           reduced camera system, gradients), the cost, the candidate evaluation and all trust-region
+                                           bookkeeping stay fp64, as does the first sweep of a solve.  Which parts may be float was
+                                           measured (a float line Jacobian changes accept / reject decisions: its depth column carries
+                                           d = cos t / sin t, reference src/lba_problem.h:63).  Grouped sweep only (lba_elimination 0 or
+                                           4, at most 10 free cameras); opt-in; results within the tolerance stated in DESIGN.md 7e and
+                                           tests/test_gpu_lba.py::test_mixed_precision_solves of the fp64 path and of the oracle      */
 } slslam_solver_options;
 
 /* Fills every field with the configuration the reference runs (robust loss on, 10 iterations). */
