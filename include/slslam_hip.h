@@ -301,10 +301,15 @@ int slslam_po_solve(const slslam_po_graph* graph, const slslam_solver_options* o
 /* The symbolic analysis behind the structured pose-graph factorisation (host only, no device needed), for
  * inspection and tests: slot[N] = offset of each pose in the reduced vector (-1: the constant pose of edge 0 or a
  * pose no edge references), chains first, junction poses last; chain_start / chain_len / chain_left / chain_right
- * [*num_chains, capacity max_chains] describe the chains (left / right = slot of the junction at that end, -1 when
- * free).  Returns SLSLAM_ERR_INVALID_ARGUMENT on malformed graphs, SLSLAM_ERR_UNSUPPORTED if max_chains is too small. */
+ * [*num_chains, capacity max_chains] describe the chains (left / right = slot of what the chain ends at - a junction or, for a piece of a
+ * long path, a cut pose -, -1 when free).  Returns SLSLAM_ERR_INVALID_ARGUMENT on malformed graphs, SLSLAM_ERR_UNSUPPORTED if max_chains is too small. */
 int slslam_po_structure(const slslam_po_graph* graph, int* slot, int max_chains, int* num_chains, int* chain_start,
                         int* chain_len, int* chain_left, int* chain_right, int* num_chain_unknowns, int* num_unknowns);
+/* The chains come on two levels (a long path is cut into pieces of ~sqrt(longest path) poses by single cut poses; a path's cut poses form a
+ * chain of their own, eliminated after the pieces): how many of the chains the calling thread's last slslam_po_structure listed - the first
+ * ones - are level-1 chains (consecutive poses are graph neighbours); the others are level-2 chains (consecutive poses are cut poses of one
+ * path; left / right = the path's junctions). */
+int slslam_po_structure_level1(void);
 
 /* ------------------------------------------------------------------ RANSAC hypothesis scoring
  * (the per-frame cost centre next to the hot path.)

@@ -86,7 +86,7 @@ EXPORTS = [
     "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts", "slslam_lba_batch_window_chunks", "slslam_lba_batch_path", "slslam_lba_batch_elimination",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
-    "slslam_po_solve", "slslam_po_structure", "slslam_po_set_profiling", "slslam_po_last_timing", "slslam_debug_phase_cycles", "slslam_debug_read_cycles", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_release_cached_memory", "slslam_version", "slslam_status_string",
+    "slslam_po_solve", "slslam_po_structure", "slslam_po_structure_level1", "slslam_po_set_profiling", "slslam_po_last_timing", "slslam_debug_phase_cycles", "slslam_debug_read_cycles", "slslam_ransac_score", "slslam_ransac_generate", "slslam_ransac_motion", "slslam_ransac_motion_batch", "slslam_device_count", "slslam_release_cached_memory", "slslam_version", "slslam_status_string",
 ]
 
 _lib = None
@@ -524,7 +524,7 @@ def po_structure(g, max_chains=4096):
                                      _ip(ncu), _ip(nu)), "slslam_po_structure")
     k = int(nc[0])
     return {"slot": slot[:n], "chains": [tuple(int(a[c]) for a in arr) for c in range(k)],
-            "num_chain_unknowns": int(ncu[0]), "num_unknowns": int(nu[0])}
+            "num_chain_unknowns": int(ncu[0]), "num_unknowns": int(nu[0]), "level1_chains": int(lib().slslam_po_structure_level1())}
 
 
 def ransac_motion_batch(frames, baseline=0.12, error_thr=5.0 / 406.05, prob_free_outliers=0.999, max_trials=1000):

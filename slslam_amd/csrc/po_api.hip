@@ -38,7 +38,7 @@ enum { kMaxChain = 32 };
 // Output: slot[] (offset of each pose in the reduced vector: chains first, pose by pose along the
 // path; junctions last), the chain descriptors, n_chain = unknowns before the junction block.
 void order_chains_first(int N, int E, const int* p1, const int* p2, const std::vector<int>& used, int gauge,
-                        std::vector<int>& slot, std::vector<PoChain>& chains, int* n_chain, int* n_total) {
+                        std::vector<int>& slot, std::vector<PoChain>& chains, int* n_chain, int* n_total, int* n_level1) {
   std::vector<std::vector<int>> adj(N);
   auto add = [&](int a, int b) { for (int v : adj[a]) if (v == b) return; adj[a].push_back(b); };
   for (int e = 0; e < E; ++e) {
@@ -87,17 +87,49 @@ void order_chains_first(int N, int E, const int* p1, const int* p2, const std::v
     for (int v : adj[path.back()]) if (junction[v]) jr = v;
     if (jl >= 0 && jl == jr) { junction[path.back()] = 1; path.pop_back(); }
   }
-  // a chain is sequential: cut long ones into pieces of at most kMaxChain poses, the cut poses join the junctions
+  // A chain is sequential (one 6 x 6 step after the other, ~2 us each), so long paths are cut - on TWO levels since round 5: a path longer than
+  // s + 1 poses becomes pieces of s poses separated by single CUT poses (level-1 chains: their ends are cut poses or the path's junctions), and
+  // the cut poses of a path, in path order, are a chain of their own (level 2): eliminating the pieces leaves them coupled to each other and to
+  // the path's two junctions exactly as the poses of a chain are (the pieces' Schur complements land on the blocks (c_i, c_i), (c_i+1, c_i),
+  // (junction, c_1), (junction, c_m) - what k_po_chain_eliminate reads for a chain c_1 .. c_m).  The same two kernels run twice, level 1 then
+  // level 2 for the elimination, level 2 then level 1 for the substitution; the sequential depth of a path of L poses falls from min(L, 32) to
+  // about s + L / (s + 1), s ~ sqrt(longest path), and the cut poses no longer enlarge the dense junction block.  A level-2 chain longer than
+  // kMaxChain gives every (kMaxChain + 1)-th of its poses to the junctions, as long paths did before.
+  std::vector<char> cut(N, 0);
+  std::vector<std::vector<int>> level2;                  // cut poses of a path, in path order
+  std::vector<std::pair<int, int>> level2_ends;           // the junction POSES at the two ends (-1: none)
   {
+    size_t longest = 0;
+    for (auto& path : paths) longest = std::max(longest, path.size());
+    int sub = (int)std::lround(std::sqrt((double)longest));
+    sub = std::min((int)kMaxChain, std::max(4, sub));
+    if (const char* e = std::getenv("SLSLAM_PO_SUBCHAIN")) sub = std::min((int)kMaxChain, std::max(1, std::atoi(e)));      // (experiments)
     std::vector<std::vector<int>> pieces;
     for (auto& path : paths) {
+      int jl_pose = -1, jr_pose = -1;
+      for (int v : adj[path.front()]) if (junction[v]) jl_pose = v;
+      for (int v : adj[path.back()]) if (junction[v] && (path.size() > 1 || v != jl_pose)) jr_pose = v;
+      std::vector<int> cuts;
       size_t b = 0;
-      while (path.size() - b > (size_t)kMaxChain) {
-        pieces.emplace_back(path.begin() + b, path.begin() + b + kMaxChain);
-        junction[path[b + kMaxChain]] = 1;
-        b += kMaxChain + 1;
+      while (path.size() - b > (size_t)sub + 1) {        // (at least one pose is left behind the cut pose)
+        pieces.emplace_back(path.begin() + b, path.begin() + b + sub);
+        cuts.push_back(path[b + sub]);
+        b += (size_t)sub + 1;
       }
-      if (b < path.size()) pieces.emplace_back(path.begin() + b, path.end());
+      pieces.emplace_back(path.begin() + b, path.end());
+      // the level-2 chain, itself cut at kMaxChain poses: those poses are junctions proper
+      size_t c0 = 0;
+      int left = jl_pose;
+      while (cuts.size() - c0 > (size_t)kMaxChain) {
+        level2.emplace_back(cuts.begin() + c0, cuts.begin() + c0 + kMaxChain);
+        const int promoted = cuts[c0 + kMaxChain];
+        junction[promoted] = 1;
+        level2_ends.emplace_back(left, promoted);
+        left = promoted;
+        c0 += (size_t)kMaxChain + 1;
+      }
+      if (c0 < cuts.size()) { level2.emplace_back(cuts.begin() + c0, cuts.end()); level2_ends.emplace_back(left, jr_pose); }
+      for (const auto& l2 : level2) for (int v : l2) cut[v] = 1;      // (idempotent; the promoted poses are not in any level-2 chain)
     }
     paths.swap(pieces);
   }
@@ -108,18 +140,31 @@ void order_chains_first(int N, int E, const int* p1, const int* p2, const std::v
     for (int v : path) { slot[v] = n; n += 6; }
     chains.push_back(c);
   }
+  if (n_level1) *n_level1 = (int)paths.size();
+  for (auto& l2 : level2) {
+    PoChain c;
+    c.start = n; c.len = (int)l2.size(); c.jl = -1; c.jr = -1;
+    for (int v : l2) { slot[v] = n; n += 6; }
+    chains.push_back(c);
+  }
   *n_chain = n;
   for (int k = 0; k < N; ++k) if (isfree[k] && junction[k]) { slot[k] = n; n += 6; }
   *n_total = n;
+  auto end_like = [&](int v) { return junction[v] || cut[v]; };      // what a level-1 chain ends at
   for (size_t q = 0; q < paths.size(); ++q) {
     const auto& path = paths[q];
     PoChain& c = chains[q];
     if (path.size() == 1) {
-      for (int v : adj[path[0]]) if (junction[v]) { if (c.jl < 0) c.jl = slot[v]; else c.jr = slot[v]; }
+      for (int v : adj[path[0]]) if (end_like(v)) { if (c.jl < 0) c.jl = slot[v]; else c.jr = slot[v]; }
     } else {
-      for (int v : adj[path.front()]) if (junction[v]) c.jl = slot[v];
-      for (int v : adj[path.back()]) if (junction[v]) c.jr = slot[v];
+      for (int v : adj[path.front()]) if (end_like(v)) c.jl = slot[v];
+      for (int v : adj[path.back()]) if (end_like(v)) c.jr = slot[v];
     }
+  }
+  for (size_t q = 0; q < level2.size(); ++q) {
+    PoChain& c = chains[paths.size() + q];
+    c.jl = level2_ends[q].first >= 0 ? slot[level2_ends[q].first] : -1;
+    c.jr = level2_ends[q].second >= 0 ? slot[level2_ends[q].second] : -1;
   }
 }
 
@@ -217,11 +262,12 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   const bool f32 = opt.po_factor_fp32 != 0;
   const bool structured = !f32 && !opt.po_dense_factor;
   std::vector<PoChain> chains;
-  int n_chain = 0;                       // unknowns of the chain poses (ordered first)
+  int n_chain = 0;                       // unknowns of the chain poses (ordered first: level-1 chains, then the level-2 chains of cut poses)
+  int n_level1 = 0;                      // chains of the first level (listed first)
   if (!structured) {
     for (int k = 0; k < N; ++k) if (used[k] && k != gauge) { slot[k] = n; n += 6; }
   } else {
-    order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, gauge, slot, chains, &n_chain, &n);
+    order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, gauge, slot, chains, &n_chain, &n, &n_level1);
   }
   for (int e = 0; e < E; ++e) if (slot[g->pose_index_1[e]] >= 0 || slot[g->pose_index_2[e]] >= 0) ++kept;
   const int ld = ((n + 7) / 8) * 8 + 8;
@@ -247,7 +293,11 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   int arena_device = 0;
   const int nj = structured ? n - n_chain : 0;
   const int nblk_j = (nj + kNB - 1) / kNB;
-  const long long zero_items = (long long)E * 144 + (long long)nj * nj + n + 1;       // k_po_zero_structured
+  // what the level-1 eliminations ADD into - the blocks of the cut poses and of the junctions, among themselves - starts at zero: the square behind
+  // the level-1 unknowns (the dense factorisation reads the junction block of it)
+  const int n_l1 = (structured && n_level1 > 0) ? chains[(size_t)n_level1 - 1].start + 6 * chains[(size_t)n_level1 - 1].len : 0;
+  const int nz = structured ? n - n_l1 : 0;
+  const long long zero_items = (long long)E * 144 + (long long)nz * nz + n + 1;       // k_po_zero_structured
   const dim3 g_zero((unsigned)((zero_items + 255) / 256));
   const bool zero_small = structured && n > 0 && !std::getenv("SLSLAM_PO_FULL_MEMSET");
   int *d_p1 = nullptr, *d_p2 = nullptr, *d_slot = nullptr;
@@ -329,7 +379,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   // (structured: only what the linearisation adds into and the junction block are zeroed, by one small launch: k_po_zero_structured)
   if (zero_small) {
     PO_TRY(hipMemsetAsync(p.g, 0, sizeof(double) * ones.size(), 0));      // (once: the padding behind the n gradient entries)
-    hipLaunchKernelGGL(k_po_zero_structured, g_zero, dim3(256), 0, 0, p, n_chain);
+    hipLaunchKernelGGL(k_po_zero_structured, g_zero, dim3(256), 0, 0, p, n_l1);
   } else {
     PO_TRY(hipMemsetAsync(p.H, 0, hbytes, 0));
     PO_TRY(hipMemsetAsync(p.g, 0, sizeof(double) * ones.size(), 0));
@@ -343,7 +393,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
       PO_TRY(hipStreamSynchronize(0));
       if (hst.status != kRunning) break;
     }
-    if (zero_small) hipLaunchKernelGGL(k_po_zero_structured, g_zero, dim3(256), 0, 0, p, n_chain);
+    if (zero_small) hipLaunchKernelGGL(k_po_zero_structured, g_zero, dim3(256), 0, 0, p, n_l1);
     else {
       PO_TRY(hipMemsetAsync(p.H, 0, hbytes, 0));
       PO_TRY(hipMemsetAsync(p.g, 0, sizeof(double) * ones.size(), 0));
@@ -355,11 +405,14 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     stamp();
     if (structured) {
       // chains eliminated concurrently, then the dense MFMA Cholesky of the junction block only
-      if (!chains.empty()) hipLaunchKernelGGL(k_po_chain_eliminate, dim3((unsigned)chains.size()), dim3(64), 0, 0, p, (const PoChain*)d_chains);
+      const unsigned nc1 = (unsigned)n_level1, nc2 = (unsigned)(chains.size() - (size_t)n_level1);
+      if (nc1) hipLaunchKernelGGL(k_po_chain_eliminate, dim3(nc1), dim3(64), 0, 0, p, (const PoChain*)d_chains);
+      if (nc2) hipLaunchKernelGGL(k_po_chain_eliminate, dim3(nc2), dim3(64), 0, 0, p, (const PoChain*)(d_chains + nc1));      // the cut poses of every path
       double* Lf_j = d_Lf + (size_t)n_chain * ld + n_chain;          // the junction block's factor (same leading dimension)
       po_factor_dense<double>(pj, pj.H, Lf_j, d_linv, nblk_j);
       if (nj > 0) hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(1024), 0, 0, pj, (const double*)Lf_j, (const double*)d_linv);
-      if (!chains.empty()) hipLaunchKernelGGL(k_po_chain_backsub, dim3((unsigned)chains.size()), dim3(64), 0, 0, p, (const PoChain*)d_chains);
+      if (nc2) hipLaunchKernelGGL(k_po_chain_backsub, dim3(nc2), dim3(64), 0, 0, p, (const PoChain*)(d_chains + nc1));
+      if (nc1) hipLaunchKernelGGL(k_po_chain_backsub, dim3(nc1), dim3(64), 0, 0, p, (const PoChain*)d_chains);
     }
     if (!structured) {
       if (f32) po_factor_dense<float>(p, d_Hf, d_Lff, d_linvf, nblk);
@@ -425,6 +478,11 @@ done:
 }
 
 
+namespace { thread_local int g_last_level1 = 0; }
+/* (inspection, beside slslam_po_structure: how many of the chains it listed - the first ones - are level-1 chains; the rest are the level-2
+ * chains of cut poses) */
+extern "C" int slslam_po_structure_level1(void) { return g_last_level1; }
+
 extern "C" int slslam_po_structure(const slslam_po_graph* g, int* slot_out, int max_chains, int* num_chains, int* chain_start,
                                    int* chain_len, int* chain_left, int* chain_right, int* num_chain_unknowns, int* num_unknowns) {
   if (!g || !slot_out || !num_chains || g->num_poses < 0 || g->num_edges < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
@@ -438,7 +496,7 @@ extern "C" int slslam_po_structure(const slslam_po_graph* g, int* slot_out, int 
   for (int e = 0; e < E; ++e) { used[g->pose_index_1[e]] = 1; used[g->pose_index_2[e]] = 1; }
   std::vector<PoChain> chains;
   int n_chain = 0, n = 0;
-  if (E > 0) order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, g->pose_index_1[0], slot, chains, &n_chain, &n);
+  if (E > 0) order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, g->pose_index_1[0], slot, chains, &n_chain, &n, &g_last_level1);
   for (int k = 0; k < N; ++k) slot_out[k] = slot[k];
   *num_chains = (int)chains.size();
   if (num_chain_unknowns) *num_chain_unknowns = n_chain;

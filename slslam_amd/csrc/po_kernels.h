@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void k_po_linearise(PoPtrs p, int mode) {
 // pose blocks and their coupling (the same index rule as k_po_linearise), the junction block (the dense factorisation reads all of it),
 // the gradient and the cost - instead of a memset of the whole dense matrix (20 MB at 1554 unknowns, a third of a structured solve
 // in fill kernels).  Everything else the structured path reads from H it has written itself (k_po_chain_eliminate: factor and fill).
-__global__ __launch_bounds__(256) void k_po_zero_structured(PoPtrs p, int n_chain) {
+__global__ __launch_bounds__(256) void k_po_zero_structured(PoPtrs p, int n_chain /* unknowns of the level-1 chains: the square behind them is zeroed */) {
   if (p.st->status != kRunning) return;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long n_edge = (long long)p.E * 144;
