@@ -38,7 +38,7 @@ enum { kMaxChain = 32 };
 // Output: slot[] (offset of each pose in the reduced vector: chains first, pose by pose along the
 // path; junctions last), the chain descriptors, n_chain = unknowns before the junction block.
 void order_chains_first(int N, int E, const int* p1, const int* p2, const std::vector<int>& used, int gauge,
-                        std::vector<int>& slot, std::vector<PoChain>& chains, int* n_chain, int* n_total, int* n_level1) {
+                        std::vector<int>& slot, std::vector<PoChain>& chains, int* n_chain, int* n_total, std::vector<int>* level_counts) {
   std::vector<std::vector<int>> adj(N);
   auto add = [&](int a, int b) { for (int v : adj[a]) if (v == b) return; adj[a].push_back(b); };
   for (int e = 0; e < E; ++e) {
@@ -87,84 +87,71 @@ void order_chains_first(int N, int E, const int* p1, const int* p2, const std::v
     for (int v : adj[path.back()]) if (junction[v]) jr = v;
     if (jl >= 0 && jl == jr) { junction[path.back()] = 1; path.pop_back(); }
   }
-  // A chain is sequential (one 6 x 6 step after the other, ~2 us each), so long paths are cut - on TWO levels since round 5: a path longer than
-  // s + 1 poses becomes pieces of s poses separated by single CUT poses (level-1 chains: their ends are cut poses or the path's junctions), and
-  // the cut poses of a path, in path order, are a chain of their own (level 2): eliminating the pieces leaves them coupled to each other and to
+  // A chain is sequential (one 6 x 6 step after the other, ~2 us each), so long paths are cut - on several LEVELS since round 5: a path of L poses
+  // becomes pieces of s poses separated by single CUT poses (level-1 chains: their ends are cut poses or the path's junctions), and the cut
+  // poses of a path, in path order, are a chain of their own on the next level: eliminating the pieces leaves them coupled to each other and to
   // the path's two junctions exactly as the poses of a chain are (the pieces' Schur complements land on the blocks (c_i, c_i), (c_i+1, c_i),
-  // (junction, c_1), (junction, c_m) - what k_po_chain_eliminate reads for a chain c_1 .. c_m).  The same two kernels run twice, level 1 then
-  // level 2 for the elimination, level 2 then level 1 for the substitution; the sequential depth of a path of L poses falls from min(L, 32) to
-  // about s + L / (s + 1), s ~ sqrt(longest path), and the cut poses no longer enlarge the dense junction block.  A level-2 chain longer than
-  // kMaxChain gives every (kMaxChain + 1)-th of its poses to the junctions, as long paths did before.
-  std::vector<char> cut(N, 0);
-  std::vector<std::vector<int>> level2;                  // cut poses of a path, in path order
-  std::vector<std::pair<int, int>> level2_ends;           // the junction POSES at the two ends (-1: none)
+  // (junction, c_1), (junction, c_m) - what k_po_chain_eliminate reads for a chain c_1 .. c_m) - so that chain is cut the same way, and so on.
+  // The same two kernels run once per level, upwards for the elimination, downwards for the substitution; s ~ L^(1/levels) with up to three
+  // levels, i.e. a sequential depth of ~3 L^(1/3) steps for a long path instead of min(L, 32), and the cut poses no longer enlarge the dense
+  // junction block (until round 5 a path was cut every 32 poses and the cut poses joined the junctions: 26 junction poses instead of 10
+  // for the 260-pose bench graph - a second 64-wide block step of the dense factorisation in every iteration).
+  struct Piece { std::vector<int> poses; int left, right; };      // left / right: the POSE the piece ends at (-1: a free end)
+  std::vector<std::vector<Piece>> levels;
   {
-    size_t longest = 0;
-    for (auto& path : paths) longest = std::max(longest, path.size());
-    int sub = (int)std::lround(std::sqrt((double)longest));
-    sub = std::min((int)kMaxChain, std::max(4, sub));
-    if (const char* e = std::getenv("SLSLAM_PO_SUBCHAIN")) sub = std::min((int)kMaxChain, std::max(1, std::atoi(e)));      // (experiments)
-    std::vector<std::vector<int>> pieces;
+    static const char* env_sub = std::getenv("SLSLAM_PO_SUBCHAIN");        // (experiments: piece length of the first level)
+    auto piece_len = [&](size_t L, int level) -> size_t {
+      if (level == 0 && env_sub) return (size_t)std::min((int)kMaxChain, std::max(1, std::atoi(env_sub)));
+      const int m = L <= 8 ? 1 : (L <= 72 ? 2 : 3);                    // levels this chain is spread over
+      if (m == 1) return L;
+      return (size_t)std::min((int)kMaxChain, std::max(3, (int)std::lround(std::pow((double)L, 1.0 / m))));
+    };
+    struct Job { std::vector<int> seq; int left, right, level; };
+    std::vector<Job> jobs;
     for (auto& path : paths) {
       int jl_pose = -1, jr_pose = -1;
       for (int v : adj[path.front()]) if (junction[v]) jl_pose = v;
       for (int v : adj[path.back()]) if (junction[v] && (path.size() > 1 || v != jl_pose)) jr_pose = v;
+      jobs.push_back(Job{ path, jl_pose, jr_pose, 0 });
+    }
+    for (size_t q = 0; q < jobs.size(); ++q) {                         // (jobs grows: a cut chain is the next level's job)
+      const Job job = jobs[q];
+      if (levels.size() <= (size_t)job.level) levels.resize((size_t)job.level + 1);
+      const size_t sub = std::max<size_t>(1, piece_len(job.seq.size(), job.level));
       std::vector<int> cuts;
       size_t b = 0;
-      while (path.size() - b > (size_t)sub + 1) {        // (at least one pose is left behind the cut pose)
-        pieces.emplace_back(path.begin() + b, path.begin() + b + sub);
-        cuts.push_back(path[b + sub]);
-        b += (size_t)sub + 1;
+      int left = job.left;
+      while (job.seq.size() - b > sub + 1 && (int)levels.size() < 8) {   // (at least one pose is left behind the cut pose)
+        levels[(size_t)job.level].push_back(Piece{ std::vector<int>(job.seq.begin() + b, job.seq.begin() + b + sub), left, job.seq[b + sub] });
+        left = job.seq[b + sub];
+        cuts.push_back(left);
+        b += sub + 1;
       }
-      pieces.emplace_back(path.begin() + b, path.end());
-      // the level-2 chain, itself cut at kMaxChain poses: those poses are junctions proper
-      size_t c0 = 0;
-      int left = jl_pose;
-      while (cuts.size() - c0 > (size_t)kMaxChain) {
-        level2.emplace_back(cuts.begin() + c0, cuts.begin() + c0 + kMaxChain);
-        const int promoted = cuts[c0 + kMaxChain];
-        junction[promoted] = 1;
-        level2_ends.emplace_back(left, promoted);
-        left = promoted;
-        c0 += (size_t)kMaxChain + 1;
-      }
-      if (c0 < cuts.size()) { level2.emplace_back(cuts.begin() + c0, cuts.end()); level2_ends.emplace_back(left, jr_pose); }
-      for (const auto& l2 : level2) for (int v : l2) cut[v] = 1;      // (idempotent; the promoted poses are not in any level-2 chain)
+      // (the rest of the chain; longer than kMaxChain only when the level cap above was reached - then it is simply a long chain)
+      levels[(size_t)job.level].push_back(Piece{ std::vector<int>(job.seq.begin() + b, job.seq.end()), left, job.right });
+      if (!cuts.empty()) jobs.push_back(Job{ cuts, job.left, job.right, job.level + 1 });
     }
-    paths.swap(pieces);
   }
   int n = 0;
-  for (auto& path : paths) {
-    PoChain c;
-    c.start = n; c.len = (int)path.size(); c.jl = -1; c.jr = -1;
-    for (int v : path) { slot[v] = n; n += 6; }
-    chains.push_back(c);
-  }
-  if (n_level1) *n_level1 = (int)paths.size();
-  for (auto& l2 : level2) {
-    PoChain c;
-    c.start = n; c.len = (int)l2.size(); c.jl = -1; c.jr = -1;
-    for (int v : l2) { slot[v] = n; n += 6; }
-    chains.push_back(c);
-  }
+  for (const auto& lv : levels)
+    for (const Piece& pc : lv) {
+      PoChain c;
+      c.start = n; c.len = (int)pc.poses.size(); c.jl = -1; c.jr = -1;
+      for (int v : pc.poses) { slot[v] = n; n += 6; }
+      chains.push_back(c);
+    }
+  if (level_counts) { level_counts->clear(); for (const auto& lv : levels) level_counts->push_back((int)lv.size()); }
   *n_chain = n;
   for (int k = 0; k < N; ++k) if (isfree[k] && junction[k]) { slot[k] = n; n += 6; }
   *n_total = n;
-  auto end_like = [&](int v) { return junction[v] || cut[v]; };      // what a level-1 chain ends at
-  for (size_t q = 0; q < paths.size(); ++q) {
-    const auto& path = paths[q];
-    PoChain& c = chains[q];
-    if (path.size() == 1) {
-      for (int v : adj[path[0]]) if (end_like(v)) { if (c.jl < 0) c.jl = slot[v]; else c.jr = slot[v]; }
-    } else {
-      for (int v : adj[path.front()]) if (end_like(v)) c.jl = slot[v];
-      for (int v : adj[path.back()]) if (end_like(v)) c.jr = slot[v];
-    }
-  }
-  for (size_t q = 0; q < level2.size(); ++q) {
-    PoChain& c = chains[paths.size() + q];
-    c.jl = level2_ends[q].first >= 0 ? slot[level2_ends[q].first] : -1;
-    c.jr = level2_ends[q].second >= 0 ? slot[level2_ends[q].second] : -1;
+  {
+    size_t q = 0;
+    for (const auto& lv : levels)
+      for (const Piece& pc : lv) {
+        PoChain& c = chains[q++];
+        c.jl = pc.left >= 0 ? slot[pc.left] : -1;
+        c.jr = pc.right >= 0 ? slot[pc.right] : -1;
+      }
   }
 }
 
@@ -263,11 +250,11 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   const bool structured = !f32 && !opt.po_dense_factor;
   std::vector<PoChain> chains;
   int n_chain = 0;                       // unknowns of the chain poses (ordered first: level-1 chains, then the level-2 chains of cut poses)
-  int n_level1 = 0;                      // chains of the first level (listed first)
+  std::vector<int> level_counts;         // chains per level (listed level after level)
   if (!structured) {
     for (int k = 0; k < N; ++k) if (used[k] && k != gauge) { slot[k] = n; n += 6; }
   } else {
-    order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, gauge, slot, chains, &n_chain, &n, &n_level1);
+    order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, gauge, slot, chains, &n_chain, &n, &level_counts);
   }
   for (int e = 0; e < E; ++e) if (slot[g->pose_index_1[e]] >= 0 || slot[g->pose_index_2[e]] >= 0) ++kept;
   const int ld = ((n + 7) / 8) * 8 + 8;
@@ -295,6 +282,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   const int nblk_j = (nj + kNB - 1) / kNB;
   // what the level-1 eliminations ADD into - the blocks of the cut poses and of the junctions, among themselves - starts at zero: the square behind
   // the level-1 unknowns (the dense factorisation reads the junction block of it)
+  const int n_level1 = level_counts.empty() ? 0 : level_counts[0];
   const int n_l1 = (structured && n_level1 > 0) ? chains[(size_t)n_level1 - 1].start + 6 * chains[(size_t)n_level1 - 1].len : 0;
   const int nz = structured ? n - n_l1 : 0;
   const long long zero_items = (long long)E * 144 + (long long)nz * nz + n + 1;       // k_po_zero_structured
@@ -405,14 +393,23 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     stamp();
     if (structured) {
       // chains eliminated concurrently, then the dense MFMA Cholesky of the junction block only
-      const unsigned nc1 = (unsigned)n_level1, nc2 = (unsigned)(chains.size() - (size_t)n_level1);
-      if (nc1) hipLaunchKernelGGL(k_po_chain_eliminate, dim3(nc1), dim3(64), 0, 0, p, (const PoChain*)d_chains);
-      if (nc2) hipLaunchKernelGGL(k_po_chain_eliminate, dim3(nc2), dim3(64), 0, 0, p, (const PoChain*)(d_chains + nc1));      // the cut poses of every path
+      {
+        size_t off = 0;                                                // level after level: the pieces, then the chains of their cut poses, ...
+        for (int cnt : level_counts) {
+          if (cnt > 0) hipLaunchKernelGGL(k_po_chain_eliminate, dim3((unsigned)cnt), dim3(64), 0, 0, p, (const PoChain*)(d_chains + off));
+          off += (size_t)cnt;
+        }
+      }
       double* Lf_j = d_Lf + (size_t)n_chain * ld + n_chain;          // the junction block's factor (same leading dimension)
       po_factor_dense<double>(pj, pj.H, Lf_j, d_linv, nblk_j);
       if (nj > 0) hipLaunchKernelGGL(k_po_trisolve<double>, dim3(1), dim3(1024), 0, 0, pj, (const double*)Lf_j, (const double*)d_linv);
-      if (nc2) hipLaunchKernelGGL(k_po_chain_backsub, dim3(nc2), dim3(64), 0, 0, p, (const PoChain*)(d_chains + nc1));
-      if (nc1) hipLaunchKernelGGL(k_po_chain_backsub, dim3(nc1), dim3(64), 0, 0, p, (const PoChain*)d_chains);
+      {
+        size_t off = chains.size();                                    // ... and back down
+        for (size_t lv = level_counts.size(); lv-- > 0;) {
+          off -= (size_t)level_counts[lv];
+          if (level_counts[lv] > 0) hipLaunchKernelGGL(k_po_chain_backsub, dim3((unsigned)level_counts[lv]), dim3(64), 0, 0, p, (const PoChain*)(d_chains + off));
+        }
+      }
     }
     if (!structured) {
       if (f32) po_factor_dense<float>(p, d_Hf, d_Lff, d_linvf, nblk);
@@ -496,7 +493,9 @@ extern "C" int slslam_po_structure(const slslam_po_graph* g, int* slot_out, int 
   for (int e = 0; e < E; ++e) { used[g->pose_index_1[e]] = 1; used[g->pose_index_2[e]] = 1; }
   std::vector<PoChain> chains;
   int n_chain = 0, n = 0;
-  if (E > 0) order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, g->pose_index_1[0], slot, chains, &n_chain, &n, &g_last_level1);
+  std::vector<int> lc;
+  if (E > 0) order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, g->pose_index_1[0], slot, chains, &n_chain, &n, &lc);
+  g_last_level1 = lc.empty() ? 0 : lc[0];
   for (int k = 0; k < N; ++k) slot_out[k] = slot[k];
   *num_chains = (int)chains.size();
   if (num_chain_unknowns) *num_chain_unknowns = n_chain;

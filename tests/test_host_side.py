@@ -736,15 +736,22 @@ def _check_po_structure(g, st):
             adj[a].add(b); adj[b].add(a)
     in_chain = {}
     covered = 0
+    n1 = st["level1_chains"]
     for ci, (start, ln, left, right) in enumerate(st["chains"]):
-        assert 1 <= ln <= 32 and start == covered                      # chains are laid out back to back, cut at 32 poses
+        assert 1 <= ln <= 32 and start == covered                      # chains are laid out back to back, level after level; at most 32 poses each
         covered += 6 * ln
         poses = [pose_of[start + 6 * i] for i in range(ln)]
+        for j in (left, right):
+            assert j < 0 or j >= start + 6 * ln                         # what a chain ends at comes later in the ordering (a cut pose of a higher level or a junction)
+        assert left < 0 or left != right
         for i, v in enumerate(poses):
+            assert v not in in_chain
             in_chain[v] = ci
+            if ci >= n1:
+                continue                                                # a chain of cut poses: consecutive poses are joined by a piece, not by an edge
             nb = set(adj[v])
             if i > 0:
-                assert poses[i - 1] in nb; nb.discard(poses[i - 1])     # consecutive poses of a chain are connected
+                assert poses[i - 1] in nb; nb.discard(poses[i - 1])     # consecutive poses of a level-1 chain are connected
             if i + 1 < ln:
                 assert poses[i + 1] in nb; nb.discard(poses[i + 1])
             ends = set()
@@ -752,11 +759,18 @@ def _check_po_structure(g, st):
                 ends.add(pose_of[left])
             if i == ln - 1 and right >= 0:
                 ends.add(pose_of[right])
-            assert nb == ends, (v, nb, ends)                            # every other neighbour is the junction at that end
-        for j in (left, right):
-            assert j < 0 or j >= st["num_chain_unknowns"]               # junction slots come after all chain slots
-        assert left < 0 or left != right
+            assert nb == ends, (v, nb, ends)                            # every other neighbour is what the chain ends at on that side
     assert covered == st["num_chain_unknowns"]
+    # the poses of the higher-level chains are cut poses: each is the end of a chain of a lower level, and has exactly two graph neighbours
+    ends_of_lower = {}
+    for ci, (start, ln, left, right) in enumerate(st["chains"]):
+        for j in (left, right):
+            if 0 <= j < st["num_chain_unknowns"]:
+                ends_of_lower.setdefault(pose_of[j], []).append(ci)
+    for ci, (start, ln, left, right) in enumerate(st["chains"][n1:], start=n1):
+        for i in range(ln):
+            v = pose_of[start + 6 * i]
+            assert len(adj[v]) == 2 and v in ends_of_lower and all(c < ci for c in ends_of_lower[v]), (v, ci)
     for k in range(N):                                                  # what is not on a chain is a junction
         if free[k] and k not in in_chain:
             assert slot[k] >= st["num_chain_unknowns"]
@@ -781,8 +795,18 @@ def test_po_structure_topologies():
         cases.append(graph(n, [e for e in extra if e[1] - e[0] > 1]))
     for g in cases:
         _check_po_structure(g, capi.po_structure(g))
+    # a bare path of 299 free poses: three levels of chains (pieces of ~299^(1/3) poses, the chains of their cut poses), NO junction block, and
+    # a sequential depth - the longest chain of every level, added up - of about 3 x 299^(1/3) steps (until round 5: ten chains of 32 + 9 junction poses)
     st = capi.po_structure(graph(300, []))
-    assert len(st["chains"]) == 10 and st["num_unknowns"] - st["num_chain_unknowns"] == 6 * 9      # 299 free poses: cut every 32
+    assert st["num_unknowns"] == st["num_chain_unknowns"] == 6 * 299
+    n1 = st["level1_chains"]
+    lens1 = [c[1] for c in st["chains"][:n1]]
+    assert max(lens1) <= 8 and n1 >= 30
+    upper = [c[1] for c in st["chains"][n1:]]
+    assert upper and sum(upper) == 299 - sum(lens1) and max(upper) <= 8
+    # the bench graph: its 8 loop closures leave 10 junction poses - one 64-wide block of the dense factorisation
+    st = capi.po_structure(synth.make_pose_graph(7, num_poses=260, num_loops=8))
+    assert st["num_unknowns"] - st["num_chain_unknowns"] == 60
     # malformed graphs
     bad = graph(5, [])
     bad["pose_index_2"] = bad["pose_index_2"].copy(); bad["pose_index_2"][1] = 7
