@@ -325,14 +325,18 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
     s0 = st.stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tick = []
+    tick, marks = [], []
     for k in range(batches_timed):
+        marks.append(time.perf_counter())           # a batch PERIOD: collect of the batch `depth` back + submit of this one
         if k >= depth:
             st.collect(tick[k - depth], want_summaries=False)
         tick.append(st.submit(sets[depth + 1 + k]))
+    marks.append(time.perf_counter())
     for k in range(max(0, batches_timed - depth), batches_timed):
         st.collect(tick[k], want_summaries=False)
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0                   # ... and `value` also pays for draining the last `depth` batches
+    periods = sorted(b - a for a, b in zip(marks[depth:-1], marks[depth + 1:]))
+    steady = periods[len(periods) // 2] if periods else None
     s1 = st.stats()
     its = s1["lm_iterations"] - s0["lm_iterations"]
     nwin = s1["windows"] - s0["windows"]
@@ -350,6 +354,8 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
     out = {"value": its / dt, "unit": "LM iterations/s", "ms_per_batch": 1e3 * dt / batches_timed, "windows_per_batch": B,
            "batches_timed": batches_timed, "depth": depth, "host_threads": s1["host_threads"],
            "fraction_of_resident": (its / dt) / resident_value if resident_value else None,
+           "steady_ms_per_batch": 1e3 * steady if steady else None,           # median period between submits once the pipeline is full (a long stream's rate)
+           "steady_value": (its / batches_timed) / steady if steady else None,
            "refills": s1["refills"] - s0["refills"], "rebuilds": s1["builds"] - s0["builds"],
            "host_ms_per_window_wall": (s1["ms_submit"] - s0["ms_submit"]) / max(nwin, 1),
            "host_thread_ms_per_window_upper_bound": (s1["ms_submit"] - s0["ms_submit"]) * s1["host_threads"] / max(nwin, 1),
