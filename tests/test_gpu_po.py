@@ -133,12 +133,13 @@ def _add_edges(g, pairs, rng):
                 constraints=np.array([ed[k] for k in keys]))
 
 
-@pytest.mark.parametrize("shape", ["single_chain", "ring", "two_ends_one_junction", "hub", "long_chains", "dense_loops", "two_poses"])
+@pytest.mark.parametrize("shape", ["single_chain", "ring", "two_ends_one_junction", "hub", "long_chains", "dense_loops", "two_poses", "three_levels", "two_levels_two_paths"])
 def test_po_structured_factorisation_topologies(hip, oracle, shape):
     """The default factorisation eliminates chains of poses concurrently and factors only the junction poses
     densely.  Every topology class of the symbolic analysis (free-ended chain, junction-free cycle, chain
     returning to its junction, high-degree junction, chains longer than the cut length, many loop closures)
-    must give what the dense factorisation of the whole matrix and the oracle give."""
+    must give what the dense factorisation of the whole matrix and the oracle give.  Round 5: long paths are cut on several levels (the cut
+    poses of a path are a chain of the next level): the last two shapes."""
     rng = np.random.default_rng(11)
     if shape == "single_chain":
         g = synth.make_pose_graph(21, num_poses=50, num_loops=0)
@@ -153,6 +154,14 @@ def test_po_structured_factorisation_topologies(hip, oracle, shape):
         g = synth.make_pose_graph(25, num_poses=120, num_loops=2)
     elif shape == "dense_loops":
         g = _add_edges(synth.make_pose_graph(26, num_poses=60, num_loops=0), [(i, i + 7) for i in range(1, 50, 3)], rng)
+    elif shape == "three_levels":              # (round 5) one path of ~290 poses between two junctions: pieces, chains of cut poses, a chain of THEIR cut poses
+        g = _add_edges(synth.make_pose_graph(28, num_poses=300, num_loops=0), [(4, 296), (2, 298)], rng)
+        st = hip.po_structure(g)
+        assert len(st["chains"]) - st["level1_chains"] >= 7 and max(c[1] for c in st["chains"]) <= 8
+    elif shape == "two_levels_two_paths":      # two paths of ~50 poses (two levels each) and short ones around them
+        g = _add_edges(synth.make_pose_graph(29, num_poses=120, num_loops=0), [(5, 60), (8, 115), (60, 115)], rng)
+        st = hip.po_structure(g)
+        assert len(st["chains"]) > st["level1_chains"]
     else:
         g = synth.make_pose_graph(27, num_poses=2, num_loops=0)
         g["parameters"] = g["parameters"] + np.r_[np.zeros(6), rng.normal(0, 1e-2, 6)]
