@@ -305,10 +305,10 @@ int slslam_po_solve(const slslam_po_graph* graph, const slslam_solver_options* o
  * long path, a cut pose -, -1 when free).  Returns SLSLAM_ERR_INVALID_ARGUMENT on malformed graphs, SLSLAM_ERR_UNSUPPORTED if max_chains is too small. */
 int slslam_po_structure(const slslam_po_graph* graph, int* slot, int max_chains, int* num_chains, int* chain_start,
                         int* chain_len, int* chain_left, int* chain_right, int* num_chain_unknowns, int* num_unknowns);
-/* The chains come on two levels (a long path is cut into pieces of ~sqrt(longest path) poses by single cut poses; a path's cut poses form a
- * chain of their own, eliminated after the pieces): how many of the chains the calling thread's last slslam_po_structure listed - the first
- * ones - are level-1 chains (consecutive poses are graph neighbours); the others are level-2 chains (consecutive poses are cut poses of one
- * path; left / right = the path's junctions). */
+/* The chains come on several levels (a long path is cut into pieces of ~L^(1/levels) poses by single cut poses; a path's cut poses form a
+ * chain of the next level, eliminated after the pieces, and so on - up to three levels): how many of the chains the calling thread's last
+ * slslam_po_structure listed - the first ones - are level-1 chains (consecutive poses are graph neighbours); the others are higher-level
+ * chains (consecutive poses are cut poses of one path; left / right = a cut pose of a still higher level or the path's junction). */
 int slslam_po_structure_level1(void);
 
 /* ------------------------------------------------------------------ RANSAC hypothesis scoring

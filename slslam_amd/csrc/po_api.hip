@@ -249,7 +249,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   const bool f32 = opt.po_factor_fp32 != 0;
   const bool structured = !f32 && !opt.po_dense_factor;
   std::vector<PoChain> chains;
-  int n_chain = 0;                       // unknowns of the chain poses (ordered first: level-1 chains, then the level-2 chains of cut poses)
+  int n_chain = 0;                       // unknowns of the chain poses (ordered first: level-1 chains, then the chains of cut poses, level after level)
   std::vector<int> level_counts;         // chains per level (listed level after level)
   if (!structured) {
     for (int k = 0; k < N; ++k) if (used[k] && k != gauge) { slot[k] = n; n += 6; }
