@@ -490,7 +490,7 @@ def main():
     ap.add_argument("--no-result-check", action="store_true", help="skip the cross-rank bitwise check of the results (outside the timed region)")
     ap.add_argument("--stream-depth", type=int, default=3, help="batches in flight in the streamed leg")
     ap.add_argument("--no-streamed", action="store_true", help="skip the streamed leg (config 4 as a stream of host-side windows)")
-    ap.add_argument("--stream-batches", type=int, default=16, help="timed batches of the streamed leg")
+    ap.add_argument("--stream-batches", type=int, default=32, help="timed batches of the streamed leg (the drain of the last `depth` batches is inside the timed region: the more batches, the closer to a long stream)")
     ap.add_argument("--host-threads", type=int, default=0, help="host threads of the streamed leg (0 = up to 16)")
     ap.add_argument("--streams", type=int, default=1,
                     help="the rank's windows are split into this many batches on separate HIP streams, so that the "
