@@ -681,7 +681,7 @@ int device_init_after_upload(slslam_lba_batch* b, hipStream_t s) {
   const long long nt = b->used_tiles;
   if (nt > 0 && !b->big_mode)
     hipLaunchKernelGGL(k_build_lane_ctx, dim3((unsigned)((nt * 64 + 255) / 256)), dim3(256), 0, s, b->ptrs, (int)nt, b->d_lane_ctx.p);
-  const long long total = 6LL * b->ncam + 4LL * b->nline + b->ptrs.nwin;      // one thread per parameter / per window state
+  const long long total = 6LL * b->ncam + (long long)b->nline + b->ptrs.nwin;      // one thread per line / camera parameter / window state
   if (total > 0) hipLaunchKernelGGL(k_reset, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b->ptrs, b->pol);
   HIP_TRY(hipGetLastError());
   return SLSLAM_OK;
@@ -1098,7 +1098,7 @@ int enqueue_solve(slslam_lba_batch* b, hipStream_t s, bool prof, bool capturing 
     __VA_ARGS__;                                           \
     if ((rc = L.end())) return rc;                         \
   } while (0)
-  if (b->nline > 0) LAUNCH(FAM_TRIG, hipLaunchKernelGGL(k_line_trig, g_line, blk256, 0, s, p, 0));
+  // (the sin / cos table of the accepted line parameters is k_reset's: every solve that has anything to do follows one - finalize, refill or reset)
   if (b->fused_motion_only && !b->big_mode) {
     LAUNCH(FAM_LIN, hipLaunchKernelGGL(k_motion_only, g_win, blk64, b->lds_motion_only, s, p, pol));
     HIP_TRY(hipGetLastError());
@@ -1277,7 +1277,7 @@ extern "C" int slslam_lba_batch_reset(slslam_lba_batch* b, void* stream) {
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
   if (b->part[0]) { b->downloaded = false; return on_both_parts(b, s, [](slslam_lba_batch* pb, void* st) { return slslam_lba_batch_reset(pb, st); }); }
-  const long long total = 6LL * b->ncam + 4LL * b->nline + b->ptrs.nwin;      // one thread per parameter / per window state
+  const long long total = 6LL * b->ncam + (long long)b->nline + b->ptrs.nwin;      // one thread per line / camera parameter / window state
   if (total > 0)
     hipLaunchKernelGGL(k_reset, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b->ptrs, b->pol);
   HIP_TRY(hipGetLastError());

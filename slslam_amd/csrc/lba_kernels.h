@@ -2208,14 +2208,25 @@ __global__ __launch_bounds__(64) void k_debug_linearise(BatchPtrs p, Policy pol,
 // Restores the initial parameters and LM state of every window (repeated solves of the same
 // inputs).  lane <-> parameter block / window.
 __global__ __launch_bounds__(256) void k_reset(BatchPtrs p, Policy pol) {
-  // thread <-> one parameter (both buffers), four threads per line / six per camera: coalesced reads, 32 / 48-byte runs written
+  // thread <-> one LINE (its whole record in the accepted buffer - the four parameters and their sin / cos table, what k_line_trig used to add
+  // in a launch of its own at the start of every solve - and the parameters in the candidate buffer: consecutive threads write consecutive 88-byte
+  // records, whole cache lines instead of 32-byte pieces of them: 157 + 88 us -> one launch), then one thread per camera parameter, per window state
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long ncp = 6LL * p.ncam, nlp = 4LL * p.nline;
+  const long long ncp = 6LL * p.ncam, nlp = (long long)p.nline;
   if (i < nlp) {
-    const long long ls = i >> 2;
-    const int a = (int)(i & 3);
-    const double v = p.line_u0[i];
-    p.line_x[line_rec(p, ls, 0) + a] = v; p.line_x[line_rec(p, ls, 1) + a] = v;
+    const long long ls = i;
+    if (p.line_win[ls] >= 0) {                           // (a record beyond the batch's lines - room for refills - is left alone)
+      const double2* u0 = reinterpret_cast<const double2*>(p.line_u0 + 4 * ls);
+      const double2 a01 = u0[0], a23 = u0[1];
+      double u[4] = { a01.x, a01.y, a23.x, a23.y }, trig[7];
+      line_trig<double>(u, trig);
+      double* r0 = p.line_x + line_rec(p, ls, 0);       // (88-byte records: 8-byte aligned only)
+      double* r1 = p.line_x + line_rec(p, ls, 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { r0[q] = u[q]; r1[q] = u[q]; }
+#pragma unroll
+      for (int q = 0; q < 7; ++q) r0[4 + q] = trig[q];
+    }
   } else if (i < nlp + ncp) {
     const long long q = i - nlp, c = q / 6;
     const double v = p.cam_x0[q];

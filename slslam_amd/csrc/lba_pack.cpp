@@ -7,6 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 // host-side phase clock of pack_window (tools/pack_bench.cpp -DSLS_PACK_TIMING): where a window's pack time goes
 #if defined(SLS_PACK_TIMING)
@@ -337,6 +340,12 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
   {
     double* pl[4] = { P.ob.data(), P.ob.data() + 2 * (size_t)M, P.ob.data() + 4 * (size_t)M, P.ob.data() + 6 * (size_t)M };
     if (ob_dest) for (int q = 0; q < 4; ++q) pl[q] = ob_dest->plane[q];
+    // a refill packs straight into the pinned host image the copy engine reads next: nobody on the host reads these planes again, so they are
+    // written past the caches (when the four planes are 16-byte aligned, which the image's are)
+    bool stream_out = ob_dest != nullptr;
+    for (int q = 0; q < 4; ++q) if (reinterpret_cast<uintptr_t>(pl[q]) & 15u) stream_out = false;
+    static const bool no_stream = std::getenv("SLSLAM_PACK_NO_STREAMING_STORES") != nullptr;      // (measurement switch)
+    if (no_stream) stream_out = false;
     uint64_t nonfinite = 0;
     for (int o = 0; o < M; ++o) {
       const int i = P.ob_orig[o];
@@ -345,6 +354,11 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
       if (o + 16 < M) { const double* nx = w->observations + 8 * (size_t)P.ob_orig[o + 16]; __builtin_prefetch(nx); __builtin_prefetch(nx + 7); }
       P.ob_cam[o] = w->camera_index[i];
       const double* src = w->observations + 8 * (size_t)i;
+#if defined(__SSE2__)
+      if (stream_out) {                             // (16-byte non-temporal stores: four write-combining streams, no line is read in order to be overwritten)
+        for (int q = 0; q < 4; ++q) _mm_stream_pd(pl[q] + 2 * (size_t)o, _mm_loadu_pd(src + 2 * q));
+      } else
+#endif
       for (int q = 0; q < 4; ++q) { pl[q][2 * (size_t)o] = src[2 * q]; pl[q][2 * (size_t)o + 1] = src[2 * q + 1]; }
       for (int q = 0; q < 8; ++q) {               // exponent field all ones <=> NaN / Inf (branch-free, as all_finite)
         uint64_t x;
@@ -353,6 +367,9 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
       }
       if (!(cam_const[w->camera_index[i]] && line_const[w->line_index[i]])) ++P.nkept;
     }
+#if defined(__SSE2__)
+    if (stream_out) _mm_sfence();
+#endif
     if (nonfinite) return SLSLAM_ERR_INVALID_ARGUMENT;
   }
 
