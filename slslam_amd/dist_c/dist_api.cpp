@@ -106,6 +106,12 @@ extern "C" int slslam_dist_solve(slslam_dist* d, const slslam_lba_window* w, int
   double local[3] = { 0.0, 0.0, 0.0 };
   long long my_count = 0;
   slslam_lba_batch* b = nullptr;
+  // (every way out of this function - the error returns of the macros included - first waits for the stream, whose asynchronous copies read and
+  // write this frame's variables and the caller's arrays, and then gives the batch back)
+  struct Guard {
+    slslam_lba_batch*& b; hipStream_t s;
+    ~Guard() { if (s) (void)hipStreamSynchronize(s); if (b) { slslam_lba_batch_destroy(b); b = nullptr; } }
+  } guard{ b, d->stream };
   int rc = SLSLAM_OK;
   if (n > 0) {
     if ((rc = slslam_lba_batch_create(d->device, &b)) != SLSLAM_OK) return rc;
@@ -151,6 +157,5 @@ extern "C" int slslam_dist_solve(slslam_dist* d, const slslam_lba_window* w, int
     if (count_per_rank) DIST_HIP(hipMemcpyAsync(count_per_rank, d->d_counts, (size_t)d->world * sizeof(long long), hipMemcpyDeviceToHost, d->stream));
   }
   DIST_HIP(hipStreamSynchronize(d->stream));
-  if (b) slslam_lba_batch_destroy(b);
   return rc;
 }
