@@ -2,6 +2,8 @@
 object on top of it (slslam_lba_stream_*) - what a caller that hands over five host arrays per window (reference
 src/slam.cpp:899-921) drives instead of building a batch per set of windows.  The bar is bytes: a refilled batch returns what a
 fresh batch of the same windows returns."""
+import os
+
 import numpy as np
 import pytest
 
@@ -165,3 +167,46 @@ def test_reproducible_option_makes_results_independent_of_the_batch(hip, oracle)
         hip.lba_solve(wide, reproducible=1, lba_elimination=4)
     assert e.value.status == 4
     hip.lba_solve(wide, reproducible=1)
+
+
+def test_stream_from_a_cxx_host(hip, tmp_path):
+    """tests/host_cxx/stream_demo.cpp: the stream API driven from C++ through the C ABI alone (no ctypes, no torch) - six batches of eight windows
+    of three shapes through a depth-2 stream on three host threads, the later batches refills; with reproducible = 1 every solved parameter
+    vector equals, to the byte, the same window solved alone through slslam_lba_solve, and the step count the demo adds up (the counter of
+    reference src/slam.cpp:949-950) equals the sum of the solo summaries."""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(ROOT, "slslam_amd", "_lib")
+    demo = os.path.join(ROOT, "tests", "_build", "stream_demo")
+    os.makedirs(os.path.dirname(demo), exist_ok=True)
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", demo,
+                           os.path.join(ROOT, "tests", "host_cxx", "stream_demo.cpp"), "-L", libdir, "-lslslam_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    per, nb = 8, 6
+    ws = [synth.make_window(900 + i, num_lines=(150, 220, 300)[i % 3], num_kf=(12, 20, 16)[i % 3], num_free=(6, 10, 8)[i % 3]) for i in range(per * 3)]
+    with open(tmp_path / "wins.bin", "wb") as f:
+        np.array([len(ws)], dtype=np.int32).tofile(f)
+        for w in ws:
+            np.array([w["num_cameras"], w["num_lines"], len(w["camera_index"])], dtype=np.int32).tofile(f)
+            np.asarray(w["camera_index"], dtype=np.int32).tofile(f)
+            np.asarray(w["line_index"], dtype=np.int32).tofile(f)
+            np.asarray(w["fixed_index"], dtype=np.int32).tofile(f)
+            np.asarray(w["observations"], dtype=np.float64).tofile(f)
+            np.asarray(w["parameters"], dtype=np.float64).tofile(f)
+    p = subprocess.run([demo, str(tmp_path / "wins.bin"), str(tmp_path / "out.bin"), str(per), str(nb), "2", "3"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "refilled" in p.stdout
+    out = np.fromfile(tmp_path / "out.bin")
+    steps, off = out[0], 1
+    solo = {}
+    want_steps = 0
+    for k in range(nb):
+        for j in range(per):
+            i = (k * per + j) % len(ws)
+            if i not in solo:
+                solo[i] = hip.lba_solve(ws[i], reproducible=1)
+            x, s, _ = solo[i]
+            assert np.array_equal(out[off:off + x.size], x), "batch %d window %d" % (k, j)
+            off += x.size
+            want_steps += s["num_successful_steps"] + s["num_unsuccessful_steps"]
+    assert off == out.size and steps == want_steps
