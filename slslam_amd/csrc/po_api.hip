@@ -121,7 +121,7 @@ void order_chains_first(int N, int E, const int* p1, const int* p2, const std::v
       std::vector<int> cuts;
       size_t b = 0;
       int left = job.left;
-      while (job.seq.size() - b > sub + 1 && (int)levels.size() < 8) {   // (at least one pose is left behind the cut pose)
+      while (job.seq.size() - b > sub + 1 && job.level < 7) {            // (at least one pose is left behind the cut pose; eight levels at most)
         levels[(size_t)job.level].push_back(Piece{ std::vector<int>(job.seq.begin() + b, job.seq.begin() + b + sub), left, job.seq[b + sub] });
         left = job.seq[b + sub];
         cuts.push_back(left);
