@@ -102,9 +102,11 @@ void order_chains_first(int N, int E, const int* p1, const int* p2, const std::v
     static const char* env_sub = std::getenv("SLSLAM_PO_SUBCHAIN");        // (experiments: piece length of the first level)
     auto piece_len = [&](size_t L, int level) -> size_t {
       if (level == 0 && env_sub) return (size_t)std::min((int)kMaxChain, std::max(1, std::atoi(env_sub)));
-      const int m = L <= 8 ? 1 : (L <= 72 ? 2 : 3);                    // levels this chain is spread over
-      if (m == 1) return L;
-      return (size_t)std::min((int)kMaxChain, std::max(3, (int)std::lround(std::pow((double)L, 1.0 / m))));
+      static const char* env_lv = std::getenv("SLSLAM_PO_LEVELS");       // (experiments: levels a long path is spread over)
+      int m = L <= 8 ? 1 : (L <= 72 ? 2 : 3);                          // levels this chain is spread over
+      if (env_lv && L > 8) m = std::max(1, std::atoi(env_lv) - level);
+      if (m <= 1) return L;
+      return (size_t)std::min((int)kMaxChain, std::max(2, (int)std::lround(std::pow((double)L, 1.0 / m))));
     };
     struct Job { std::vector<int> seq; int left, right, level; };
     std::vector<Job> jobs;
