@@ -778,7 +778,12 @@ def main():
             out["traj_error_vs_oracle"] = {"rms_m": float(np.sqrt((err ** 2).mean())), "mean_m": float(err.mean()),
                                            "keyframes": int(err.size)}
         if world == 1 and not args.no_streamed and ns == 1:
-            resident_params = {i: batches[where[i][0]].parameters(where[i][1]) for i in range(B)} if B <= 4096 else {}
+            resident_params = {i: batches[where[i][0]].parameters(where[i][1]).copy() for i in range(B)} if B <= 4096 else {}
+            # the resident batches are done: their HBM, graphs and queues go back before the stream of windows starts (an idle batch kept open beside
+            # the stream's slots makes the process's HIP streams share hardware queues, and uploads then wait behind solves: tools/streamed_dbg.py)
+            for bt in batches:
+                bt.close()
+            batches = []
             try:
                 out["streamed"] = streamed_block(windows, local_rank, out["value"], resident_params, batches_timed=args.stream_batches,
                                                  host_threads=args.host_threads, depth=args.stream_depth, chunks_per_window=args.chunks, lba_elimination=args.elim,

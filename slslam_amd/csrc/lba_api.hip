@@ -272,6 +272,7 @@ struct slslam_lba_batch {
   DevBuf<double> d_cam_x, d_cam_x0, d_cam_scale, d_cam_tab; DevBuf<int> d_cam_cf, d_cam_win;
   DevBuf<double> d_line_x, d_line_x0, d_line_scale; DevBuf<int> d_line_ptr, d_line_flags, d_line_win, d_line_orig;
   DevBuf<double> d_ob; DevBuf<int> d_ob_cam, d_ob_orig;
+  DevBuf<double> d_ob_raw;                   // refillable batches: a refill's observations as the caller holds them, permuted into d_ob on the device (k_permute_obs)
   // windows beyond the tiled sweeps (lba_big.h)
   bool big_mode = false;
   BigPtrs big;
@@ -329,7 +330,7 @@ struct slslam_lba_batch {
     d_sys_map.release(); d_wins.release(); d_tiles.release(); d_chunks.release(); d_items.release(); d_lane_map.release(); d_lane_ctx.release(); d_line_desc.release(); d_dbg_cycles.release();
     d_cam_x.release(); d_cam_x0.release(); d_cam_scale.release(); d_cam_tab.release(); d_cam_cf.release(); d_cam_win.release();
     d_line_x.release(); d_line_x0.release(); d_line_scale.release(); d_line_ptr.release(); d_line_flags.release();
-    d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release();
+    d_line_win.release(); d_line_orig.release(); d_ob.release(); d_ob_cam.release(); d_ob_orig.release(); d_ob_raw.release();
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
     d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release(); d_active.release();
     d_fstore.release(); d_line_elim.release(); d_line_h.release(); d_slab_sum.release();
@@ -656,6 +657,20 @@ HostPool* batch_pool(slslam_lba_batch* b, int threads) {
 // One 16-byte record per lane and tile (BatchPtrs.lane_ctx): sorted line | first observation of the line | position in the run (bits 0-5),
 // run length (6-12), lane has a line (13), skew (14), the line's constant flag (15), the tile's flags (16-23), line slot (24-31) | the
 // tile's lane-th line descriptor - lane_map, line_ptr, line_flags and line_desc resolved once per batch.  thread <-> (tile, lane).
+// A refill's observations arrive in the caller's order (one linear copy per window on the host, one upload): thread <-> sorted observation o of
+// window blockIdx.y takes observation ob_orig[o] of that window's raw block and lays its four (x, y) pairs into the planes the sweeps stream.
+// What pack_window's gather does on the host for a fresh batch - the same bytes - at the device's memory rate instead of a host core's.
+__global__ __launch_bounds__(256) void k_permute_obs(BatchPtrs p, const double* raw, const int* ob_orig, double* ob_planes) {
+  const WinDesc wd = p.wins[blockIdx.y];
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= wd.M) return;
+  const long long g = (long long)wd.obs_off + o;
+  const double2* src = reinterpret_cast<const double2*>(raw + ((long long)wd.obs_off + ob_orig[g]) * 8);
+  const double2 a = src[0], b = src[1], c = src[2], d = src[3];
+  double2* out = reinterpret_cast<double2*>(ob_planes);
+  out[g] = a; out[p.ob_stride + g] = b; out[2 * p.ob_stride + g] = c; out[3 * p.ob_stride + g] = d;
+}
+
 __global__ __launch_bounds__(256) void k_build_lane_ctx(BatchPtrs p, int ntiles, int32_t* out) {
   const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
   if (g >= (long long)ntiles * 64) return;
@@ -843,6 +858,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.staged(b->d_line_win, cap_line);
   ar.staged(b->d_line_orig, cap_line);
   ar.staged(b->d_ob, 8 * cap_obs);
+  ar.scratch(b->d_ob_raw, b->refillable ? 8 * cap_obs : 0);
   ar.staged(b->d_ob_cam, cap_obs);
   ar.staged(b->d_ob_orig, cap_obs);
   ar.scratch(b->d_slab, std::max<size_t>(1, room(slab)));
@@ -1264,7 +1280,9 @@ extern "C" int slslam_lba_batch_solve(slslam_lba_batch* b, void* stream) {
     }
     const hipError_t ei = hipGraphInstantiate(&b->graph_exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
-    if (ei != hipSuccess) { (void)hipStreamDestroy(b->capture_stream); b->capture_stream = nullptr; }
+    // (the stream only served the capture: kept alive it would occupy one of the device's few hardware queues, which the streams of a process
+    // share - a resident batch next to a stream of windows made uploads wait behind solves, tools/streamed_dbg.py)
+    (void)hipStreamDestroy(b->capture_stream); b->capture_stream = nullptr;
     HIP_TRY(ei);
   }
   HIP_TRY(hipGraphLaunch(b->graph_exec, s));
@@ -1416,9 +1434,13 @@ extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_win
   wins.resize((size_t)B);
   std::vector<int> st((size_t)B, SLSLAM_OK);
   HostPool* pool = batch_pool(b, (int)std::min<long long>(B, b->opt.host_threads > 0 ? b->opt.host_threads : (B >= 64 ? 8 : 1)));
+  // (the observation region of the pinned image holds the windows' RAW observations, one after the other, after a refill: the device permutes)
+  static const bool host_gather = std::getenv("SLSLAM_REFILL_HOST_GATHER") != nullptr;      // (measurement switch: the gather on the host threads, as a fresh batch is built)
+  const bool device_gather = b->d_ob_raw.n >= (size_t)8 * (size_t)obs_off[(size_t)B] && b->d_ob_raw.p && !host_gather;
   auto pack_one = [&](int i) {
     ObPlanes dest;
     for (int q = 0; q < 4; ++q) dest.plane[q] = img.ob + ((size_t)q * (size_t)img.ob_stride + (size_t)obs_off[(size_t)i]) * 2;
+    if (device_gather) dest.raw = img.ob + (size_t)obs_off[(size_t)i] * 8;
     st[(size_t)i] = pack_window(&windows[i], &wins[(size_t)i], grouping, &dest);
   };
   if (pool) pool->run(B, pack_one); else for (int i = 0; i < B; ++i) pack_one(i);
@@ -1469,9 +1491,16 @@ extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_win
   SLS_UP(b->d_cam_x0, 6 * plan.ncam); SLS_UP(b->d_cam_cf, b->d_cam_cf.n); SLS_UP(b->d_cam_win, b->d_cam_win.n);
   SLS_UP(b->d_line_x0, 4 * plan.nline); SLS_UP(b->d_line_ptr, plan.nline + 1); SLS_UP(b->d_line_flags, std::max<long long>(1, plan.nline));
   SLS_UP(b->d_line_win, b->d_line_win.n); SLS_UP(b->d_line_orig, plan.nline);
-  for (int q = 0; q < 4 && plan.nobs > 0; ++q)
-    HIP_TRY(hipMemcpyAsync(b->d_ob.p + (size_t)q * (size_t)img.ob_stride * 2, img.ob + (size_t)q * (size_t)img.ob_stride * 2, (size_t)plan.nobs * 2 * sizeof(double), hipMemcpyHostToDevice, s));
   SLS_UP(b->d_ob_cam, plan.nobs); SLS_UP(b->d_ob_orig, plan.nobs); SLS_UP(b->d_param_off, B);
+  if (device_gather && plan.nobs > 0) {
+    int maxM = 0;
+    for (int i = 0; i < B; ++i) maxM = std::max(maxM, windows[i].num_observations);
+    HIP_TRY(hipMemcpyAsync(b->d_ob_raw.p, img.ob, (size_t)plan.nobs * 8 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (maxM > 0) hipLaunchKernelGGL(k_permute_obs, dim3((unsigned)((maxM + 255) / 256), (unsigned)B), dim3(256), 0, s, b->ptrs, (const double*)b->d_ob_raw.p, (const int*)b->d_ob_orig.p, b->d_ob.p);
+  } else {
+    for (int q = 0; q < 4 && plan.nobs > 0; ++q)
+      HIP_TRY(hipMemcpyAsync(b->d_ob.p + (size_t)q * (size_t)img.ob_stride * 2, img.ob + (size_t)q * (size_t)img.ob_stride * 2, (size_t)plan.nobs * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+  }
 #undef SLS_UP
   if (!b->ev_stage_free) HIP_TRY(hipEventCreateWithFlags(&b->ev_stage_free, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(b->ev_stage_free, s));

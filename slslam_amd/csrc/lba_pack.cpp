@@ -347,6 +347,41 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
     static const bool no_stream = std::getenv("SLSLAM_PACK_NO_STREAMING_STORES") != nullptr;      // (measurement switch)
     if (no_stream) stream_out = false;
     uint64_t nonfinite = 0;
+    if (ob_dest && ob_dest->raw) {
+      // the device gathers (refill): here only the linear copy of the caller's array, tested for NaN / Inf on the way, and the sorted camera ids
+      const double* src = w->observations;
+      double* dst = ob_dest->raw;
+      const size_t n8 = (size_t)8 * (size_t)M;
+#if defined(__SSE2__)
+      if (!(reinterpret_cast<uintptr_t>(dst) & 15u) && !no_stream) {
+        // (non-temporal 16-byte stores, the exponent test of all_finite on the same registers)
+        const __m128i expo = _mm_set1_epi64x((long long)0x7ff0000000000000ull), one = _mm_set1_epi64x((long long)0x0010000000000000ull);
+        __m128i acc = _mm_setzero_si128();
+        for (size_t q = 0; q < n8; q += 2) {
+          const __m128d v = _mm_loadu_pd(src + q);
+          _mm_stream_pd(dst + q, v);
+          acc = _mm_or_si128(acc, _mm_add_epi64(_mm_and_si128(_mm_castpd_si128(v), expo), one));
+        }
+        _mm_sfence();
+        uint64_t lanes[2];
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(lanes), acc);
+        nonfinite |= (lanes[0] | lanes[1]) & 0x8000000000000000ull;
+      } else
+#endif
+      {
+        std::memcpy(dst, src, n8 * sizeof(double));
+        for (size_t q = 0; q < n8; ++q) {
+          uint64_t x;
+          std::memcpy(&x, src + q, 8);
+          nonfinite |= ((x & 0x7ff0000000000000ull) + 0x0010000000000000ull) & 0x8000000000000000ull;
+        }
+      }
+      for (int o = 0; o < M; ++o) {
+        const int i = P.ob_orig[o];
+        P.ob_cam[o] = w->camera_index[i];
+        if (!(cam_const[w->camera_index[i]] && line_const[w->line_index[i]])) ++P.nkept;
+      }
+    } else
     for (int o = 0; o < M; ++o) {
       const int i = P.ob_orig[o];
       // (a stream of windows reads every observation from memory exactly once, here, in the order of the sorted lines: ask for the lines a

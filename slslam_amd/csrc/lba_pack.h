@@ -51,7 +51,12 @@ struct PackedWindow {
 // ob_dest (optional): the four observation planes are written THERE (plane q: ob_dest->plane[q][2 o + {0, 1}], o = sorted position) instead of
 // into out->ob, which stays empty - a batch that is refilled from host buffers packs straight into its pinned staging image
 // (slslam_lba_batch_refill: one pass over the caller's observations, no second copy).
-struct ObPlanes { double* plane[4]; };
+struct ObPlanes {
+  double* plane[4];
+  // raw != nullptr (a refill whose batch permutes the observations on the DEVICE, lba_api.hip::k_permute_obs): the window's observations are
+  // copied there in the CALLER'S order, [8 M] doubles - one linear pass with the finite check - and the planes are not written
+  double* raw = nullptr;
+};
 int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping = 0, const ObPlanes* ob_dest = nullptr);
 // The same window packed again with another grouping (the caller's arrays are rebuilt from the packed ones).
 int repack_window(const PackedWindow& P, int grouping, PackedWindow* out);
