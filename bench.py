@@ -20,6 +20,11 @@ import os
 import sys
 import time
 
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams beyond that SHARE a queue: with torch's
+# stream pool alive (the informational two-stream run creates it) the three slot streams of the streamed leg then queued behind each other - uploads
+# waiting for another batch's solve, 6-8 ms per batch (tools/streamed_dbg.py).  Eight queues keep them apart; set before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
