@@ -2,7 +2,7 @@
 (tools/gpu_r5_profile.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE of `bench.py --eager --steps 1`, tools/rocpd_pmc.py -> <tag>_pmc.txt).
 Per launch, dispatch-weighted over the first-sweep and steady instantiations of the elimination kernel; FETCH_SIZE doubled as MI355X_MICROARCH.md
 prescribes for gfx950 (calibrated in round 1 on k_candidate_cost), WRITE_SIZE as reported, both in KB.
-    python tools/make_pmc_traffic.py profiles/round5_v4_pmc.txt round5_v4"""
+    python tools/make_pmc_traffic.py profiles/round5_v7_pmc.txt round5_v7"""
 import json
 import os
 import re
