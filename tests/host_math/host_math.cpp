@@ -125,6 +125,25 @@ int hm_pack_g(int C, int L, int M, const int* cam, const int* line, const int* f
 }
 }
 
+// The three destinations of a pack's observations (lba_pack.h): the packed window itself (planes in P.ob), caller planes (a refill with the gather on
+// the host: planes_out[8 M]), or - a refill whose batch permutes on the device - the RAW copy in the caller's order (raw_out[8 M]; the planes stay
+// untouched).  Returns the packer's status; ob_orig / ob_cam / nkept of the pack come back in every mode.
+extern "C" int hm_pack_dest(int C, int L, int M, const int* cam, const int* line, const int* fixed, const double* obs, double* params, int grouping,
+                            int mode /*0 own, 1 planes, 2 raw*/, double* planes_out, double* raw_out, int* ob_orig, int* ob_cam, int* nkept, double* own_out) {
+  slslam_lba_window w{C, L, M, cam, line, fixed, obs, params};
+  slslam::PackedWindow P;
+  slslam::ObPlanes d;
+  for (int q = 0; q < 4; ++q) d.plane[q] = planes_out + (size_t)2 * q * M;
+  if (mode == 2) d.raw = raw_out;
+  const int rc = slslam::pack_window(&w, &P, grouping, mode == 0 ? nullptr : &d);
+  if (rc) return rc;
+  copy_bytes(ob_orig, P.ob_orig.data(), sizeof(int) * M);
+  copy_bytes(ob_cam, P.ob_cam.data(), sizeof(int) * M);
+  *nkept = P.nkept;
+  if (mode == 0) copy_bytes(own_out, P.ob.data(), sizeof(double) * 8 * M);
+  return (mode != 0 && !P.ob.empty()) ? -2 : 0;
+}
+
 // ---- the matrix-core elimination's index maps (lba_eliminate_mfma.h), exported so that the CPU suite can replay one tile
 #include "../../slslam_amd/csrc/lba_eliminate_mfma_maps.h"
 extern "C" {

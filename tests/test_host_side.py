@@ -910,3 +910,42 @@ def test_packer_layout_matches_the_golden_digest(host_math):
             assert mod.digest(P) == ref["crc32"], (name, g)
             seen += 1
     assert seen == len(gold) == 12
+
+
+def test_pack_observation_destinations(host_math):
+    """Where a pack's observations go (lba_pack.h::ObPlanes): into the packed window, into caller planes (a refill that gathers on the host), or
+    - a refill whose batch permutes on the device (lba_api.hip::k_permute_obs) - as a RAW copy in the caller's order.  The three agree: planes =
+    own planes; raw = the caller's array, and permuting it with ob_orig (what the device kernel does) gives the planes; ob_orig, ob_cam and the
+    count of kept residual blocks do not depend on the mode; NaN / Inf in the observations is refused in every mode."""
+    rng = np.random.default_rng(2)
+    for seed, nl, grouping in ((3, 150, 0), (4, 400, 1), (5, 60, 1)):
+        w = synth.make_window(seed, num_lines=nl)
+        if seed == 5:
+            perm = rng.permutation(len(w["camera_index"]))
+            for k in ("camera_index", "line_index", "observations"):
+                w[k] = np.asarray(w[k])[perm]
+            w["fixed_index"] = np.asarray(w["fixed_index"]).reshape(-1, 2)[perm].reshape(-1)
+        Cn, L, M = int(w["num_cameras"]), int(w["num_lines"]), len(w["camera_index"])
+        cam = np.ascontiguousarray(w["camera_index"], dtype=np.int32); line = np.ascontiguousarray(w["line_index"], dtype=np.int32)
+        fixed = np.ascontiguousarray(w["fixed_index"], dtype=np.int32); obs = np.ascontiguousarray(w["observations"], dtype=np.float64).reshape(-1)
+        prm = np.ascontiguousarray(w["parameters"], dtype=np.float64).copy()
+        res = {}
+        for mode in (0, 1, 2):
+            planes, raw, own = np.full(8 * M, -7.0), np.full(8 * M, -7.0), np.zeros(8 * M)
+            oo, oc, nk = np.zeros(M, np.int32), np.zeros(M, np.int32), C.c_int(0)
+            rc = host_math.hm_pack_dest(Cn, L, M, _ip(cam), _ip(line), _ip(fixed), _dp(obs), _dp(prm), grouping, mode, _dp(planes), _dp(raw), _ip(oo), _ip(oc),
+                                        C.byref(nk), _dp(own))
+            assert rc == 0
+            res[mode] = (planes, raw, own, oo, oc, nk.value)
+        for mode in (1, 2):
+            assert np.array_equal(res[mode][3], res[0][3]) and np.array_equal(res[mode][4], res[0][4]) and res[mode][5] == res[0][5]
+        assert np.array_equal(res[1][0], res[0][2])                               # caller planes = the packed window's planes
+        assert np.array_equal(res[2][1], obs) and np.all(res[2][0] == -7.0)        # raw mode: the caller's array, planes untouched
+        gathered = obs.reshape(M, 4, 2)[res[2][3]]                                 # what k_permute_obs does: sorted position o <- observation ob_orig[o]
+        assert np.array_equal(gathered.transpose(1, 0, 2).reshape(-1), res[0][2])
+        bad = obs.copy(); bad[8 * (M // 2) + 3] = np.inf
+        for mode in (0, 1, 2):
+            planes, raw, own = np.zeros(8 * M), np.zeros(8 * M), np.zeros(8 * M)
+            oo, oc, nk = np.zeros(M, np.int32), np.zeros(M, np.int32), C.c_int(0)
+            assert host_math.hm_pack_dest(Cn, L, M, _ip(cam), _ip(line), _ip(fixed), _dp(bad), _dp(prm), grouping, mode, _dp(planes), _dp(raw), _ip(oo), _ip(oc),
+                                          C.byref(nk), _dp(own)) == 1
