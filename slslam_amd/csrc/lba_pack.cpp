@@ -136,8 +136,6 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
   std::vector<int> tile_rows;                      // row ids, tile after tile
   std::vector<int> tile_ptr(1, 0);
   if (!P.big) {
-    static const bool no_disjoint = std::getenv("SLSLAM_PACK_NO_DISJOINT") != nullptr;       // (experiment: the camera-disjoint preference off for the grouped packing)
-    const int first_pass = (grouping && no_disjoint) ? 1 : 0;
     // open rows by the lanes they have left, with the free cameras of their lines (beside the id: the search below reads nothing else).
     // and_mask[room]: a subset of the cameras EVERY row of that list holds (the AND of the masks pushed since the list was last empty -
     // rows leave, so the true AND can only have more bits): a line that shares one of them shares a camera with every row of the list,
@@ -160,7 +158,7 @@ int pack_window(const slslam_lba_window* w, PackedWindow* out, int grouping, con
         // serialise in the LDS (tools/micro/lds_atomic_bench.hip)
         int r = -1;
         const unsigned fm = fmask[l];
-        for (int pass = first_pass; pass < 2 && r < 0; ++pass)          // pass 0: rows without a common free camera only
+        for (int pass = 0; pass < 2 && r < 0; ++pass)                   // pass 0: rows without a common free camera only
           for (int room = len; room <= 16 && r < 0; ++room) {
             std::vector<OpenRow>& cand = open.by_room[room];
             if (cand.empty() || (pass == 0 && (open.and_mask[room] & fm))) continue;
