@@ -37,9 +37,14 @@ void slslam_dist_shard_range(long long n, int rank, int world, long long* lo, lo
  * ncclAllReduce on the solve stream, behind the solve).  gathered != NULL: also one ncclAllGather - gathered[r * slot + k] = the k-th
  * double of rank r's concatenated parameter vectors (windows in shard order, each [6C | 4L]), `slot` doubles per rank (the bound every
  * rank passes: >= the largest shard's parameter count, same on all ranks), count_per_rank[r] = doubles rank r filled.  HOST pointers.
- * Collective: every rank calls it with the same options, slot and gathered-ness. */
+ * Collective: every rank calls it with the same options, slot and gathered-ness.
+ * Errors keep the ranks in step: a rank whose shard fails (bad window, allocation, ...) still enters the all-reduce - with zeros and an
+ * error count as a fourth element - so nobody blocks; when that count is non-zero EVERY rank returns an error (its own status, or
+ * SLSLAM_ERR_STATE on the healthy ranks: the sums would silently omit a shard) and NO rank enters the all-gather. */
 int  slslam_dist_solve(slslam_dist* d, const slslam_lba_window* my_windows, int n_mine, const slslam_solver_options* opt,
                        double sums[3], double* gathered, long long slot, long long* count_per_rank);
+/* Test hook: the next slslam_dist_solve on this rank solves its shard and then reports it as failed (exercises the path above). */
+int  slslam_dist_debug_fail_next_shard(slslam_dist* d);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,8 @@
 #ifndef SLSLAM_HIP_H_
 #define SLSLAM_HIP_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -28,7 +30,8 @@ enum {
   SLSLAM_ERR_NO_DEVICE = 2,        /* no HIP device / HIP runtime error */
   SLSLAM_ERR_HIP = 3,
   SLSLAM_ERR_UNSUPPORTED = 4,      /* problem shape outside what the kernels support */
-  SLSLAM_ERR_STATE = 5             /* call sequence violated (e.g. solve before finalize) */
+  SLSLAM_ERR_STATE = 5,            /* call sequence violated (e.g. solve before finalize) */
+  SLSLAM_ERR_NO_MEMORY = 6         /* a host allocation failed while building a window (std::bad_alloc caught at the boundary) */
 };
 
 /* Termination of one solve: mirrors ceres::Solver::Summary::termination_type of Ceres 1.7.
@@ -124,7 +127,16 @@ typedef struct slslam_solver_options {
                                            measured (a float line Jacobian changes accept / reject decisions: its depth column carries
                                            d = cos t / sin t, reference src/lba_problem.h:63).  Grouped sweep only (lba_elimination 0 or
                                            4, at most 10 free cameras); opt-in; results within the tolerance stated in DESIGN.md 7e and
-                                           tests/test_gpu_lba.py::test_mixed_precision_solves of the fp64 path and of the oracle      */
+                                           tests/test_gpu_lba.py::test_mixed_precision_solves of the fp64 path and of the oracle.
+                                           MEASURED: buys nothing (0.997 x the fp64 step) - fp32 line Jacobians change LM accept / reject
+                                           decisions, and what is left to fp32 is a few per cent of the sweep.  Kept as a tested option  */
+  int    device_build;                  /* who runs the LBAProblem::build stage (reference src/lba_problem.cpp:54-93) of a REFILL
+                                           (slslam_lba_batch_refill, slslam_lba_stream_submit): 0 (default) = the device when it can
+                                           (csrc/lba_device_build.h: at most 64 cameras and 65534 lines per window; the windows' arrays are
+                                           read by the GPU where they are when they lie in page-locked memory - slslam_pinned_alloc /
+                                           slslam_pinned_register - else from a pinned staging copy the host threads make), with the host
+                                           packer as the fallback; -1 = always the host packer (lba_pack.cpp, options.host_threads
+                                           threads).  Same layout, same solved bytes either way                                          */
 } slslam_solver_options;
 
 /* Fills every field with the configuration the reference runs (robust loss on, 10 iterations). */
@@ -216,7 +228,12 @@ int  slslam_lba_batch_wait(slslam_lba_batch* b);
  * solve graph stays valid.  The windows are cut into chunks by the policy finalize resolved, so a refilled batch returns the bytes a
  * fresh batch of the same windows returns.  SLSLAM_ERR_UNSUPPORTED (batch unchanged, still solvable): the windows do not fit the
  * room the arrays have, or need another path / sweep - build a new batch then.
- * Host arrays are read before the call returns; `stream` must be the stream the batch is solved on. */
+ * Host arrays are read before the call returns - EXCEPT arrays in page-locked memory (slslam_pinned_alloc / _register) when the device
+ * builds (options.device_build = 0): those are read by the GPU after the call returns and must stay valid until the results have been
+ * waited for.  When the device builds, what only the build can find out arrives with the results: a window with bad input, of a shape
+ * for the host path, or a refill that does not fit the room is flagged - slslam_lba_batch_get_parameters / _get_summary of such a window
+ * return SLSLAM_ERR_INVALID_ARGUMENT / SLSLAM_ERR_UNSUPPORTED (the other windows are solved); sizes that cannot fit are still refused here.
+ * `stream` must be the stream the batch is solved on. */
 int  slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_window* windows, int n, void* stream);
 /* After download: solved parameters of window `index` in the caller's original layout. */
 int  slslam_lba_batch_get_parameters(const slslam_lba_batch* b, int index, double* parameters);
@@ -262,10 +279,28 @@ int  slslam_lba_batch_kernel_times(const slslam_lba_batch* b, double ms[8], int 
 int  slslam_lba_batch_linearise(slslam_lba_batch* b, int index, double* residuals, double* j_cam,
                                 double* j_line, double* cost);
 
+/* ---- page-locked host memory the GPU reads and writes IN PLACE.
+ * Replaces: the `new int[...]` / `new double[...]` of the caller's five arrays per window (reference src/slam.cpp:899-903) for a caller
+ * that streams windows: arrays allocated here (or in a range registered once with slslam_pinned_register - an arena the caller owns) are
+ * read by the device straight over the host link during slslam_lba_batch_refill / slslam_lba_stream_submit (no host thread touches the
+ * data; 57 GB/s measured, tools/micro/zero_copy_bench.hip) and the solved `parameters` are written back the same way.  Such arrays
+ * must stay valid and unmodified until the results have been waited for / collected.  Arrays anywhere else keep working: the host threads
+ * copy them into a pinned staging buffer first.  slslam_pinned_contains: 1 when [p, p + bytes) lies in one such range. */
+int  slslam_pinned_alloc(size_t bytes, void** out);
+int  slslam_pinned_free(void* p);
+int  slslam_pinned_register(void* p, size_t bytes);
+int  slslam_pinned_unregister(void* p);
+int  slslam_pinned_contains(const void* p, size_t bytes);
+/* The three index arrays of a window narrowed to ONE 32-bit word per observation - line | camera << 16 | camera constant << 24 |
+ * line constant << 25 - the form the device build works on (16 -> 4 bytes per observation over the host link: what the staging copy
+ * produces on the way).  SLSLAM_ERR_UNSUPPORTED when a camera index exceeds 255 or a line index 65534. */
+int  slslam_pack_indices(int n, const int* camera_index, const int* line_index, const int* fixed_index, unsigned int* packed);
+
 /* ---- a STREAM of windows (BASELINE config 4: many independent windows arriving in host memory): `depth` refillable batches in
  * flight on HIP streams of their own, so that packing (host threads), upload (copy engine), solve and download of consecutive
  * batches overlap.  submit() = LBAProblem::build + ceres::Solve for `n` windows, asynchronous: it returns when the windows' arrays
- * have been read (only `parameters` of each window must stay valid - it is written by collect); collect() waits for that submit's
+ * have been read or handed to the GPU (`parameters` of each window must stay valid - it is written by collect -, and so must arrays in
+ * page-locked memory, which the GPU reads in place: slslam_pinned_alloc); collect() waits for that submit's
  * results and writes every window's solved parameters in place (the in/out contract of reference src/slam.cpp:957-972) and, when
  * `summaries` is not NULL, summaries[0 .. n).  Tickets must be collected before their slot comes round again (every `depth` submits:
  * SLSLAM_ERR_STATE otherwise).  options: as for a batch; host_threads (0 = up to 16) pack and copy; refill_headroom_percent 0 = 10. */
@@ -279,6 +314,13 @@ int  slslam_lba_stream_collect(slslam_lba_stream* s, int ticket, slslam_summary*
  * count of reference src/slam.cpp:949-950) of the windows collected; host threads in use.  Any pointer may be NULL. */
 int  slslam_lba_stream_stats(const slslam_lba_stream* s, double* ms_submit, double* ms_collect_wait, double* ms_collect_copy,
                              long long* refills, long long* builds, long long* windows, long long* lm_iterations, int* host_threads);
+/* Of the refills: how many were built on the device, how many of those read the callers' page-locked arrays in place (zero copy); windows the
+ * device build handed back to the host path at collect time (a camera that sees a line twice, a line with more than 64 observations, more
+ * than 20 free cameras, no room in the slot's arrays).  Any pointer may be NULL. */
+int  slslam_lba_stream_build_stats(const slslam_lba_stream* s, long long* device_builds, long long* zero_copy, long long* fallback_windows);
+/* The batch that served `ticket` (valid until its slot is submitted to again; after collect: its traces, chunk cuts and sweep can be read
+ * with the slslam_lba_batch_* getters).  Read only. */
+int  slslam_lba_stream_batch(slslam_lba_stream* s, int ticket, slslam_lba_batch** batch);
 
 /* ------------------------------------------------------------------ pose graph
  * Replaces: POProblem(size, n_iter) + set_pose_index_1/2 + set_constraints + set_parameters
@@ -384,6 +426,14 @@ int slslam_debug_phase_cycles(slslam_lba_batch* batch, double* out);
  * 30 / 31, the constant-clock (s_memrealtime, 100 MHz) times at which the chunk's wave started and ended its last sweep: what
  * tools/chunk_timeline.py reads).  Copies min(n, size) words; *size = words the buffer holds. */
 int slslam_debug_read_cycles(slslam_lba_batch* batch, unsigned long long* out, long long n, long long* size);
+
+/* Test hook of the device build (csrc/lba_device_build.h): ONE window through k_ingest / k_build_window / k_build_layout / k_build_tiles
+ * alone; everything the host packer emits for the window comes back (counts: Cf, tiles, items, free parameters, kept residual blocks;
+ * tiles: line_begin, nlines, flags, nitems per tile) so that tests compare the two byte for byte.  *status: 0 built, else the reason
+ * bits (1 bad input, 2 a shape for the host path). */
+int slslam_debug_device_pack(const slslam_lba_window* window, int grouping, int* counts, int* line_order, int* line_ptr, int* ob_orig,
+                             int* ob_cam, int* tiles, unsigned char* items, int* cam_cf, int max_tiles, int max_items,
+                             unsigned short* lane_map, unsigned* line_desc, int* status);
 
 /* ------------------------------------------------------------------ misc */
 int         slslam_device_count(void);          /* 0 when no HIP device is usable */

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libslslam_hip.so")
 
 OK = 0
 STATUS = {0: "ok", 1: "invalid argument", 2: "no usable HIP device", 3: "HIP runtime error",
-          4: "unsupported problem shape", 5: "invalid call sequence"}
+          4: "unsupported problem shape", 5: "invalid call sequence", 6: "host allocation failed"}
 TERMINATION = {0: "NO_CONVERGENCE", 1: "GRADIENT_TOLERANCE", 2: "FUNCTION_TOLERANCE",
                3: "PARAMETER_TOLERANCE", 4: "NUMERICAL_FAILURE", 5: "MIN_RADIUS"}
 KERNEL_FAMILIES = ["linearise_schur", "reduced_solve", "backsub", "line_trig", "candidate_cost",
@@ -37,7 +37,7 @@ class SolverOptions(C.Structure):
                 ("jacobi_scaling", C.c_int), ("use_graph", C.c_int), ("chunks_per_window", C.c_int),
                 ("reuse_elimination", C.c_int), ("po_factor_fp32", C.c_int), ("po_dense_factor", C.c_int), ("lba_fused_motion_only", C.c_int),
                 ("lba_elimination", C.c_int), ("lba_keep_jacobian", C.c_int), ("refill_headroom_percent", C.c_int),
-                ("host_threads", C.c_int), ("reproducible", C.c_int), ("lba_precision", C.c_int)]
+                ("host_threads", C.c_int), ("reproducible", C.c_int), ("lba_precision", C.c_int), ("device_build", C.c_int)]
 
 
 class Summary(C.Structure):
@@ -83,6 +83,8 @@ EXPORTS = [
     "slslam_lba_batch_add", "slslam_lba_batch_finalize", "slslam_lba_batch_solve", "slslam_lba_batch_reset",
     "slslam_lba_batch_download", "slslam_lba_batch_download_async", "slslam_lba_batch_wait", "slslam_lba_batch_refill",
     "slslam_lba_stream_create", "slslam_lba_stream_destroy", "slslam_lba_stream_submit", "slslam_lba_stream_collect", "slslam_lba_stream_stats",
+    "slslam_lba_stream_build_stats", "slslam_lba_stream_batch", "slslam_pinned_alloc", "slslam_pinned_free", "slslam_pinned_register", "slslam_pinned_unregister",
+    "slslam_pinned_contains", "slslam_pack_indices", "slslam_debug_device_pack",
     "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts", "slslam_lba_batch_window_chunks", "slslam_lba_batch_path", "slslam_lba_batch_elimination",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
@@ -124,6 +126,16 @@ def lib():
     L.slslam_lba_stream_submit.argtypes = [vp, C.POINTER(LBAWindow), C.c_int, ip]
     L.slslam_lba_stream_collect.argtypes = [vp, C.c_int, C.POINTER(Summary)]
     L.slslam_lba_stream_stats.argtypes = [vp, dp, dp, dp] + [C.POINTER(C.c_longlong)] * 4 + [ip]
+    L.slslam_lba_stream_build_stats.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 3
+    L.slslam_lba_stream_batch.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.slslam_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.slslam_pinned_free.argtypes = [vp]
+    L.slslam_pinned_register.argtypes = [vp, C.c_size_t]
+    L.slslam_pinned_unregister.argtypes = [vp]
+    L.slslam_pinned_contains.argtypes = [vp, C.c_size_t]
+    L.slslam_pack_indices.argtypes = [C.c_int, ip, ip, ip, C.POINTER(C.c_uint)]
+    L.slslam_debug_device_pack.argtypes = [C.POINTER(LBAWindow), C.c_int, ip, ip, ip, ip, ip, ip, C.POINTER(C.c_ubyte), ip, C.c_int, C.c_int,
+                                           C.POINTER(C.c_ushort), C.POINTER(C.c_uint), ip]
     L.slslam_lba_batch_get_parameters.argtypes = [vp, C.c_int, dp]
     L.slslam_lba_batch_get_summary.argtypes = [vp, C.c_int, C.POINTER(Summary)]
     L.slslam_lba_batch_get_trace.argtypes = [vp, C.c_int, C.POINTER(Iteration), C.c_int, ip]
@@ -200,15 +212,54 @@ def _trace_list(tr, n):
     return [{k: getattr(tr[i], k) for k, _ in Iteration._fields_} for i in range(n)]
 
 
+class PinnedArena:
+    """One block of page-locked host memory (slslam_pinned_alloc) that numpy arrays are carved out of: what a caller that streams windows
+    allocates its five arrays per window from (instead of `new[]`, reference src/slam.cpp:899-903), so that the GPU reads them in place."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(nbytes) + 64
+        _check(lib().slslam_pinned_alloc(self.nbytes, C.byref(self.ptr)), "slslam_pinned_alloc")
+        self._buf = (C.c_ubyte * self.nbytes).from_address(self.ptr.value)
+        self._mem = np.frombuffer(self._buf, dtype=np.uint8)
+        self._off = (-self.ptr.value) % 64
+
+    def take(self, a):
+        """A copy of array `a` inside the block (64-byte aligned)."""
+        a = np.ascontiguousarray(a)
+        n = a.nbytes
+        if self._off + n > self.nbytes:
+            raise MemoryError("PinnedArena exhausted")
+        out = self._mem[self._off:self._off + n].view(a.dtype).reshape(a.shape)
+        out[...] = a
+        self._off += (n + 63) & ~63
+        return out
+
+    def close(self):
+        if self.ptr:
+            self._mem = None
+            self._buf = None
+            lib().slslam_pinned_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _WindowArrays:
     """Keeps the numpy buffers a slslam_lba_window points to alive."""
 
-    def __init__(self, w, params=None):
+    def __init__(self, w, params=None, arena=None):
         self.cam = np.ascontiguousarray(w["camera_index"], dtype=np.int32)
         self.line = np.ascontiguousarray(w["line_index"], dtype=np.int32)
         self.fixed = np.ascontiguousarray(w["fixed_index"], dtype=np.int32).reshape(-1)
         self.obs = np.ascontiguousarray(w["observations"], dtype=np.float64).reshape(-1)
         self.params = np.array(w["parameters"] if params is None else params, dtype=np.float64).reshape(-1).copy()
+        if arena is not None:
+            self.cam, self.line, self.fixed, self.obs, self.params = (arena.take(x) for x in (self.cam, self.line, self.fixed, self.obs, self.params))
         m = len(self.cam)
         if len(self.line) != m or len(self.fixed) != 2 * m or len(self.obs) != 8 * m:
             raise ValueError("inconsistent window arrays")
@@ -355,8 +406,14 @@ class WindowSet:
     """A C array of slslam_lba_window over numpy buffers that stay alive with it (what a caller of the stream / refill entry points
     holds: the five arrays of every window, reference src/slam.cpp:899-921)."""
 
-    def __init__(self, windows):
-        self.arrays = [_WindowArrays(w) for w in windows]
+    def __init__(self, windows, pinned=False):
+        """pinned: the arrays live in ONE page-locked block (slslam_pinned_alloc): the device build reads them in place (zero copy) and the
+        solved parameters are written back into them by the GPU."""
+        self.arena = None
+        if pinned:
+            need = sum(80 * len(w["camera_index"]) + 8 * (6 * int(w["num_cameras"]) + 4 * int(w["num_lines"])) + 5 * 64 for w in windows)
+            self.arena = PinnedArena(need + 4096)
+        self.arrays = [_WindowArrays(w, arena=self.arena) for w in windows]
         self.c = (LBAWindow * max(len(self.arrays), 1))(*[a.c for a in self.arrays])
         self.sizes = [(int(w["num_cameras"]), int(w["num_lines"])) for w in windows]
 
@@ -365,6 +422,47 @@ class WindowSet:
 
     def parameters(self, i):
         return self.arrays[i].params
+
+    def close(self):
+        if self.arena is not None:
+            self.arrays = []
+            self.arena.close()
+            self.arena = None
+
+
+class _BatchView(LBABatch):
+    """A batch owned by somebody else (a stream's slot): the getters of LBABatch, no destroy."""
+
+    def __init__(self, handle, sizes):
+        self._h = handle
+        self.sizes = list(sizes)
+        self.finalized = True
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+def debug_device_pack(w, grouping=0):
+    """slslam_debug_device_pack: one window through the device build alone; returns (status bits, dict as tests/test_host_side.py::_pack)."""
+    arr = _WindowArrays(w)
+    Cn, L, M = int(w["num_cameras"]), int(w["num_lines"]), len(arr.cam)
+    counts = np.zeros(5, dtype=np.int32)
+    lo, lp = np.zeros(max(L, 1), dtype=np.int32), np.zeros(L + 1, dtype=np.int32)
+    oo, oc, cf = np.zeros(max(M, 1), dtype=np.int32), np.zeros(max(M, 1), dtype=np.int32), np.zeros(max(Cn, 1), dtype=np.int32)
+    max_tiles, max_items = L + 8, 64 * M + 8
+    tiles = np.zeros(4 * max_tiles, dtype=np.int32)
+    items = np.zeros(2 * max_items, dtype=np.uint8)
+    lane_map = np.zeros(64 * max_tiles, dtype=np.uint16)
+    desc = np.zeros(max(L, 1), dtype=np.uint32)
+    st = C.c_int(-1)
+    _check(lib().slslam_debug_device_pack(C.byref(arr.c), int(grouping), _ip(counts), _ip(lo), _ip(lp), _ip(oo), _ip(oc), _ip(tiles),
+                                          items.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cf), max_tiles, max_items,
+                                          lane_map.ctypes.data_as(C.POINTER(C.c_ushort)), desc.ctypes.data_as(C.POINTER(C.c_uint)), C.byref(st)),
+           "slslam_debug_device_pack")
+    return st.value, dict(desc=desc[:L], Cf=int(counts[0]), ntiles=int(counts[1]), nitems=int(counts[2]), nfree=int(counts[3]), nkept=int(counts[4]),
+                          line_order=lo[:L], line_ptr=lp, ob_orig=oo[:M], ob_cam=oc[:M], cam_cf=cf[:Cn],
+                          tiles=tiles[:4 * int(counts[1])].reshape(-1, 4), items=items[:2 * int(counts[2])].reshape(-1, 2),
+                          lane_map=lane_map[:64 * int(counts[1])].reshape(-1, 64))
 
 
 class LBAStream:
@@ -402,6 +500,17 @@ class LBAStream:
         sm = (Summary * max(len(ws), 1))() if want_summaries else None
         _check(lib().slslam_lba_stream_collect(self._h, int(ticket), sm), "slslam_lba_stream_collect")
         return [_summary_dict(sm[i]) for i in range(len(ws))] if want_summaries else None
+
+    def batch_of(self, ticket, ws):
+        """The batch that served `ticket` (its traces, chunk cuts, sweep): valid until the slot is submitted to again."""
+        h = C.c_void_p()
+        _check(lib().slslam_lba_stream_batch(self._h, int(ticket), C.byref(h)), "slslam_lba_stream_batch")
+        return _BatchView(h, ws.sizes)
+
+    def build_stats(self):
+        q = [C.c_longlong(0) for _ in range(3)]
+        _check(lib().slslam_lba_stream_build_stats(self._h, *[C.byref(x) for x in q]), "slslam_lba_stream_build_stats")
+        return {"device_builds": q[0].value, "zero_copy": q[1].value, "fallback_windows": q[2].value}
 
     def stats(self):
         d = [C.c_double(0) for _ in range(3)]

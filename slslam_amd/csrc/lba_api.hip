@@ -22,9 +22,15 @@
 #include "device_cache.h"
 #include "lba_motion_only.h"
 #include "lba_pack.h"
+#include "lba_device_build.h"
 #include "host_pool.h"
+#include "pinned_registry.h"
 
+#include <functional>
 #include <memory>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <thread>
 
 using namespace slslam;
@@ -66,6 +72,7 @@ extern "C" void slslam_default_options(slslam_solver_options* o) {
   o->host_threads = 0;
   o->reproducible = 0;
   o->lba_precision = 0;
+  o->device_build = 0;
 }
 
 extern "C" void slslam_release_cached_memory(void) { DeviceBlockCache::drop(); }
@@ -86,6 +93,7 @@ extern "C" const char* slslam_status_string(int s) {
     case SLSLAM_ERR_HIP: return "HIP runtime error";
     case SLSLAM_ERR_UNSUPPORTED: return "problem shape not supported by the kernels";
     case SLSLAM_ERR_STATE: return "invalid call sequence";
+    case SLSLAM_ERR_NO_MEMORY: return "host allocation failed";
     default: return "unknown status";
   }
 }
@@ -273,6 +281,21 @@ struct slslam_lba_batch {
   DevBuf<double> d_line_x, d_line_x0, d_line_scale; DevBuf<int> d_line_ptr, d_line_flags, d_line_win, d_line_orig;
   DevBuf<double> d_ob; DevBuf<int> d_ob_cam, d_ob_orig;
   DevBuf<double> d_ob_raw;                   // refillable batches: a refill's observations as the caller holds them, permuted into d_ob on the device (k_permute_obs)
+  // the build stage on the device (lba_device_build.h): a refill whose windows go up as the caller holds them
+  DevBuf<RawWin> d_rawwin; DevBuf<BuildWin> d_buildwin; DevBuf<uint32_t> d_raw_idx, d_fmask; DevBuf<double> d_line_raw; DevBuf<uint8_t> d_lflags;
+  DevBuf<int> d_item_base, d_totals;
+  RawWin* h_rawwin = nullptr;                // pinned [B]: what the device reads of every window (uploaded per refill)
+  BuildWin* h_buildwin = nullptr;            // pinned [B]: what came of every window (downloaded with the results)
+  WinDesc* h_wins_dl = nullptr;              // pinned [B]: the descriptors the device made
+  int* h_totals = nullptr;                   // pinned [8]
+  char* h_raw_stage = nullptr;               // pinned, made on demand: pageable inputs are copied here (indices narrowed) and read from here by k_ingest
+  size_t raw_stage_bytes = 0;
+  bool device_built = false;                 // the batch's present windows were built on the device
+  bool inplace_export = false;               // ... and their `parameters` arrays are pinned: results can be written straight into them
+  bool results_inplace = false;              // the last download wrote them there
+  std::vector<slslam_lba_window> src_windows;   // the callers' descriptors of a device-built refill (fallback of flagged windows, in-place export)
+  std::vector<int> build_status;             // per window, after wait(): 0 or the SLSLAM_ERR_* a flagged window is reported with
+  long long n_device_builds = 0, n_zero_copy = 0;
   // windows beyond the tiled sweeps (lba_big.h)
   bool big_mode = false;
   BigPtrs big;
@@ -334,6 +357,10 @@ struct slslam_lba_batch {
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
     d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release(); d_active.release();
     d_fstore.release(); d_line_elim.release(); d_line_h.release(); d_slab_sum.release();
+    d_rawwin.release(); d_buildwin.release(); d_raw_idx.release(); d_fmask.release(); d_line_raw.release(); d_lflags.release(); d_item_base.release(); d_totals.release();
+    if (h_rawwin) (void)hipHostFree(h_rawwin); if (h_buildwin) (void)hipHostFree(h_buildwin); if (h_wins_dl) (void)hipHostFree(h_wins_dl);
+    if (h_totals) (void)hipHostFree(h_totals); if (h_raw_stage) (void)hipHostFree(h_raw_stage);
+    h_rawwin = nullptr; h_buildwin = nullptr; h_wins_dl = nullptr; h_totals = nullptr; h_raw_stage = nullptr; raw_stage_bytes = 0;
     d_big_ob_line.release(); d_big_cam_ptr.release(); d_big_cam_obs.release(); d_big_pair_ptr.release(); d_big_pair_row.release();
     d_big_pair_col.release(); d_big_pair_desc.release(); d_big_flags.release(); d_big_J.release(); d_big_F.release(); d_big_cost.release();
     d_big_camtab.release(); d_big_line_acc.release(); d_big_sys.release(); d_big_scal.release(); d_big_linv.release(); d_big_sys_off.release();
@@ -644,6 +671,15 @@ void fill_tail(const slslam_lba_batch* b, const LayoutPlan& plan, const HostImag
   if (plan.nline == 0) m.line_flags[0] = 1;
 }
 
+// fn(i) for i in [0, n) on the pool's threads (or the calling one); false when some fn(i) threw - an allocation failure in a window's
+// vectors -, which is caught where it happens: nothing unwinds across threads or through the extern "C" entry points
+bool run_all(HostPool* pool, int n, const std::function<void(int)>& fn) {
+  if (pool) return pool->run(n, fn);
+  bool ok = true;
+  for (int i = 0; i < n; ++i) { try { fn(i); } catch (...) { ok = false; } }
+  return ok;
+}
+
 HostPool* batch_pool(slslam_lba_batch* b, int threads) {
   if (threads <= 1) return nullptr;
   if (b->ext_pool) return b->ext_pool;
@@ -671,7 +707,8 @@ __global__ __launch_bounds__(256) void k_permute_obs(BatchPtrs p, const double* 
   out[g] = a; out[p.ob_stride + g] = b; out[2 * p.ob_stride + g] = c; out[3 * p.ob_stride + g] = d;
 }
 
-__global__ __launch_bounds__(256) void k_build_lane_ctx(BatchPtrs p, int ntiles, int32_t* out) {
+__global__ __launch_bounds__(256) void k_build_lane_ctx(BatchPtrs p, int ntiles, const int* ntiles_dev, int32_t* out) {
+  if (ntiles_dev) ntiles = min(ntiles, *ntiles_dev);      // (a device-built refill: the launch covers the room the arrays have, the count is the device's)
   const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
   if (g >= (long long)ntiles * 64) return;
   const int t = (int)(g >> 6), lane = (int)(g & 63);
@@ -695,7 +732,7 @@ __global__ __launch_bounds__(256) void k_build_lane_ctx(BatchPtrs p, int ntiles,
 int device_init_after_upload(slslam_lba_batch* b, hipStream_t s) {
   const long long nt = b->used_tiles;
   if (nt > 0 && !b->big_mode)
-    hipLaunchKernelGGL(k_build_lane_ctx, dim3((unsigned)((nt * 64 + 255) / 256)), dim3(256), 0, s, b->ptrs, (int)nt, b->d_lane_ctx.p);
+    hipLaunchKernelGGL(k_build_lane_ctx, dim3((unsigned)((nt * 64 + 255) / 256)), dim3(256), 0, s, b->ptrs, (int)nt, (const int*)(b->device_built ? b->d_totals.p : nullptr), b->d_lane_ctx.p);
   const long long total = 6LL * b->ncam + (long long)b->nline + b->ptrs.nwin;      // one thread per line / camera parameter / window state
   if (total > 0) hipLaunchKernelGGL(k_reset, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b->ptrs, b->pol);
   HIP_TRY(hipGetLastError());
@@ -768,7 +805,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
         if (st[(size_t)q] == SLSLAM_OK) b->wins[(size_t)todo[(size_t)q]] = std::move(Q);
       };
       HostPool* pool = batch_pool(b, (int)std::min<size_t>(todo.size(), b->opt.host_threads > 0 ? (size_t)b->opt.host_threads : (todo.size() >= 64 ? 8 : 1)));
-      if (pool) pool->run((int)todo.size(), one); else for (int q = 0; q < (int)todo.size(); ++q) one(q);
+      if (!run_all(pool, (int)todo.size(), one)) return SLSLAM_ERR_NO_MEMORY;
       for (int r : st) if (r != SLSLAM_OK) return r;
     }
   }
@@ -859,6 +896,18 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
   ar.staged(b->d_line_orig, cap_line);
   ar.staged(b->d_ob, 8 * cap_obs);
   ar.scratch(b->d_ob_raw, b->refillable ? 8 * cap_obs : 0);
+  {
+    // what the build stage on the device needs beside the batch's own arrays (lba_device_build.h)
+    const bool db = b->refillable && b->opt.device_build >= 0;
+    ar.scratch(b->d_rawwin, db ? (size_t)std::max(1, B) : 0);
+    ar.scratch(b->d_buildwin, db ? (size_t)std::max(1, B) : 0);
+    ar.scratch(b->d_raw_idx, db ? cap_obs : 0);
+    ar.scratch(b->d_fmask, db ? cap_line : 0);
+    ar.scratch(b->d_line_raw, db ? 4 * cap_line : 0);
+    ar.scratch(b->d_lflags, db ? cap_line : 0);
+    ar.scratch(b->d_item_base, db ? (size_t)std::max(1, B) : 0);
+    ar.scratch(b->d_totals, db ? 8 : 0);
+  }
   ar.staged(b->d_ob_cam, cap_obs);
   ar.staged(b->d_ob_orig, cap_obs);
   ar.scratch(b->d_slab, std::max<size_t>(1, room(slab)));
@@ -992,7 +1041,7 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     HostImage img = host_image(b);
     HostPool* pool = batch_pool(b, (int)std::min<long long>(B, b->opt.host_threads > 0 ? b->opt.host_threads : (B >= 64 ? 8 : 1)));
     auto one = [&](int wi) { fill_window(b, plan, b->wins, wi, img, /*copy_observations=*/true); };
-    if (pool) pool->run(B, one); else for (int wi = 0; wi < B; ++wi) one(wi);
+    if (!run_all(pool, B, one)) return SLSLAM_ERR_NO_MEMORY;
     fill_tail(b, plan, img);
   }
   if ((rc = ar.push())) return rc;
@@ -1356,30 +1405,88 @@ extern "C" int slslam_lba_batch_export_device(slslam_lba_batch* b, double* devic
   return SLSLAM_OK;
 }
 
-extern "C" int slslam_lba_batch_download_async(slslam_lba_batch* b, void* stream) {
+namespace {
+// Results of a device-built refill whose `parameters` arrays are page-locked go straight where the caller wants them (reference
+// src/slam.cpp:957-972 reads them there): thread <-> parameter block, the window's destination from the RawWin table.  A window that ended in
+// NUMERICAL_FAILURE is left untouched, as Ceres leaves the user's parameters.
+__global__ __launch_bounds__(256) void k_export_inplace(BatchPtrs p, const RawWin* raw, const int* cam_win, const int* line_orig) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < p.ncam) {
+    const int w = cam_win[i];
+    if (w < 0 || p.state[w].status == SLSLAM_NUMERICAL_FAILURE) return;
+    const WinDesc wd = p.wins[w];
+    const double* x = p.cam_x + ((long long)i * 2 + p.state[w].cur) * kCamRec;
+    double* o = raw[w].params + 6 * (long long)(i - wd.cam_off);
+    for (int a = 0; a < 6; ++a) o[a] = x[a];
+  } else if (i < p.ncam + p.nline) {
+    const int ls = i - p.ncam;
+    const int w = p.line_win[ls];
+    if (w < 0 || p.state[w].status == SLSLAM_NUMERICAL_FAILURE) return;
+    const WinDesc wd = p.wins[w];
+    const double* x = p.line_x + line_rec(p, ls, p.state[w].cur);
+    double* o = raw[w].params + 6 * (long long)wd.C + 4 * (long long)line_orig[ls];
+    for (int a = 0; a < 4; ++a) o[a] = x[a];
+  }
+}
+
+int download_async_impl(slslam_lba_batch* b, void* stream, bool allow_inplace) {
   if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (!b->finalized) return SLSLAM_ERR_STATE;
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
   b->downloaded = false;
   if (b->part[0]) {
-    int rc0 = slslam_lba_batch_download_async(b->part[0], stream);
-    if (rc0 == SLSLAM_OK) rc0 = slslam_lba_batch_download_async(b->part[1], stream);
+    int rc0 = download_async_impl(b->part[0], stream, false);
+    if (rc0 == SLSLAM_OK) rc0 = download_async_impl(b->part[1], stream, false);
     return rc0;
   }
-  int rc = slslam_lba_batch_export_device(b, b->d_params_out.p, stream);
-  if (rc) return rc;
-  if (b->total_params > 0)
-    HIP_TRY(hipMemcpyAsync(b->h_params.data(), b->d_params_out.p, (size_t)b->total_params * sizeof(double), hipMemcpyDeviceToHost, s));
+  const bool inplace = allow_inplace && b->device_built && b->inplace_export;
+  b->results_inplace = inplace;
+  if (inplace) {
+    const int total = b->ncam + b->nline;
+    if (total > 0)
+      hipLaunchKernelGGL(k_export_inplace, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b->ptrs, (const RawWin*)b->d_rawwin.p,
+                         (const int*)b->d_cam_win.p, (const int*)b->d_line_orig.p);
+    HIP_TRY(hipGetLastError());
+  } else {
+    int rc = slslam_lba_batch_export_device(b, b->d_params_out.p, stream);
+    if (rc) return rc;
+    if (b->total_params > 0)
+      HIP_TRY(hipMemcpyAsync(b->h_params.data(), b->d_params_out.p, (size_t)b->total_params * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
   if (!b->h_state.empty()) {
     HIP_TRY(hipMemcpyAsync(b->h_state.data(), b->d_state.p, b->h_state.size() * sizeof(LMState), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(b->h_trace.data(), b->d_trace.p, b->h_trace.size() * sizeof(IterRec), hipMemcpyDeviceToHost, s));
+  }
+  if (b->device_built && !b->wins.empty()) {
+    // what the device made of the windows: descriptors (free cameras, kept residual blocks, chunk cut) and the per-window build status
+    HIP_TRY(hipMemcpyAsync(b->h_wins_dl, b->d_wins.p, b->wins.size() * sizeof(WinDesc), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(b->h_buildwin, b->d_buildwin.p, b->wins.size() * sizeof(BuildWin), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals.p, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
   }
   if (!b->ev_results) HIP_TRY(hipEventCreateWithFlags(&b->ev_results, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(b->ev_results, s));
   b->results_pending = true;
   return SLSLAM_OK;
 }
+
+// after the copies of a download have arrived: the host mirrors of a device-built refill
+void adopt_device_build(slslam_lba_batch* b) {
+  if (!b->device_built) return;
+  const size_t B = b->wins.size();
+  for (size_t i = 0; i < B; ++i) {
+    const BuildWin& bw = b->h_buildwin[i];
+    b->h_wins[i] = b->h_wins_dl[i];
+    b->build_status[i] = bw.status == 0 ? SLSLAM_OK : (bw.status & kBuildInvalid) ? SLSLAM_ERR_INVALID_ARGUMENT : SLSLAM_ERR_UNSUPPORTED;
+    b->h_win_graded[i] = bw.graded;
+    PackedWindow& P = b->wins[i];
+    P.Cf = b->h_wins[i].Cf; P.nfree_params = b->h_wins[i].nfree_params; P.nkept = b->h_wins[i].nkept;
+  }
+  b->used_tiles = b->h_totals[0]; b->used_items = b->h_totals[1];
+}
+}  // namespace
+
+extern "C" int slslam_lba_batch_download_async(slslam_lba_batch* b, void* stream) { return download_async_impl(b, stream, false); }
 
 extern "C" int slslam_lba_batch_wait(slslam_lba_batch* b) {
   if (!b) return SLSLAM_ERR_INVALID_ARGUMENT;
@@ -1396,6 +1503,7 @@ extern "C" int slslam_lba_batch_wait(slslam_lba_batch* b) {
   if (hipEventQuery(b->ev_results) != hipSuccess) HIP_TRY(hipEventSynchronize(b->ev_results));
   b->results_pending = false;
   if (b->profiling) b->harvest_events();
+  adopt_device_build(b);
   b->downloaded = true;
   return SLSLAM_OK;
 }
@@ -1404,6 +1512,235 @@ extern "C" int slslam_lba_batch_download(slslam_lba_batch* b, void* stream) {
   const int rc = slslam_lba_batch_download_async(b, stream);
   return rc != SLSLAM_OK ? rc : slslam_lba_batch_wait(b);
 }
+
+
+namespace {
+
+int ensure_build_host_buffers(slslam_lba_batch* b, int B) {
+  if (!b->h_rawwin) HIP_TRY(hipHostMalloc((void**)&b->h_rawwin, sizeof(RawWin) * (size_t)std::max(1, B), hipHostMallocDefault));
+  if (!b->h_buildwin) { HIP_TRY(hipHostMalloc((void**)&b->h_buildwin, sizeof(BuildWin) * (size_t)std::max(1, B), hipHostMallocDefault)); std::memset(b->h_buildwin, 0, sizeof(BuildWin) * (size_t)std::max(1, B)); }
+  if (!b->h_wins_dl) HIP_TRY(hipHostMalloc((void**)&b->h_wins_dl, sizeof(WinDesc) * (size_t)std::max(1, B), hipHostMallocDefault));
+  if (!b->h_totals) { HIP_TRY(hipHostMalloc((void**)&b->h_totals, sizeof(int) * 8, hipHostMallocDefault)); std::memset(b->h_totals, 0, sizeof(int) * 8); }
+  return SLSLAM_OK;
+}
+
+// Copies `n` doubles (n even or odd) with the NaN / Inf test of lba_pack.cpp::all_finite; non-temporal stores when the destination allows.
+unsigned long long copy_checked(double* dst, const double* src, size_t n) {
+  unsigned long long bad = 0;
+  size_t q = 0;
+#if defined(__SSE2__)
+  if (!(reinterpret_cast<uintptr_t>(dst) & 15u)) {
+    const __m128i expo = _mm_set1_epi64x((long long)0x7ff0000000000000ull), one = _mm_set1_epi64x((long long)0x0010000000000000ull);
+    __m128i acc = _mm_setzero_si128();
+    for (; q + 2 <= n; q += 2) {
+      const __m128d v = _mm_loadu_pd(src + q);
+      _mm_stream_pd(dst + q, v);
+      acc = _mm_or_si128(acc, _mm_add_epi64(_mm_and_si128(_mm_castpd_si128(v), expo), one));
+    }
+    _mm_sfence();
+    unsigned long long lanes[2];
+    _mm_storeu_si128(reinterpret_cast<__m128i*>(lanes), acc);
+    bad |= (lanes[0] | lanes[1]) & 0x8000000000000000ull;
+  }
+#endif
+  for (; q < n; ++q) {
+    unsigned long long x;
+    std::memcpy(&x, src + q, 8);
+    dst[q] = src[q];
+    bad |= ((x & 0x7ff0000000000000ull) + 0x0010000000000000ull) & 0x8000000000000000ull;
+  }
+  return bad;
+}
+
+// The LBAProblem::build stage of a refill ON THE DEVICE (lba_device_build.h).  SLSLAM_OK: taken; SLSLAM_ERR_UNSUPPORTED: not this path's
+// business - nothing was touched, the caller goes on with the host packer; anything else: the refill failed.
+int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, hipStream_t s) {
+  if (b->opt.device_build < 0 || b->d_rawwin.n < (size_t)std::max(1, B) || !b->d_ob_raw.p) return SLSLAM_ERR_UNSUPPORTED;
+  if (std::getenv("SLSLAM_CHUNK_WEIGHTS")) return SLSLAM_ERR_UNSUPPORTED;          // (an experiment knob of the host-side cut)
+  static const bool timing = std::getenv("SLSLAM_REFILL_TIMING") != nullptr;
+  const auto tt0 = std::chrono::steady_clock::now();
+  // ---- what the host knows without reading an array: the windows' sizes, hence their places in the batch
+  std::vector<int> cam_off((size_t)B + 1, 0), line_off((size_t)B + 1, 0);
+  std::vector<long long> obs_off((size_t)B + 1, 0), par_off((size_t)B + 1, 0);
+  int maxL = 0, maxM = 0, maxC = 1;
+  for (int i = 0; i < B; ++i) {
+    const slslam_lba_window& w = windows[i];
+    if (w.num_cameras < 0 || w.num_lines < 0 || w.num_observations < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
+    if (w.num_observations > 0 && (!w.camera_index || !w.line_index || !w.fixed_index || !w.observations)) return SLSLAM_ERR_INVALID_ARGUMENT;
+    if ((w.num_cameras > 0 || w.num_lines > 0) && !w.parameters) return SLSLAM_ERR_INVALID_ARGUMENT;
+    if (w.num_cameras > kMaxCams || w.num_lines > 0xfffe || w.num_observations >= (1 << 24)) return SLSLAM_ERR_UNSUPPORTED;
+    maxL = std::max(maxL, w.num_lines); maxM = std::max(maxM, w.num_observations); maxC = std::max(maxC, w.num_cameras);
+    cam_off[(size_t)i + 1] = cam_off[(size_t)i] + w.num_cameras; line_off[(size_t)i + 1] = line_off[(size_t)i] + w.num_lines;
+    obs_off[(size_t)i + 1] = obs_off[(size_t)i] + w.num_observations;
+    par_off[(size_t)i + 1] = par_off[(size_t)i] + 6LL * w.num_cameras + 4LL * w.num_lines;
+  }
+  const size_t lds_build = build_lds_bytes(maxL), lds_tiles = build_tiles_lds_bytes(maxL, maxL);
+  if (lds_build > 158 * 1024 || lds_tiles > 158 * 1024) return SLSLAM_ERR_UNSUPPORTED;
+  const long long ncam = cam_off[(size_t)B], nline = line_off[(size_t)B], nobs = obs_off[(size_t)B], nparams = par_off[(size_t)B];
+  const long long ob_stride = (long long)(b->d_ob.n / 8);
+  if ((size_t)ncam > b->d_cam_cf.n || (size_t)nline > b->d_line_win.n || nobs > ob_stride || (size_t)nparams > b->d_params_out.n ||
+      (size_t)nparams > b->h_params.size() || maxC > b->cap_maxC || nobs > 0x7fffffffLL)
+    return SLSLAM_ERR_UNSUPPORTED;                      // (the host path says the same, before touching anything)
+  int rc = ensure_build_host_buffers(b, B);
+  if (rc != SLSLAM_OK) return rc;
+  // ---- where the device reads the windows: where they are when all their arrays are page-locked (slslam_pinned_alloc /
+  // slslam_pinned_register), else a pinned staging copy made here by the host threads (indices narrowed on the way)
+  bool all_pinned = true, params_pinned = true;
+  {
+    const std::vector<PinnedRegistry::Range> rs = PinnedRegistry::get().snapshot();
+    for (int i = 0; i < B && (all_pinned || params_pinned); ++i) {
+      const slslam_lba_window& w = windows[i];
+      const size_t M = (size_t)w.num_observations, np = (size_t)6 * w.num_cameras + (size_t)4 * w.num_lines;
+      if (np && !PinnedRegistry::contains(rs, w.parameters, 8 * np)) { params_pinned = false; all_pinned = false; }
+      if (M && all_pinned && !(PinnedRegistry::contains(rs, w.camera_index, 4 * M) && PinnedRegistry::contains(rs, w.line_index, 4 * M) &&
+                               PinnedRegistry::contains(rs, w.fixed_index, 8 * M) && PinnedRegistry::contains(rs, w.observations, 64 * M)))
+        all_pinned = false;
+    }
+  }
+  // the host image / the previous refill's sources may still be read by the device; results under way arrive first (and stay readable)
+  if (b->ev_stage_free) HIP_TRY(hipEventSynchronize(b->ev_stage_free));
+  if (b->results_pending) { HIP_TRY(hipEventSynchronize(b->ev_results)); b->results_pending = false; adopt_device_build(b); b->downloaded = true; if (b->profiling) b->harvest_events(); }
+  const auto tt1 = std::chrono::steady_clock::now();
+  RawWin* rw = b->h_rawwin;
+  if (all_pinned) {
+    for (int i = 0; i < B; ++i) {
+      const slslam_lba_window& w = windows[i];
+      RawWin& r = rw[i];
+      r.cam = w.camera_index; r.line = w.line_index; r.fixed = w.fixed_index; r.packed = nullptr; r.obs = w.observations; r.params = w.parameters;
+    }
+  } else {
+    // staging: per window [observations 64 M | narrowed indices 4 M | parameters], 64-byte aligned pieces
+    std::vector<size_t> st_off((size_t)B + 1, 0);
+    for (int i = 0; i < B; ++i) {
+      const size_t M = (size_t)windows[i].num_observations, np = (size_t)6 * windows[i].num_cameras + (size_t)4 * windows[i].num_lines;
+      st_off[(size_t)i + 1] = st_off[(size_t)i] + ((64 * M + 63) & ~(size_t)63) + ((4 * M + 63) & ~(size_t)63) + ((8 * np + 63) & ~(size_t)63);
+    }
+    if (st_off[(size_t)B] > b->raw_stage_bytes) {
+      if (b->h_raw_stage) { (void)hipHostFree(b->h_raw_stage); b->h_raw_stage = nullptr; b->raw_stage_bytes = 0; }
+      const size_t want = st_off[(size_t)B] + st_off[(size_t)B] / 8 + 4096;
+      HIP_TRY(hipHostMalloc((void**)&b->h_raw_stage, want, hipHostMallocDefault));
+      b->raw_stage_bytes = want;
+    }
+    std::vector<int> st((size_t)B, SLSLAM_OK);
+    HostPool* pool = batch_pool(b, (int)std::min<long long>(B, b->opt.host_threads > 0 ? b->opt.host_threads : (B >= 64 ? 8 : 1)));
+    auto stage_one = [&](int i) {
+      const slslam_lba_window& w = windows[i];
+      const size_t M = (size_t)w.num_observations, np = (size_t)6 * w.num_cameras + (size_t)4 * w.num_lines;
+      char* base = b->h_raw_stage + st_off[(size_t)i];
+      double* ob = reinterpret_cast<double*>(base);
+      uint32_t* ix = reinterpret_cast<uint32_t*>(base + ((64 * M + 63) & ~(size_t)63));
+      double* pr = reinterpret_cast<double*>(base + ((64 * M + 63) & ~(size_t)63) + ((4 * M + 63) & ~(size_t)63));
+      unsigned long long bad = copy_checked(ob, w.observations, 8 * M);
+      bad |= copy_checked(pr, w.parameters, np);
+      const int C = w.num_cameras, L = w.num_lines;
+      unsigned oob = 0;
+      for (size_t q = 0; q < M; ++q) {
+        const int c = w.camera_index[q], l = w.line_index[q];
+        oob |= (unsigned)(c < 0) | (unsigned)(c >= C) | (unsigned)(l < 0) | (unsigned)(l >= L);
+        ix[q] = ((uint32_t)l & 0xffffu) | ((uint32_t)c & 0xffu) << 16 | (w.fixed_index[2 * q] ? 1u << 24 : 0u) | (w.fixed_index[2 * q + 1] ? 1u << 25 : 0u);
+      }
+      if (bad || oob) st[(size_t)i] = SLSLAM_ERR_INVALID_ARGUMENT;           // reported now, as the host packer does
+      RawWin& r = rw[i];
+      r.cam = nullptr; r.line = nullptr; r.fixed = nullptr; r.packed = ix; r.obs = ob; r.params = pr;
+    };
+    if (!run_all(pool, B, stage_one)) return SLSLAM_ERR_NO_MEMORY;
+    for (int v : st) if (v != SLSLAM_OK) return v;
+  }
+  for (int i = 0; i < B; ++i) {
+    RawWin& r = rw[i];
+    r.param_off = par_off[(size_t)i]; r.C = windows[i].num_cameras; r.L = windows[i].num_lines; r.M = windows[i].num_observations;
+    r.cam_off = cam_off[(size_t)i]; r.line_off = line_off[(size_t)i]; r.obs_off = (int)obs_off[(size_t)i]; r.pad = 0;
+  }
+  const auto tt2 = std::chrono::steady_clock::now();
+  // ---- commit: the batch now IS the new windows (what the device makes of them comes back with the results: slslam_lba_batch_wait)
+  b->wins_spare.resize((size_t)B);
+  for (int i = 0; i < B; ++i) {
+    PackedWindow& P = b->wins_spare[(size_t)i];
+    P.C = windows[i].num_cameras; P.L = windows[i].num_lines; P.M = windows[i].num_observations; P.Cf = 0; P.nfree_params = 0; P.nkept = 0;
+    P.big = false; P.dup_free_obs = false; P.grouping = b->elim_grouped ? 1 : 0;
+    P.tiles.clear(); P.lane_map.clear(); P.items.clear(); P.ob.clear(); P.params0.clear(); P.line_order.clear(); P.ob_orig.clear(); P.ob_cam.clear();
+  }
+  b->wins.swap(b->wins_spare);
+  b->h_wins.assign((size_t)B, WinDesc());
+  b->h_param_off.assign(par_off.begin(), par_off.end() - 1);
+  b->h_ob_orig_off.resize((size_t)B);
+  for (int i = 0; i < B; ++i) {
+    WinDesc& wd = b->h_wins[(size_t)i];
+    std::memset(&wd, 0, sizeof(wd));
+    wd.C = rw[i].C; wd.L = rw[i].L; wd.M = rw[i].M; wd.cam_off = rw[i].cam_off; wd.line_off = rw[i].line_off; wd.obs_off = rw[i].obs_off;
+    b->h_ob_orig_off[(size_t)i] = rw[i].obs_off;
+  }
+  b->h_win_graded.assign((size_t)std::max(1, B), 0);
+  b->total_params = nparams; b->nobs = nobs;
+  b->used_ncam = ncam; b->used_nline = nline; b->used_nobs = nobs; b->used_tiles = (long long)b->d_tiles.n; b->used_items = (long long)(b->d_items.n / 2);
+  b->device_built = true; b->inplace_export = all_pinned || params_pinned; b->results_inplace = false;
+  b->src_windows.assign(windows, windows + B);
+  b->build_status.assign((size_t)B, SLSLAM_OK);
+  b->downloaded = false;
+  ++b->n_device_builds; if (all_pinned) ++b->n_zero_copy;
+  // ---- enqueue
+  BuildPtrs P;
+  std::memset(&P, 0, sizeof(P));
+  P.raw = b->d_rawwin.p; P.bw = b->d_buildwin.p; P.nwin = B; P.grouping = b->elim_grouped ? 1 : 0;
+  P.ob_raw = b->d_ob_raw.p; P.raw_idx = b->d_raw_idx.p; P.line_raw = b->d_line_raw.p; P.lflags = b->d_lflags.p; P.fmask = b->d_fmask.p;
+  P.wins = b->d_wins.p; P.tiles = b->d_tiles.p; P.chunks = b->d_chunks.p; P.items = b->d_items.p; P.lane_map = b->d_lane_map.p; P.line_desc = b->d_line_desc.p;
+  P.cam_x0 = b->d_cam_x0.p; P.cam_cf = b->d_cam_cf.p; P.cam_win = b->d_cam_win.p;
+  P.line_x0 = b->d_line_x0.p; P.line_ptr = b->d_line_ptr.p; P.line_flags = b->d_line_flags.p; P.line_win = b->d_line_win.p; P.line_orig = b->d_line_orig.p;
+  P.ob_cam = b->d_ob_cam.p; P.ob_orig = b->d_ob_orig.p; P.param_off = b->d_param_off.p; P.item_base = b->d_item_base.p; P.totals = b->d_totals.p;
+  LayoutArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.chunks_per_window = b->opt.chunks_per_window; a.reproducible = b->opt.reproducible; a.auto_rounds = b->auto_rounds; a.auto_cpw = b->auto_cpw;
+  a.elim_waves = b->elim_waves; a.elim_mode = b->elim_mode; a.equal_chunks = std::getenv("SLSLAM_EQUAL_CHUNKS") ? 1 : 0;
+  a.cap_tiles = (int)std::min<size_t>(b->d_tiles.n, 0x7fffffff); a.cap_items = (int)std::min<size_t>(b->d_items.n / 2, 0x7fffffff); a.cap_chunks = b->nchunk;
+  a.cap_maxn = b->cap_maxn; a.slab_sum = b->slab_sum_stride ? 1 : 0; a.slab_sum_image = b->slab_sum_image ? 1 : 0;
+  a.cap_slab = (long long)b->d_slab.n; a.cap_sys = (long long)b->d_ysys.n; a.slab_sum_stride = b->slab_sum_stride;
+  a.nline = (int)nline; a.nobs = (int)nobs; a.max_free = b->elim_mode == 1 ? (int)kMfmaMaxFree : (int)kMaxFreeCams;
+  for (int cf = 0; cf < kMaxFreeCams + 2; ++cf) a.sys_map_off[cf] = (size_t)cf < b->sys_map_off_of_cf.size() ? b->sys_map_off_of_cf[(size_t)cf] : -1;
+  {
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_build_window, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_build_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      attr_set = true;
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(b->d_rawwin.p, rw, sizeof(RawWin) * (size_t)B, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(b->d_buildwin.p, 0, sizeof(BuildWin) * (size_t)B, s));
+  // the records beyond the refill's lines / cameras belong to no window
+  if ((size_t)nline < b->d_line_win.n) HIP_TRY(hipMemsetAsync(b->d_line_win.p + nline, 0xFF, (b->d_line_win.n - (size_t)nline) * sizeof(int), s));
+  if ((size_t)ncam < b->d_cam_win.n) {
+    HIP_TRY(hipMemsetAsync(b->d_cam_win.p + ncam, 0xFF, (b->d_cam_win.n - (size_t)ncam) * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(b->d_cam_cf.p + ncam, 0xFF, (b->d_cam_cf.n - (size_t)ncam) * sizeof(int), s));
+  }
+  static const int ingest_wgs = std::getenv("SLSLAM_INGEST_WORKGROUPS") ? std::max(1, std::atoi(std::getenv("SLSLAM_INGEST_WORKGROUPS"))) : 64;
+  if (B > 0) {
+    hipLaunchKernelGGL(k_ingest, dim3((unsigned)std::min(B, ingest_wgs)), dim3(256), 0, s, P);
+    if (!b->ev_stage_free) HIP_TRY(hipEventCreateWithFlags(&b->ev_stage_free, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->ev_stage_free, s));
+    hipLaunchKernelGGL(k_build_window, dim3((unsigned)B), dim3(256), lds_build, s, P);
+    hipLaunchKernelGGL(k_build_layout, dim3(1), dim3(256), 0, s, P, a);
+    hipLaunchKernelGGL(k_build_tiles, dim3((unsigned)B), dim3(256), lds_tiles, s, P, (const int*)b->d_cam_cf.p);
+  }
+  HIP_TRY(hipGetLastError());
+  // what a fresh batch finds zeroed
+  HIP_TRY(hipMemsetAsync(b->d_cam_scale.p, 0, b->d_cam_scale.n * sizeof(double), s));
+  HIP_TRY(hipMemsetAsync(b->d_line_scale.p, 0, b->d_line_scale.n * sizeof(double), s));
+  HIP_TRY(hipMemsetAsync(b->d_cam_tab.p, 0, b->d_cam_tab.n * sizeof(double), s));
+  if (b->slab_sum_image) HIP_TRY(hipMemsetAsync(b->d_slab_sum.p, 0, b->d_slab_sum.n * sizeof(double), s));
+  HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
+  if (nobs > 0 && maxM > 0)
+    hipLaunchKernelGGL(k_permute_obs, dim3((unsigned)((maxM + 255) / 256), (unsigned)B), dim3(256), 0, s, b->ptrs, (const double*)b->d_ob_raw.p, (const int*)b->d_ob_orig.p, b->d_ob.p);
+  rc = device_init_after_upload(b, s);
+  if (timing) {
+    const auto tt3 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+    std::fprintf(stderr, "slslam refill (device build, %s): sizes + wait %.2f  stage %.2f  commit + enqueue %.2f ms  (%d windows)\n",
+                 all_pinned ? "zero copy" : "staged", ms(tt0, tt1), ms(tt1, tt2), ms(tt2, tt3), B);
+  }
+  return rc;
+}
+
+}  // namespace
 
 // ------------------------------------------------------------------------------------------
 // A batch for a stream of windows: every window replaced, nothing allocated, nothing captured again (include/slslam_hip.h).
@@ -1415,10 +1752,17 @@ extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_win
   if (n != B) return SLSLAM_ERR_UNSUPPORTED;              // the launches of the captured solve were made for this many windows
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
+  {
+    // the build stage on the device when the windows allow it (lba_device_build.h); UNSUPPORTED: not that path's business, nothing touched
+    const int drc = refill_device(b, windows, n, s);
+    if (drc != SLSLAM_ERR_UNSUPPORTED) return drc;
+  }
   static const bool timing = std::getenv("SLSLAM_REFILL_TIMING") != nullptr;      // host-side split of a refill on stderr
   const auto tt0 = std::chrono::steady_clock::now();
   if (b->ev_stage_free) HIP_TRY(hipEventSynchronize(b->ev_stage_free));      // the host image may still feed the previous refill's copies
-  if (b->results_pending) { HIP_TRY(hipEventSynchronize(b->ev_results)); b->results_pending = false; }
+  // (an asynchronous download still under way has arrived before the host image is touched - and stays readable: a refill that is refused
+  // below leaves the batch as it was, its results included)
+  if (b->results_pending) { HIP_TRY(hipEventSynchronize(b->ev_results)); b->results_pending = false; adopt_device_build(b); b->downloaded = true; if (b->profiling) b->harvest_events(); }
   const auto tt1 = std::chrono::steady_clock::now();
   // ---- pack (the LBAProblem::build stage, one window per host thread), the observations straight into the host image: where a window's
   // observations go only depends on the counts before it
@@ -1443,7 +1787,7 @@ extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_win
     if (device_gather) dest.raw = img.ob + (size_t)obs_off[(size_t)i] * 8;
     st[(size_t)i] = pack_window(&windows[i], &wins[(size_t)i], grouping, &dest);
   };
-  if (pool) pool->run(B, pack_one); else for (int i = 0; i < B; ++i) pack_one(i);
+  if (!run_all(pool, B, pack_one)) return SLSLAM_ERR_NO_MEMORY;
   for (int r : st) if (r != SLSLAM_OK) return r;
   const auto tt2 = std::chrono::steady_clock::now();
   for (const PackedWindow& P : wins) {
@@ -1478,8 +1822,9 @@ extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_win
   b->used_ncam = plan.ncam; b->used_nline = plan.nline; b->used_nobs = plan.nobs; b->used_tiles = plan.ntiles; b->used_items = plan.nitems;
   b->wins.swap(wins);
   b->downloaded = false;
+  b->device_built = false; b->inplace_export = false; b->results_inplace = false; b->src_windows.clear(); b->build_status.clear();
   auto fill_one = [&](int wi) { fill_window(b, plan, b->wins, wi, img, /*copy_observations=*/false); };
-  if (pool) pool->run(B, fill_one); else for (int wi = 0; wi < B; ++wi) fill_one(wi);
+  (void)run_all(pool, B, fill_one);                      // (fill_window copies into the image: it allocates nothing)
   fill_tail(b, plan, img);
   const auto tt3 = std::chrono::steady_clock::now();
   // ---- upload what is used of every array, asynchronously from the pinned image
@@ -1525,6 +1870,14 @@ extern "C" int slslam_lba_batch_get_parameters(const slslam_lba_batch* b, int in
   if (!b->downloaded) return SLSLAM_ERR_STATE;
   const PackedWindow& P = b->wins[index];
   const size_t n = (size_t)6 * P.C + (size_t)4 * P.L;
+  if (b->device_built) {
+    // a window the device build flagged (bad input, a shape for the host path, no room) was emitted empty: it has no result here
+    if (b->build_status[(size_t)index] != SLSLAM_OK) return b->build_status[(size_t)index];
+    // (NUMERICAL_FAILURE: k_export hands back the initial values; in place the kernel left the caller's array alone)
+    if (b->results_inplace) { if (parameters != b->src_windows[(size_t)index].parameters) std::memcpy(parameters, b->src_windows[(size_t)index].parameters, n * sizeof(double)); }
+    else std::memcpy(parameters, b->h_params.data() + b->h_param_off[index], n * sizeof(double));
+    return SLSLAM_OK;
+  }
   // Ceres leaves the user's parameters untouched on NUMERICAL_FAILURE
   if (b->h_state[index].status == SLSLAM_NUMERICAL_FAILURE) std::memcpy(parameters, P.params0.data(), n * sizeof(double));
   else std::memcpy(parameters, b->h_params.data() + b->h_param_off[index], n * sizeof(double));
@@ -1535,6 +1888,7 @@ extern "C" int slslam_lba_batch_get_summary(const slslam_lba_batch* b, int index
   if (!b || !s || index < 0 || index >= b->num_windows()) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (b->part[0]) return slslam_lba_batch_get_summary(b->part[b->route[index].first], b->route[index].second, s);
   if (!b->downloaded) return SLSLAM_ERR_STATE;
+  if (b->device_built && b->build_status[(size_t)index] != SLSLAM_OK) return b->build_status[(size_t)index];
   const LMState& st = b->h_state[index];
   s->num_successful_steps = st.n_success;
   s->num_unsuccessful_steps = st.n_unsuccess;
@@ -1551,6 +1905,7 @@ extern "C" int slslam_lba_batch_get_trace(const slslam_lba_batch* b, int index, 
   if (!b || index < 0 || index >= b->num_windows()) return SLSLAM_ERR_INVALID_ARGUMENT;
   if (b->part[0]) return slslam_lba_batch_get_trace(b->part[b->route[index].first], b->route[index].second, trace, cap, len);
   if (!b->downloaded) return SLSLAM_ERR_STATE;
+  if (b->device_built && b->build_status[(size_t)index] != SLSLAM_OK) return b->build_status[(size_t)index];
   const int n = std::min<int>(b->h_state[index].ntrace, kMaxTrace);
   if (len) *len = n;
   for (int i = 0; trace && i < n && i < cap; ++i) {
@@ -1705,6 +2060,121 @@ extern "C" int slslam_lba_solve(const slslam_lba_window* w, const slslam_solver_
 }
 
 // ------------------------------------------------------------------------------------------
+// Page-locked host memory the GPU reads and writes in place (include/slslam_hip.h)
+extern "C" int slslam_pinned_alloc(size_t bytes, void** out) {
+  if (!out) return SLSLAM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SLSLAM_ERR_NO_DEVICE;
+  HIP_TRY(PinnedRegistry::get().alloc(bytes, out));
+  return SLSLAM_OK;
+}
+extern "C" int slslam_pinned_free(void* p) {
+  if (!p) return SLSLAM_OK;
+  return PinnedRegistry::get().free(p) == 0 ? SLSLAM_OK : SLSLAM_ERR_INVALID_ARGUMENT;
+}
+extern "C" int slslam_pinned_register(void* p, size_t bytes) {
+  if (!p || !bytes) return SLSLAM_ERR_INVALID_ARGUMENT;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SLSLAM_ERR_NO_DEVICE;
+  HIP_TRY(PinnedRegistry::get().register_range(p, bytes));
+  return SLSLAM_OK;
+}
+extern "C" int slslam_pinned_unregister(void* p) {
+  if (!p) return SLSLAM_OK;
+  return PinnedRegistry::get().unregister_range(p) == 0 ? SLSLAM_OK : SLSLAM_ERR_INVALID_ARGUMENT;
+}
+extern "C" int slslam_pinned_contains(const void* p, size_t bytes) { return PinnedRegistry::get().contains(p, bytes) ? 1 : 0; }
+extern "C" int slslam_pack_indices(int n, const int* camera_index, const int* line_index, const int* fixed_index, unsigned int* packed) {
+  if (n < 0 || (n > 0 && (!camera_index || !line_index || !fixed_index || !packed))) return SLSLAM_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < n; ++i) {
+    const int c = camera_index[i], l = line_index[i];
+    if (c < 0 || c > 0xff || l < 0 || l > 0xfffe) return SLSLAM_ERR_UNSUPPORTED;
+    packed[i] = (unsigned)l | (unsigned)c << 16 | (fixed_index[2 * i] ? 1u << 24 : 0u) | (fixed_index[2 * i + 1] ? 1u << 25 : 0u);
+  }
+  return SLSLAM_OK;
+}
+
+// Test hook (tests/test_gpu_device_build.py): ONE window through the device build alone - k_ingest, k_build_window, k_build_layout,
+// k_build_tiles on temporary device arrays - everything pack_window emits comes back in the form tests/host_math::hm_pack_g returns the
+// host packer's output in, so that the two are compared byte for byte.  status_out: the BuildWin.status bits (0: built).
+extern "C" int slslam_debug_device_pack(const slslam_lba_window* w, int grouping, int* out_counts /*Cf, ntiles, nitems, nfree_params, nkept*/,
+                                        int* line_order, int* line_ptr, int* ob_orig, int* ob_cam, int* tiles /*4 per tile: line_begin, nlines, flags, nitems*/,
+                                        unsigned char* items, int* cam_cf, int max_tiles, int max_items, unsigned short* lane_map, unsigned* line_desc,
+                                        int* status_out) {
+  if (!w || !out_counts || !status_out) return SLSLAM_ERR_INVALID_ARGUMENT;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SLSLAM_ERR_NO_DEVICE;
+  const int C = w->num_cameras, L = w->num_lines, M = w->num_observations;
+  if (C < 0 || L < 0 || M < 0 || C > kMaxCams || L > 0xfffe || M >= (1 << 24)) return SLSLAM_ERR_UNSUPPORTED;
+  const size_t lds_build = build_lds_bytes(L), lds_tiles = build_tiles_lds_bytes(L, L);
+  if (lds_build > 158 * 1024 || lds_tiles > 158 * 1024) return SLSLAM_ERR_UNSUPPORTED;
+  const size_t Lq = (size_t)std::max(1, L), Mq = (size_t)std::max(1, M), Cq = (size_t)std::max(1, C), np = (size_t)6 * C + (size_t)4 * L;
+  const size_t cap_tiles = Lq + 8, cap_items = (size_t)std::max(1, max_items);
+  DeviceArena ar;
+  DevBuf<int> d_cam, d_line, d_fixed, d_cam_cf, d_cam_win, d_line_ptr, d_line_flags, d_line_win, d_line_orig, d_ob_cam, d_ob_orig, d_item_base, d_totals;
+  DevBuf<double> d_obs, d_params, d_ob_raw, d_line_raw, d_cam_x0, d_line_x0;
+  DevBuf<uint32_t> d_raw_idx, d_fmask, d_line_desc; DevBuf<uint8_t> d_lflags, d_items; DevBuf<uint16_t> d_lane_map;
+  DevBuf<RawWin> d_raw; DevBuf<BuildWin> d_bw; DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<long long> d_param_off;
+  ar.add(d_cam, Mq, w->camera_index, (size_t)M, 0); ar.add(d_line, Mq, w->line_index, (size_t)M, 0); ar.add(d_fixed, 2 * Mq, w->fixed_index, 2 * (size_t)M, 0);
+  ar.add(d_obs, 8 * Mq, w->observations, 8 * (size_t)M, 0); ar.add(d_params, std::max<size_t>(1, np), (const double*)w->parameters, np, 0);
+  ar.scratch(d_ob_raw, 8 * Mq); ar.scratch(d_raw_idx, Mq); ar.scratch(d_line_raw, 4 * Lq); ar.scratch(d_lflags, Lq); ar.scratch(d_fmask, Lq);
+  ar.scratch(d_wins, 1); ar.scratch(d_tiles, cap_tiles); ar.scratch(d_chunks, 16); ar.scratch(d_items, 2 * cap_items); ar.scratch(d_lane_map, 64 * cap_tiles);
+  ar.scratch(d_line_desc, Lq); ar.scratch(d_cam_x0, 6 * Cq); ar.scratch(d_cam_cf, Cq); ar.scratch(d_cam_win, Cq);
+  ar.scratch(d_line_x0, 4 * Lq); ar.scratch(d_line_ptr, Lq + 1); ar.scratch(d_line_flags, Lq); ar.scratch(d_line_win, Lq); ar.scratch(d_line_orig, Lq);
+  ar.scratch(d_ob_cam, Mq); ar.scratch(d_ob_orig, Mq); ar.scratch(d_param_off, 1); ar.scratch(d_item_base, 1); ar.zeroed(d_totals, 8);
+  ar.scratch(d_raw, 1); ar.zeroed(d_bw, 1);
+  int rc = ar.commit();
+  if (rc != SLSLAM_OK) { ar.release(); return rc; }
+  RawWin r;
+  std::memset(&r, 0, sizeof(r));
+  r.cam = d_cam.p; r.line = d_line.p; r.fixed = d_fixed.p; r.packed = nullptr; r.obs = d_obs.p; r.params = d_params.p;
+  r.C = C; r.L = L; r.M = M;
+  hipError_t e = hipMemcpy(d_raw.p, &r, sizeof(r), hipMemcpyHostToDevice);
+  BuildPtrs P;
+  std::memset(&P, 0, sizeof(P));
+  P.raw = d_raw.p; P.bw = d_bw.p; P.nwin = 1; P.grouping = grouping ? 1 : 0;
+  P.ob_raw = d_ob_raw.p; P.raw_idx = d_raw_idx.p; P.line_raw = d_line_raw.p; P.lflags = d_lflags.p; P.fmask = d_fmask.p;
+  P.wins = d_wins.p; P.tiles = d_tiles.p; P.chunks = d_chunks.p; P.items = d_items.p; P.lane_map = d_lane_map.p; P.line_desc = d_line_desc.p;
+  P.cam_x0 = d_cam_x0.p; P.cam_cf = d_cam_cf.p; P.cam_win = d_cam_win.p;
+  P.line_x0 = d_line_x0.p; P.line_ptr = d_line_ptr.p; P.line_flags = d_line_flags.p; P.line_win = d_line_win.p; P.line_orig = d_line_orig.p;
+  P.ob_cam = d_ob_cam.p; P.ob_orig = d_ob_orig.p; P.param_off = d_param_off.p; P.item_base = d_item_base.p; P.totals = d_totals.p;
+  LayoutArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.chunks_per_window = 1; a.elim_waves = 1; a.cap_tiles = (int)cap_tiles; a.cap_items = (int)cap_items; a.cap_chunks = 16; a.cap_maxn = 6 * kMaxFreeCams;
+  a.slab_sum = 0; a.cap_slab = 1LL << 40; a.cap_sys = 1LL << 40; a.nline = L; a.nobs = M; a.max_free = kMaxFreeCams;
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_build_window, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_build_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_ingest, dim3(1), dim3(256), 0, 0, P);
+    hipLaunchKernelGGL(k_build_window, dim3(1), dim3(256), lds_build, 0, P);
+    hipLaunchKernelGGL(k_build_layout, dim3(1), dim3(256), 0, 0, P, a);
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), lds_tiles, 0, P, (const int*)d_cam_cf.p);
+    e = hipDeviceSynchronize();
+  }
+  BuildWin bw;
+  WinDesc wd;
+  std::memset(&bw, 0, sizeof(bw)); std::memset(&wd, 0, sizeof(wd));
+  if (e == hipSuccess) e = hipMemcpy(&bw, d_bw.p, sizeof(bw), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&wd, d_wins.p, sizeof(wd), hipMemcpyDeviceToHost);
+  *status_out = bw.status;
+  if (e == hipSuccess && bw.status == 0) {
+    out_counts[0] = bw.Cf; out_counts[1] = bw.ntiles; out_counts[2] = bw.nitems; out_counts[3] = bw.nfree_params; out_counts[4] = bw.nkept;
+    if (bw.ntiles > max_tiles || bw.nitems > max_items) { ar.release(); return SLSLAM_ERR_UNSUPPORTED; }
+    auto dl = [&](void* dst, const void* src, size_t bytes) { if (e == hipSuccess && dst && bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); };
+    dl(line_order, d_line_orig.p, sizeof(int) * (size_t)L); dl(line_ptr, d_line_ptr.p, sizeof(int) * ((size_t)L + 1));
+    dl(ob_orig, d_ob_orig.p, sizeof(int) * (size_t)M); dl(ob_cam, d_ob_cam.p, sizeof(int) * (size_t)M); dl(cam_cf, d_cam_cf.p, sizeof(int) * (size_t)C);
+    dl(items, d_items.p, 2 * (size_t)bw.nitems); dl(lane_map, d_lane_map.p, sizeof(uint16_t) * 64 * (size_t)bw.ntiles); dl(line_desc, d_line_desc.p, sizeof(uint32_t) * (size_t)L);
+    std::vector<Tile> ht((size_t)bw.ntiles);
+    dl(ht.data(), d_tiles.p, sizeof(Tile) * ht.size());
+    for (size_t t = 0; t < ht.size() && tiles; ++t) { tiles[4 * t] = ht[t].line_begin; tiles[4 * t + 1] = ht[t].nlines; tiles[4 * t + 2] = ht[t].flags; tiles[4 * t + 3] = ht[t].nitems; }
+  }
+  ar.release();
+  HIP_TRY(e);
+  return SLSLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // A STREAM of windows (BASELINE config 4 taken literally: every window arrives as the five host arrays the reference builds per
 // window, src/slam.cpp:899-921): `depth` refillable batches in flight, each on a HIP stream of its own - while the GPU solves batch k
 // and its copy engine uploads batch k + 1, the host threads pack batch k + 2.
@@ -1726,6 +2196,7 @@ struct slslam_lba_stream {
   // host-side accounting (ms, wall clock of the calling thread)
   double ms_submit = 0, ms_collect_wait = 0, ms_collect_copy = 0;
   long long n_refills = 0, n_builds = 0, n_windows = 0, n_iterations = 0;
+  long long n_device_builds = 0, n_zero_copy = 0, n_fallback_windows = 0;
 };
 
 extern "C" int slslam_lba_stream_create(int device, const slslam_solver_options* opt, int depth, slslam_lba_stream** out) {
@@ -1776,7 +2247,7 @@ extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_
   HIP_TRY(hipSetDevice(st->device));
   int rc = SLSLAM_ERR_UNSUPPORTED;
   if (sl.batch && sl.n == n) rc = slslam_lba_batch_refill(sl.batch, windows, n, (void*)sl.stream);
-  if (rc == SLSLAM_OK) ++st->n_refills;
+  if (rc == SLSLAM_OK) { ++st->n_refills; if (sl.batch->device_built) { ++st->n_device_builds; if (sl.batch->inplace_export && sl.batch->h_rawwin && !sl.batch->h_rawwin[0].packed) ++st->n_zero_copy; } }
   else if (rc == SLSLAM_ERR_UNSUPPORTED) {
     // the first batch of the slot, another number of windows, or windows that do not fit the room the slot's arrays have: a new batch
     if (sl.batch) { HIP_TRY(hipStreamSynchronize(sl.stream)); sl.batch->ext_pool = nullptr; slslam_lba_batch_destroy(sl.batch); sl.batch = nullptr; }
@@ -1785,7 +2256,7 @@ extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_
     b->ext_pool = st->pool.get();
     b->wins.resize((size_t)n);
     std::vector<int> ps((size_t)n, SLSLAM_OK);
-    st->pool->run(n, [&](int i) { ps[(size_t)i] = pack_window(&windows[i], &b->wins[(size_t)i]); });
+    if (!st->pool->run(n, [&](int i) { ps[(size_t)i] = pack_window(&windows[i], &b->wins[(size_t)i]); })) rc = SLSLAM_ERR_NO_MEMORY;
     for (int r : ps) if (r != SLSLAM_OK) rc = r;
     if (rc == SLSLAM_OK) rc = slslam_lba_batch_finalize(b, &st->opt);
     if (rc != SLSLAM_OK) { b->ext_pool = nullptr; slslam_lba_batch_destroy(b); return rc; }
@@ -1793,7 +2264,7 @@ extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_
     ++st->n_builds;
   } else return rc;
   if ((rc = slslam_lba_batch_solve(sl.batch, (void*)sl.stream)) != SLSLAM_OK) return rc;
-  if ((rc = slslam_lba_batch_download_async(sl.batch, (void*)sl.stream)) != SLSLAM_OK) return rc;
+  if ((rc = download_async_impl(sl.batch, (void*)sl.stream, /*allow_inplace=*/true)) != SLSLAM_OK) return rc;
   sl.out_params.resize((size_t)n);
   for (int i = 0; i < n; ++i) sl.out_params[(size_t)i] = windows[i].parameters;
   sl.ticket = st->next_ticket; sl.in_flight = true;
@@ -1813,18 +2284,68 @@ extern "C" int slslam_lba_stream_collect(slslam_lba_stream* st, int ticket, slsl
   if (rc != SLSLAM_OK) return rc;
   const auto t1 = std::chrono::steady_clock::now();
   std::vector<int> rs((size_t)sl.n, SLSLAM_OK);
-  st->pool->run(sl.n, [&](int i) {
-    int r = slslam_lba_batch_get_parameters(sl.batch, i, sl.out_params[(size_t)i]);
-    if (r == SLSLAM_OK && summaries) r = slslam_lba_batch_get_summary(sl.batch, i, summaries + i);
+  // (the step counts through get_summary, which routes a window of a MIXED batch - oversize windows among ordinary ones - to the part
+  // that solved it: the top-level batch of such a slot holds no LM states of its own)
+  std::vector<int> steps((size_t)sl.n, 0);
+  slslam_lba_batch* bt = sl.batch;
+  const bool dev = bt->device_built && !bt->part[0];
+  std::vector<int> flagged;
+  if (dev) for (int i = 0; i < sl.n; ++i) if (bt->build_status[(size_t)i] != SLSLAM_OK) flagged.push_back(i);
+  auto one = [&](int i) {
+    if (dev && bt->build_status[(size_t)i] != SLSLAM_OK) return;                 // below
+    int r = SLSLAM_OK;
+    if (!(dev && bt->results_inplace)) r = slslam_lba_batch_get_parameters(bt, i, sl.out_params[(size_t)i]);     // (in place: the device wrote them there)
+    slslam_summary sm;
+    if (r == SLSLAM_OK) r = slslam_lba_batch_get_summary(bt, i, &sm);
+    if (r == SLSLAM_OK) { steps[(size_t)i] = sm.num_successful_steps + sm.num_unsuccessful_steps; if (summaries) summaries[i] = sm; }
     rs[(size_t)i] = r;
-  });
+  };
+  if (dev && bt->results_inplace) { for (int i = 0; i < sl.n; ++i) one(i); }      // (summaries only: not worth waking the pool)
+  else st->pool->run(sl.n, one);
+  // windows the device build flagged (a camera that sees a line twice, a line with more than 64 observations, more than 20 free cameras,
+  // no room in the slot's arrays, bad input): solved here through the host path, one by one, from what the device read (the caller's
+  // page-locked arrays, or the staging copy) - their status is whatever that path says
+  for (int i : flagged) {
+    const RawWin& r = bt->h_rawwin[i];
+    std::vector<int> cam, line, fixed;
+    slslam_lba_window w;
+    w.num_cameras = r.C; w.num_lines = r.L; w.num_observations = r.M; w.observations = r.obs; w.parameters = sl.out_params[(size_t)i];
+    if (r.packed) {
+      cam.resize((size_t)r.M); line.resize((size_t)r.M); fixed.resize(2 * (size_t)r.M);
+      for (int q = 0; q < r.M; ++q) { const uint32_t v = r.packed[q]; line[(size_t)q] = (int)(v & 0xffffu); cam[(size_t)q] = (int)((v >> 16) & 0xffu); fixed[2 * (size_t)q] = (v >> 24) & 1u; fixed[2 * (size_t)q + 1] = (v >> 25) & 1u; }
+      w.camera_index = cam.data(); w.line_index = line.data(); w.fixed_index = fixed.data();
+    } else { w.camera_index = r.cam; w.line_index = r.line; w.fixed_index = r.fixed; }
+    slslam_solver_options o = st->opt;
+    o.refill_headroom_percent = 0; o.host_threads = 1; o.device_build = -1;
+    slslam_summary sm;
+    const int fr = slslam_lba_solve(&w, &o, &sm, nullptr, 0, nullptr);
+    if (fr == SLSLAM_OK) { steps[(size_t)i] = sm.num_successful_steps + sm.num_unsuccessful_steps; if (summaries) summaries[i] = sm; }
+    rs[(size_t)i] = fr;
+    ++st->n_fallback_windows;
+  }
   for (int r : rs) if (r != SLSLAM_OK) rc = r;
-  for (int i = 0; i < sl.n; ++i) st->n_iterations += sl.batch->h_state[(size_t)i].n_success + sl.batch->h_state[(size_t)i].n_unsuccess;   // reference src/slam.cpp:949-950
+  for (int i = 0; i < sl.n; ++i) st->n_iterations += steps[(size_t)i];   // reference src/slam.cpp:949-950
   sl.in_flight = false;
   const auto t2 = std::chrono::steady_clock::now();
   st->ms_collect_wait += std::chrono::duration<double, std::milli>(t1 - t0).count();
   st->ms_collect_copy += std::chrono::duration<double, std::milli>(t2 - t1).count();
   return rc;
+}
+
+extern "C" int slslam_lba_stream_build_stats(const slslam_lba_stream* st, long long* device_builds, long long* zero_copy, long long* fallback_windows) {
+  if (!st) return SLSLAM_ERR_INVALID_ARGUMENT;
+  if (device_builds) *device_builds = st->n_device_builds;
+  if (zero_copy) *zero_copy = st->n_zero_copy;
+  if (fallback_windows) *fallback_windows = st->n_fallback_windows;
+  return SLSLAM_OK;
+}
+
+extern "C" int slslam_lba_stream_batch(slslam_lba_stream* st, int ticket, slslam_lba_batch** batch) {
+  if (!st || !batch || ticket < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
+  auto& sl = st->slots[(size_t)(ticket % st->depth)];
+  if (sl.ticket != ticket || !sl.batch) return SLSLAM_ERR_STATE;
+  *batch = sl.batch;
+  return SLSLAM_OK;
 }
 
 extern "C" int slslam_lba_stream_stats(const slslam_lba_stream* st, double* ms_submit, double* ms_collect_wait, double* ms_collect_copy,

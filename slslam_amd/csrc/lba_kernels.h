@@ -2244,6 +2244,8 @@ __global__ __launch_bounds__(256) void k_reset(BatchPtrs p, Policy pol) {
 
 // Gathers the accepted parameters of every window into the caller's layout
 // [6C | 4L] per window, windows concatenated.  lane <-> parameter block.
+// A window that ended in NUMERICAL_FAILURE hands back its INITIAL values: Ceres leaves the user's parameters untouched then (the host
+// mirror of a batch keeps a copy for that; a batch built on the device has none, and a collective on the exported vector wants them too).
 __global__ __launch_bounds__(256) void k_export(BatchPtrs p, const long long* win_param_off, const int* cam_win,
                                                 const int* line_orig, double* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2252,7 +2254,7 @@ __global__ __launch_bounds__(256) void k_export(BatchPtrs p, const long long* wi
     if (w < 0) return;                                 // a record beyond the batch's cameras (room for refills)
     const WinDesc wd = p.wins[w];
     const int cur = p.state[w].cur;
-    const double* x = p.cam_x + ((long long)i * 2 + cur) * kCamRec;
+    const double* x = p.state[w].status == kNumericalFailure ? p.cam_x0 + (long long)i * kCamRec : p.cam_x + ((long long)i * 2 + cur) * kCamRec;
     double* o = out + win_param_off[w] + 6 * (long long)(i - wd.cam_off);
     for (int a = 0; a < 6; ++a) o[a] = x[a];
   } else if (i < p.ncam + p.nline) {
@@ -2261,7 +2263,7 @@ __global__ __launch_bounds__(256) void k_export(BatchPtrs p, const long long* wi
     if (w < 0) return;
     const WinDesc wd = p.wins[w];
     const int cur = p.state[w].cur;
-    const double* x = p.line_x + line_rec(p, ls, cur);
+    const double* x = p.state[w].status == kNumericalFailure ? p.line_u0 + 4LL * ls : p.line_x + line_rec(p, ls, cur);
     double* o = out + win_param_off[w] + 6 * (long long)wd.C + 4 * (long long)line_orig[ls];
     for (int a = 0; a < 4; ++a) o[a] = x[a];
   }

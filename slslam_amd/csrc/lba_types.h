@@ -11,6 +11,7 @@
 namespace slslam {
 
 enum { kRunning = -1 };                 // LMState.status while the window is still iterating
+enum { kNumericalFailure = 4 };         // = SLSLAM_NUMERICAL_FAILURE (include/slslam_hip.h)
 enum { kMaxTrace = 64 };                // iteration records kept per window
 enum { kLineRec = 11 };                 // doubles per line record: u[4], trig[7] (88 B, no pad: the sweeps stream whole records)
 enum { kLineElim = 22 };               // doubles per line kept by the elimination: K[10], D2[4], g[4] and - for the streaming

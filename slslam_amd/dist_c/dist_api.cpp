@@ -33,11 +33,12 @@ struct slslam_dist {
   int rank = 0, world = 1, device = 0;
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
-  double* d_sums = nullptr;          // [3]
+  double* d_sums = nullptr;          // [4]: LM steps | initial cost | final cost | ranks whose shard failed
   double* d_local = nullptr;         // this rank's parameters, `slot` doubles
   double* d_all = nullptr;           // world * slot
   long long* d_counts = nullptr;     // [world + 1]: all-gathered counts | this rank's count
   long long slot = 0;
+  int fail_next_shard = 0;           // test hook: the next slslam_dist_solve reports its shard as failed (after solving it)
 };
 
 extern "C" int slslam_dist_unique_id(unsigned char id[SLSLAM_DIST_ID_BYTES]) {
@@ -64,7 +65,7 @@ extern "C" int slslam_dist_create(int rank, int world, int device, const unsigne
   ncclResult_t r = ncclCommInitRank(&d->comm, world, u, rank);
   if (r != ncclSuccess) { std::fprintf(stderr, "slslam_dist: ncclCommInitRank failed: %s\n", ncclGetErrorString(r)); delete d; return SLSLAM_ERR_HIP; }
   if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&d->d_sums, 3 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&d->d_sums, 4 * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&d->d_counts, (size_t)(world + 1) * sizeof(long long)) != hipSuccess) {
     slslam_dist_destroy(d);
     return SLSLAM_ERR_HIP;
@@ -103,35 +104,44 @@ extern "C" int slslam_dist_solve(slslam_dist* d, const slslam_lba_window* w, int
   if (gathered && slot <= 0) return SLSLAM_ERR_INVALID_ARGUMENT;
   DIST_HIP(hipSetDevice(d->device));
   // ---- this rank's shard: one batch, no collective on the data path
-  double local[3] = { 0.0, 0.0, 0.0 };
+  // From here to the last collective NOTHING returns: whatever fails on this rank is recorded in `rc`, the rank contributes zeros and an
+  // error count to the all-reduce, and every rank learns from that count whether the all-gather is to be entered at all - a rank that
+  // left early would leave the others blocked inside RCCL.
+  double local[4] = { 0.0, 0.0, 0.0, 0.0 };          // LM steps | initial cost | final cost | ranks that failed
   long long my_count = 0;
   slslam_lba_batch* b = nullptr;
-  // (every way out of this function - the error returns of the macros included - first waits for the stream, whose asynchronous copies read and
-  // write this frame's variables and the caller's arrays, and then gives the batch back)
+  // (every way out of this function first waits for the stream, whose asynchronous copies read and write this frame's variables and the
+  // caller's arrays, and then gives the batch back)
   struct Guard {
     slslam_lba_batch*& b; hipStream_t s;
     ~Guard() { if (s) (void)hipStreamSynchronize(s); if (b) { slslam_lba_batch_destroy(b); b = nullptr; } }
   } guard{ b, d->stream };
   int rc = SLSLAM_OK;
+  auto note = [&rc](hipError_t e, const char* what) {
+    if (e == hipSuccess) return;
+    std::fprintf(stderr, "slslam_dist: %s failed: %s\n", what, hipGetErrorString(e));
+    if (rc == SLSLAM_OK) rc = SLSLAM_ERR_HIP;
+  };
   if (n > 0) {
-    if ((rc = slslam_lba_batch_create(d->device, &b)) != SLSLAM_OK) return rc;
+    rc = slslam_lba_batch_create(d->device, &b);
     for (int i = 0; i < n && rc == SLSLAM_OK; ++i) { rc = slslam_lba_batch_add(b, &w[i], nullptr); my_count += 6LL * w[i].num_cameras + 4LL * w[i].num_lines; }
     if (rc == SLSLAM_OK) rc = slslam_lba_batch_finalize(b, opt);
     if (rc == SLSLAM_OK) rc = slslam_lba_batch_solve(b, (void*)d->stream);
   }
-  // (a rank whose shard failed still takes part in the collectives - with zeros - so that the others do not hang; it reports its error)
   if (gathered) {
-    if (my_count > slot) rc = rc == SLSLAM_OK ? SLSLAM_ERR_INVALID_ARGUMENT : rc;
+    if (my_count > slot && rc == SLSLAM_OK) rc = SLSLAM_ERR_INVALID_ARGUMENT;
     if (d->slot < slot) {
       if (d->d_local) (void)hipFree(d->d_local);
       if (d->d_all) (void)hipFree(d->d_all);
-      d->d_local = d->d_all = nullptr;
-      DIST_HIP(hipMalloc((void**)&d->d_local, (size_t)slot * sizeof(double)));
-      DIST_HIP(hipMalloc((void**)&d->d_all, (size_t)slot * (size_t)d->world * sizeof(double)));
-      d->slot = slot;
+      d->d_local = d->d_all = nullptr; d->slot = 0;
+      note(hipMalloc((void**)&d->d_local, (size_t)slot * sizeof(double)), "hipMalloc(gather slot)");
+      if (d->d_local) note(hipMalloc((void**)&d->d_all, (size_t)slot * (size_t)d->world * sizeof(double)), "hipMalloc(gather buffer)");
+      if (d->d_local && d->d_all) d->slot = slot;
     }
-    DIST_HIP(hipMemsetAsync(d->d_local, 0, (size_t)slot * sizeof(double), d->stream));
-    if (b && rc == SLSLAM_OK) rc = slslam_lba_batch_export_device(b, d->d_local, (void*)d->stream);      // straight from the parameter buffers: no host round trip
+    if (d->slot >= slot) {
+      note(hipMemsetAsync(d->d_local, 0, (size_t)slot * sizeof(double), d->stream), "hipMemsetAsync");
+      if (b && rc == SLSLAM_OK) rc = slslam_lba_batch_export_device(b, d->d_local, (void*)d->stream);      // straight from the parameter buffers: no host round trip
+    }
   }
   if (b && rc == SLSLAM_OK) {
     rc = slslam_lba_batch_download(b, (void*)d->stream);
@@ -142,14 +152,24 @@ extern "C" int slslam_dist_solve(slslam_dist* d, const slslam_lba_window* w, int
       if (rc == SLSLAM_OK) { local[0] += s.num_successful_steps + s.num_unsuccessful_steps; local[1] += s.initial_cost; local[2] += s.final_cost; }
     }
   }
-  if (rc != SLSLAM_OK) { local[0] = local[1] = local[2] = 0.0; }
-  // ---- the ONE all-reduce of the run summary (reference src/slam.cpp:949-952) ...
-  DIST_HIP(hipMemcpyAsync(d->d_sums, local, sizeof(local), hipMemcpyHostToDevice, d->stream));
-  DIST_NCCL(ncclAllReduce(d->d_sums, d->d_sums, 3, ncclDouble, ncclSum, d->comm, d->stream));
-  DIST_HIP(hipMemcpyAsync(sums, d->d_sums, 3 * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+  if (d->fail_next_shard) { d->fail_next_shard = 0; if (rc == SLSLAM_OK) rc = SLSLAM_ERR_HIP; }      // (test hook: slslam_dist_debug_fail_next_shard)
+  if (rc != SLSLAM_OK) { local[0] = local[1] = local[2] = 0.0; local[3] = 1.0; }
+  // ---- the ONE all-reduce of the run summary (reference src/slam.cpp:949-952) + the count of ranks whose shard failed ...
+  note(hipMemcpyAsync(d->d_sums, local, sizeof(local), hipMemcpyHostToDevice, d->stream), "hipMemcpyAsync(sums)");
+  double total[4] = { 0.0, 0.0, 0.0, 0.0 };
+  {
+    const ncclResult_t r = ncclAllReduce(d->d_sums, d->d_sums, 4, ncclDouble, ncclSum, d->comm, d->stream);
+    if (r != ncclSuccess) { std::fprintf(stderr, "slslam_dist: ncclAllReduce failed: %s\n", ncclGetErrorString(r)); return SLSLAM_ERR_HIP; }   // (the communicator itself is gone: nothing left to keep in step)
+  }
+  note(hipMemcpyAsync(total, d->d_sums, sizeof(total), hipMemcpyDeviceToHost, d->stream), "hipMemcpyAsync(sums back)");
+  note(hipStreamSynchronize(d->stream), "hipStreamSynchronize");
+  sums[0] = total[0]; sums[1] = total[1]; sums[2] = total[2];
+  // a failed shard anywhere: EVERY rank returns an error (the sums omit that shard) and NO rank enters the all-gather
+  const bool any_failed = total[3] > 0.5;
+  if (any_failed) return rc != SLSLAM_OK ? rc : SLSLAM_ERR_STATE;
   // ---- ... and, when asked for, the ONE all-gather of the results (+ the counts, 8 bytes per rank)
   if (gathered) {
-    const long long mine = rc == SLSLAM_OK ? my_count : 0;
+    const long long mine = my_count;
     DIST_HIP(hipMemcpyAsync(d->d_counts + d->world, &mine, sizeof(mine), hipMemcpyHostToDevice, d->stream));
     DIST_NCCL(ncclAllGather(d->d_counts + d->world, d->d_counts, 1, ncclInt64, d->comm, d->stream));
     DIST_NCCL(ncclAllGather(d->d_local, d->d_all, (size_t)slot, ncclDouble, d->comm, d->stream));
@@ -158,4 +178,10 @@ extern "C" int slslam_dist_solve(slslam_dist* d, const slslam_lba_window* w, int
   }
   DIST_HIP(hipStreamSynchronize(d->stream));
   return rc;
+}
+
+extern "C" int slslam_dist_debug_fail_next_shard(slslam_dist* d) {
+  if (!d) return SLSLAM_ERR_INVALID_ARGUMENT;
+  d->fail_next_shard = 1;
+  return SLSLAM_OK;
 }

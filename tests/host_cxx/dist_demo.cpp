@@ -1,5 +1,8 @@
 // tests/host_cxx/dist_demo.cpp — the C-level fan-out (include/slslam_dist.h) as a C++ host would drive it: one process per GPU.
-//   dist_demo <rank> <world> <id_file> <windows.bin> <out.bin> [device]
+//   dist_demo <rank> <world> <id_file> <windows.bin> <out.bin> [device] [inject]
+// inject = 1: before the real solve the rank drives the two error paths of slslam_dist_solve - a shard reported as failed
+// (slslam_dist_debug_fail_next_shard) and a shard with a malformed window - and checks that both calls RETURN (the all-reduce was entered,
+// the all-gather was not), report an error and leave the communicator usable for the real solve that follows.
 // rank 0 writes the communicator id to <id_file>, the other ranks wait for it (any launcher-side channel would do); every rank reads the
 // job's window list, solves its contiguous shard (slslam_dist_shard_range) in place and takes part in the one all-reduce + one
 // all-gather; rank 0 writes [sums(3) | slot | counts(world) | gathered(world * slot)] to <out.bin>.
@@ -75,6 +78,22 @@ int main(int argc, char** argv) {
   double sums[3] = { 0, 0, 0 };
   std::vector<double> gathered((size_t)slot * (size_t)world, 0.0);
   std::vector<long long> counts((size_t)world, 0);
+  if (argc > 7 && std::atoi(argv[7]) == 1 && !mine.empty()) {
+    std::vector<std::vector<double>> keep;
+    for (const slslam_lba_window& m : mine) keep.emplace_back(m.parameters, m.parameters + 6 * m.num_cameras + 4 * m.num_lines);
+    auto restore = [&] { for (size_t i = 0; i < mine.size(); ++i) std::memcpy(mine[i].parameters, keep[i].data(), keep[i].size() * sizeof(double)); };
+    slslam_dist_debug_fail_next_shard(d);
+    const int r1 = slslam_dist_solve(d, mine.data(), (int)mine.size(), &opt, sums, gathered.data(), slot, counts.data());
+    restore();
+    std::vector<int> bad_cam(mine[0].camera_index, mine[0].camera_index + mine[0].num_observations);
+    if (!bad_cam.empty()) bad_cam[0] = mine[0].num_cameras + 3;                 // out of range: the build refuses the window
+    std::vector<slslam_lba_window> bad = mine;
+    bad[0].camera_index = bad_cam.data();
+    const int r2 = slslam_dist_solve(d, bad.data(), (int)bad.size(), &opt, sums, gathered.data(), slot, counts.data());
+    restore();
+    if (r1 == SLSLAM_OK || r2 != SLSLAM_ERR_INVALID_ARGUMENT || sums[0] != 0.0) { std::fprintf(stderr, "rank %d: error paths: %d %d sums %.0f\n", rank, r1, r2, sums[0]); return 3; }
+    std::printf("rank %d: error paths ok (failed shard -> %s, malformed window -> %s; collectives completed)\n", rank, slslam_status_string(r1), slslam_status_string(r2));
+  }
   rc = slslam_dist_solve(d, mine.data(), (int)mine.size(), &opt, sums, gathered.data(), slot, counts.data());
   if (rc != SLSLAM_OK) std::fprintf(stderr, "rank %d: solve: %s\n", rank, slslam_status_string(rc));
   std::printf("rank %d of %d: windows [%lld, %lld), job sums: %.0f LM iterations, cost %.9e -> %.9e\n", rank, world, lo, hi, sums[0], sums[1], sums[2]);

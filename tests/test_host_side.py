@@ -627,8 +627,8 @@ def test_dist_library_exports_every_declared_symbol():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "slslam_amd", "dist_c")])
     L = C.CDLL(os.path.join(ROOT, "slslam_amd", "_lib", "libslslam_dist.so"))
     names = _declared_functions("slslam_dist.h")
-    assert names == ["slslam_dist_create", "slslam_dist_destroy", "slslam_dist_rank", "slslam_dist_shard_range", "slslam_dist_solve",
-                     "slslam_dist_unique_id", "slslam_dist_world"]
+    assert names == ["slslam_dist_create", "slslam_dist_debug_fail_next_shard", "slslam_dist_destroy", "slslam_dist_rank", "slslam_dist_shard_range",
+                     "slslam_dist_solve", "slslam_dist_unique_id", "slslam_dist_world"]
     for n in names:
         assert hasattr(L, n), "include/slslam_dist.h declares %s but libslslam_dist.so does not export it" % n
     L.slslam_dist_shard_range.argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
