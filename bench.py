@@ -305,20 +305,27 @@ def time_batch(windows, device, steps, warmup, **opt):
     return its / dt, 1e3 * dt / steps
 
 
-def streamed_block(windows, device, resident_value, resident_params, batches_timed=8, depth=3, host_threads=0, **opt):
+def streamed_block(windows, device, resident_value, resident_params, batches_timed=8, depth=3, host_threads=0, mode="pinned", **opt):
     """BASELINE config 4 taken literally - a STREAM of windows: every window arrives as the five host arrays the reference builds per
     window (src/slam.cpp:899-921) and its solved parameters go back into the caller's array (:957-972).  Inside the timed region, per
-    batch of len(windows) windows: packing on the host threads (the LBAProblem::build stage) straight into the pinned host image,
-    asynchronous upload, the same captured solve the resident headline replays, download, copy-out - `depth` batches in flight
-    (slslam_lba_stream_*).  Every batch is a fresh set of host arrays over the rank's windows, rotated so that every batch is laid out
-    differently; the first depth + 1 submits (batch builds, graph capture, pinned allocations) are warm-up.  Never the headline `value`:
-    it measures the host, PCIe and the GPU together."""
+    batch of len(windows) windows: the LBAProblem::build stage, the same captured solve the resident headline replays, the results into the
+    callers' arrays - `depth` batches in flight (slslam_lba_stream_*).  mode:
+      "pinned"   the caller's arrays live in page-locked memory (slslam_pinned_alloc): the GPU reads them in place, builds the batch on the
+                 device (csrc/lba_device_build.h) and writes the solved parameters back in place - no host thread touches the data;
+      "pageable" ordinary arrays: the host threads copy them into a pinned staging buffer (indices narrowed on the way), the device builds;
+      "host"     the round-5 path (device_build = -1): packing on the host threads, pinned image, upload, download, copy-out.
+    Every batch is a set of host arrays over the rank's windows, rotated so that every batch is laid out differently (the read-only input
+    arrays are shared between the sets, every set has parameter arrays of its own); the first depth + 1 submits (batch builds, graph
+    capture, pinned allocations) are warm-up.  Never the headline `value`: it measures the host, the host link and the GPU together."""
     B = len(windows)
     nsets = depth + 1 + batches_timed
+    base = capi.WindowSet(windows, pinned=(mode == "pinned"))
     sets = []
     for k in range(nsets):
         r = (k * 37) % B
-        sets.append(capi.WindowSet(windows[r:] + windows[:r]))
+        sets.append(base.derive(list(range(r, B)) + list(range(r))))
+    if mode == "host":
+        opt = dict(opt, device_build=-1)
     st = capi.LBAStream(device=device, depth=depth, host_threads=host_threads, **opt)
     tick = []
     for k in range(depth + 1):                      # warm-up: builds the slots' batches, then one refill
@@ -327,7 +334,7 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
         tick.append(st.submit(sets[k]))
     for k in range(1, depth + 1):
         st.collect(tick[k], want_summaries=False)
-    s0 = st.stats()
+    s0, b0 = st.stats(), st.build_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tick, marks = [], []
@@ -342,7 +349,7 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
     dt = time.perf_counter() - t0                   # ... and `value` also pays for draining the last `depth` batches
     periods = sorted(b - a for a, b in zip(marks[depth:-1], marks[depth + 1:]))
     steady = periods[len(periods) // 2] if periods else None
-    s1 = st.stats()
+    s1, b1 = st.stats(), st.build_stats()
     its = s1["lm_iterations"] - s0["lm_iterations"]
     nwin = s1["windows"] - s0["windows"]
     # the streamed results are the resident batch's results, byte for byte (same windows, same sweep, same cut)
@@ -355,22 +362,30 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
             checked += 1
             equal = equal and bool(np.array_equal(sets[k].parameters(j), resident_params[i]))
     m = sum(len(w["camera_index"]) for w in windows)
-    h2d = 8 * 8 * m + 4 * 2 * m + sum(8 * (6 * w["num_cameras"] + 4 * w["num_lines"]) + 40 * w["num_lines"] for w in windows)
-    out = {"value": its / dt, "unit": "LM iterations/s", "ms_per_batch": 1e3 * dt / batches_timed, "windows_per_batch": B,
-           "batches_timed": batches_timed, "depth": depth, "host_threads": s1["host_threads"],
-           "fraction_of_resident": (its / dt) / resident_value if resident_value else None,
+    npar = sum(8 * (6 * w["num_cameras"] + 4 * w["num_lines"]) for w in windows)
+    link_in = {"pinned": 80 * m + npar, "pageable": 68 * m + npar}.get(mode)
+    if link_in is None:
+        link_in = 8 * 8 * m + 4 * 2 * m + npar + sum(40 * w["num_lines"] for w in windows)
+    out = {"value": its / dt, "unit": "LM iterations/s", "fraction_of_resident": (its / dt) / resident_value if resident_value else None,
+           "host_threads": s1["host_threads"], "mode": mode, "ms_per_batch": 1e3 * dt / batches_timed, "windows_per_batch": B,
+           "batches_timed": batches_timed, "depth": depth,
            "steady_ms_per_batch": 1e3 * steady if steady else None,           # median period between submits once the pipeline is full (a long stream's rate)
            "steady_value": (its / batches_timed) / steady if steady else None,
            "refills": s1["refills"] - s0["refills"], "rebuilds": s1["builds"] - s0["builds"],
-           "host_ms_per_window_wall": (s1["ms_submit"] - s0["ms_submit"]) / max(nwin, 1),
-           "host_thread_ms_per_window_upper_bound": (s1["ms_submit"] - s0["ms_submit"]) * s1["host_threads"] / max(nwin, 1),
+           "device_builds": b1["device_builds"] - b0["device_builds"], "zero_copy_batches": b1["zero_copy"] - b0["zero_copy"],
+           "windows_handed_to_the_host_path": b1["fallback_windows"] - b0["fallback_windows"],
            "ms_per_batch_in_submit": (s1["ms_submit"] - s0["ms_submit"]) / batches_timed,
            "ms_per_batch_waiting_in_collect": (s1["ms_collect_wait"] - s0["ms_collect_wait"]) / batches_timed,
            "ms_per_batch_copying_results_out": (s1["ms_collect_copy"] - s0["ms_collect_copy"]) / batches_timed,
-           "approx_h2d_MB_per_batch": h2d / 1e6, "lm_iterations": its,
+           "host_link_in_MB_per_batch": link_in / 1e6, "host_link_out_MB_per_batch": npar / 1e6, "lm_iterations": its,
            "bitwise_equal_to_resident_batch": equal if checked else None, "windows_compared": checked,
-           "timed_region": "per batch: pack (host threads) + pinned H2D + hipGraph solve + D2H + copy-out into the callers' arrays, %d batches in flight" % depth}
+           "timed_region": {"pinned": "per batch: zero-copy ingest from the callers' page-locked arrays + build on the device + hipGraph solve + results written in place, %d batches in flight",
+                            "pageable": "per batch: staging copy (host threads, indices narrowed) + ingest + build on the device + hipGraph solve + D2H + copy-out, %d batches in flight",
+                            "host": "per batch: pack (host threads) + pinned H2D + hipGraph solve + D2H + copy-out into the callers' arrays, %d batches in flight"}[mode] % depth}
     st.close()
+    for ws in sets:
+        ws.close()
+    base.close()
     return out
 
 
@@ -789,12 +804,23 @@ def main():
             for bt in batches:
                 bt.close()
             batches = []
+            sopt = dict(depth=args.stream_depth, chunks_per_window=args.chunks, lba_elimination=args.elim, lba_keep_jacobian=args.keep_jacobian)
             try:
+                # the caller's arrays in page-locked memory: read in place, built on the device, written back in place - ONE host thread
                 out["streamed"] = streamed_block(windows, local_rank, out["value"], resident_params, batches_timed=args.stream_batches,
-                                                 host_threads=args.host_threads, depth=args.stream_depth, chunks_per_window=args.chunks, lba_elimination=args.elim,
-                                                 lba_keep_jacobian=args.keep_jacobian)
+                                                 host_threads=args.host_threads or 1, mode="pinned", **sopt)
             except capi.SlslamError as e:
                 out["streamed"] = {"error": str(e)}
+            if not args.no_extra_configs:
+                try:
+                    # ordinary (pageable) arrays: the staging copy on TWO host threads, the build on the device
+                    out["streamed_pageable"] = streamed_block(windows, local_rank, out["value"], resident_params, batches_timed=max(6, args.stream_batches // 2),
+                                                              host_threads=args.host_threads or 2, mode="pageable", **sopt)
+                    # the round-5 path for comparison: everything on the host threads (up to 16)
+                    out["streamed_host_packer"] = streamed_block(windows, local_rank, out["value"], resident_params, batches_timed=max(6, args.stream_batches // 2),
+                                                                 host_threads=args.host_threads, mode="host", **sopt)
+                except capi.SlslamError as e:
+                    out["streamed_pageable"] = {"error": str(e)}
         if world == 1 and not args.no_extra_configs:
             for bt in batches:           # release HBM before the extra measurements
                 bt.close()

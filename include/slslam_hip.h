@@ -434,6 +434,10 @@ int slslam_debug_read_cycles(slslam_lba_batch* batch, unsigned long long* out, l
 int slslam_debug_device_pack(const slslam_lba_window* window, int grouping, int* counts, int* line_order, int* line_ptr, int* ob_orig,
                              int* ob_cam, int* tiles, unsigned char* items, int* cam_cf, int max_tiles, int max_items,
                              unsigned short* lane_map, unsigned* line_desc, int* status);
+/* ... with the shader-clock stamps of k_build_window's phases (tools/build_phases.py): phase_clocks[0 .. 9], or NULL. */
+int slslam_debug_device_pack_timed(const slslam_lba_window* window, int grouping, int* counts, int* line_order, int* line_ptr, int* ob_orig,
+                                   int* ob_cam, int* tiles, unsigned char* items, int* cam_cf, int max_tiles, int max_items,
+                                   unsigned short* lane_map, unsigned* line_desc, int* status, unsigned long long* phase_clocks);
 
 /* ------------------------------------------------------------------ misc */
 int         slslam_device_count(void);          /* 0 when no HIP device is usable */

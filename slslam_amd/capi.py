@@ -84,7 +84,7 @@ EXPORTS = [
     "slslam_lba_batch_download", "slslam_lba_batch_download_async", "slslam_lba_batch_wait", "slslam_lba_batch_refill",
     "slslam_lba_stream_create", "slslam_lba_stream_destroy", "slslam_lba_stream_submit", "slslam_lba_stream_collect", "slslam_lba_stream_stats",
     "slslam_lba_stream_build_stats", "slslam_lba_stream_batch", "slslam_pinned_alloc", "slslam_pinned_free", "slslam_pinned_register", "slslam_pinned_unregister",
-    "slslam_pinned_contains", "slslam_pack_indices", "slslam_debug_device_pack",
+    "slslam_pinned_contains", "slslam_pack_indices", "slslam_debug_device_pack", "slslam_debug_device_pack_timed",
     "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts", "slslam_lba_batch_window_chunks", "slslam_lba_batch_path", "slslam_lba_batch_elimination",
     "slslam_lba_batch_iterations", "slslam_lba_batch_set_profiling", "slslam_lba_batch_kernel_times", "slslam_lba_batch_linearise",
@@ -136,6 +136,7 @@ def lib():
     L.slslam_pack_indices.argtypes = [C.c_int, ip, ip, ip, C.POINTER(C.c_uint)]
     L.slslam_debug_device_pack.argtypes = [C.POINTER(LBAWindow), C.c_int, ip, ip, ip, ip, ip, ip, C.POINTER(C.c_ubyte), ip, C.c_int, C.c_int,
                                            C.POINTER(C.c_ushort), C.POINTER(C.c_uint), ip]
+    L.slslam_debug_device_pack_timed.argtypes = L.slslam_debug_device_pack.argtypes + [C.POINTER(C.c_ulonglong)]
     L.slslam_lba_batch_get_parameters.argtypes = [vp, C.c_int, dp]
     L.slslam_lba_batch_get_summary.argtypes = [vp, C.c_int, C.POINTER(Summary)]
     L.slslam_lba_batch_get_trace.argtypes = [vp, C.c_int, C.POINTER(Iteration), C.c_int, ip]
@@ -252,14 +253,15 @@ class PinnedArena:
 class _WindowArrays:
     """Keeps the numpy buffers a slslam_lba_window points to alive."""
 
-    def __init__(self, w, params=None, arena=None):
+    def __init__(self, w, params=None, arena=None, params_arena=None):
         self.cam = np.ascontiguousarray(w["camera_index"], dtype=np.int32)
         self.line = np.ascontiguousarray(w["line_index"], dtype=np.int32)
         self.fixed = np.ascontiguousarray(w["fixed_index"], dtype=np.int32).reshape(-1)
         self.obs = np.ascontiguousarray(w["observations"], dtype=np.float64).reshape(-1)
         self.params = np.array(w["parameters"] if params is None else params, dtype=np.float64).reshape(-1).copy()
         if arena is not None:
-            self.cam, self.line, self.fixed, self.obs, self.params = (arena.take(x) for x in (self.cam, self.line, self.fixed, self.obs, self.params))
+            self.cam, self.line, self.fixed, self.obs = (arena.take(x) for x in (self.cam, self.line, self.fixed, self.obs))
+            self.params = (params_arena or arena).take(self.params)
         m = len(self.cam)
         if len(self.line) != m or len(self.fixed) != 2 * m or len(self.obs) != 8 * m:
             raise ValueError("inconsistent window arrays")
@@ -409,11 +411,13 @@ class WindowSet:
     def __init__(self, windows, pinned=False):
         """pinned: the arrays live in ONE page-locked block (slslam_pinned_alloc): the device build reads them in place (zero copy) and the
         solved parameters are written back into them by the GPU."""
-        self.arena = None
+        self.arena = self.params_arena = None
         if pinned:
-            need = sum(80 * len(w["camera_index"]) + 8 * (6 * int(w["num_cameras"]) + 4 * int(w["num_lines"])) + 5 * 64 for w in windows)
-            self.arena = PinnedArena(need + 4096)
-        self.arrays = [_WindowArrays(w, arena=self.arena) for w in windows]
+            # the read-only arrays of all windows in one block, the parameter arrays in another (derive() gives a set parameter arrays of its
+            # own over the same inputs): arrays that lie next to each other go up in a few large copies
+            self.arena = PinnedArena(sum(80 * len(w["camera_index"]) + 4 * 64 for w in windows) + 4096)
+            self.params_arena = PinnedArena(sum(8 * (6 * int(w["num_cameras"]) + 4 * int(w["num_lines"])) + 64 for w in windows) + 4096)
+        self.arrays = [_WindowArrays(w, arena=self.arena, params_arena=self.params_arena) for w in windows]
         self.c = (LBAWindow * max(len(self.arrays), 1))(*[a.c for a in self.arrays])
         self.sizes = [(int(w["num_cameras"]), int(w["num_lines"])) for w in windows]
 
@@ -423,11 +427,32 @@ class WindowSet:
     def parameters(self, i):
         return self.arrays[i].params
 
-    def close(self):
+    def derive(self, order):
+        """Another set over the SAME input arrays (indices, observations: read only) in another window order, with parameter arrays of its
+        own holding the present values of this set's - what a bench needs to submit many distinct sets without holding each set's gigabyte
+        of observations once more.  Page-locked like this set."""
+        import copy
+        out = WindowSet.__new__(WindowSet)
+        out.arena = out.params_arena = None
         if self.arena is not None:
-            self.arrays = []
-            self.arena.close()
-            self.arena = None
+            out.params_arena = PinnedArena(sum(a.params.nbytes + 64 for a in self.arrays) + 4096)
+        out.arrays = []
+        for j in order:
+            a = copy.copy(self.arrays[j])
+            a.params = out.params_arena.take(a.params) if out.params_arena is not None else a.params.copy()
+            a.c = LBAWindow(a.c.num_cameras, a.c.num_lines, a.c.num_observations, _ip(a.cam), _ip(a.line), _ip(a.fixed), _dp(a.obs), _dp(a.params))
+            out.arrays.append(a)
+        out.c = (LBAWindow * max(len(out.arrays), 1))(*[a.c for a in out.arrays])
+        out.sizes = [self.sizes[j] for j in order]
+        out._base = self                      # (the shared arrays live in the base set's block)
+        return out
+
+    def close(self):
+        self.arrays = [] if (self.arena is not None or self.params_arena is not None) else self.arrays
+        for name in ("arena", "params_arena"):
+            if getattr(self, name, None) is not None:
+                getattr(self, name).close()
+                setattr(self, name, None)
 
 
 class _BatchView(LBABatch):
@@ -442,8 +467,9 @@ class _BatchView(LBABatch):
         self._h = C.c_void_p()
 
 
-def debug_device_pack(w, grouping=0):
-    """slslam_debug_device_pack: one window through the device build alone; returns (status bits, dict as tests/test_host_side.py::_pack)."""
+def debug_device_pack(w, grouping=0, clocks=None):
+    """slslam_debug_device_pack: one window through the device build alone; returns (status bits, dict as tests/test_host_side.py::_pack).
+    clocks: a numpy uint64[16] that receives the shader-clock stamps of k_build_window's phases."""
     arr = _WindowArrays(w)
     Cn, L, M = int(w["num_cameras"]), int(w["num_lines"]), len(arr.cam)
     counts = np.zeros(5, dtype=np.int32)
@@ -455,9 +481,10 @@ def debug_device_pack(w, grouping=0):
     lane_map = np.zeros(64 * max_tiles, dtype=np.uint16)
     desc = np.zeros(max(L, 1), dtype=np.uint32)
     st = C.c_int(-1)
-    _check(lib().slslam_debug_device_pack(C.byref(arr.c), int(grouping), _ip(counts), _ip(lo), _ip(lp), _ip(oo), _ip(oc), _ip(tiles),
-                                          items.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cf), max_tiles, max_items,
-                                          lane_map.ctypes.data_as(C.POINTER(C.c_ushort)), desc.ctypes.data_as(C.POINTER(C.c_uint)), C.byref(st)),
+    _check(lib().slslam_debug_device_pack_timed(C.byref(arr.c), int(grouping), _ip(counts), _ip(lo), _ip(lp), _ip(oo), _ip(oc), _ip(tiles),
+                                                items.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cf), max_tiles, max_items,
+                                                lane_map.ctypes.data_as(C.POINTER(C.c_ushort)), desc.ctypes.data_as(C.POINTER(C.c_uint)), C.byref(st),
+                                                clocks.ctypes.data_as(C.POINTER(C.c_ulonglong)) if clocks is not None else None),
            "slslam_debug_device_pack")
     return st.value, dict(desc=desc[:L], Cf=int(counts[0]), ntiles=int(counts[1]), nitems=int(counts[2]), nfree=int(counts[3]), nkept=int(counts[4]),
                           line_order=lo[:L], line_ptr=lp, ob_orig=oo[:M], ob_cam=oc[:M], cam_cf=cf[:Cn],

@@ -283,13 +283,18 @@ struct slslam_lba_batch {
   DevBuf<double> d_ob_raw;                   // refillable batches: a refill's observations as the caller holds them, permuted into d_ob on the device (k_permute_obs)
   // the build stage on the device (lba_device_build.h): a refill whose windows go up as the caller holds them
   DevBuf<RawWin> d_rawwin; DevBuf<BuildWin> d_buildwin; DevBuf<uint32_t> d_raw_idx, d_fmask; DevBuf<double> d_line_raw; DevBuf<uint8_t> d_lflags;
-  DevBuf<int> d_item_base, d_totals;
+  DevBuf<int> d_item_base, d_totals, d_line_pos;
+  DevBuf<uint32_t> d_mid_keys; DevBuf<BuildLine> d_mid_li; DevBuf<uint4> d_mid_rows; DevBuf<uint16_t> d_mid_next, d_mid_trows, d_mid_tptr; DevBuf<BuildMid> d_mid;
   RawWin* h_rawwin = nullptr;                // pinned [B]: what the device reads of every window (uploaded per refill)
   BuildWin* h_buildwin = nullptr;            // pinned [B]: what came of every window (downloaded with the results)
   WinDesc* h_wins_dl = nullptr;              // pinned [B]: the descriptors the device made
   int* h_totals = nullptr;                   // pinned [8]
-  char* h_raw_stage = nullptr;               // pinned, made on demand: pageable inputs are copied here (indices narrowed) and read from here by k_ingest
+  char* h_raw_stage = nullptr;               // pinned, made on demand: pageable inputs are copied here (indices narrowed on the way)
   size_t raw_stage_bytes = 0;
+  char* d_stage_in = nullptr;                // device, made on demand: where the copy engine puts a refill's arrays (k_ingest reads them from here)
+  size_t d_stage_bytes = 0;
+  std::vector<RawWin> host_src;              // per window: host-readable pointers to what the device was given (the callers' page-locked arrays, or the staging copy)
+  int ingest_mode = 0;                       // of the last device-built refill: 0 zero-copy kernel reads of the callers' page-locked arrays, 1 copy engine
   bool device_built = false;                 // the batch's present windows were built on the device
   bool inplace_export = false;               // ... and their `parameters` arrays are pinned: results can be written straight into them
   bool results_inplace = false;              // the last download wrote them there
@@ -357,9 +362,12 @@ struct slslam_lba_batch {
     d_slab.release(); d_bs_part.release(); d_cost_part.release(); d_ysys.release(); d_params_out.release();
     d_state.release(); d_trace.release(); d_param_off.release(); d_iter_counter.release(); d_active.release();
     d_fstore.release(); d_line_elim.release(); d_line_h.release(); d_slab_sum.release();
-    d_rawwin.release(); d_buildwin.release(); d_raw_idx.release(); d_fmask.release(); d_line_raw.release(); d_lflags.release(); d_item_base.release(); d_totals.release();
+    d_rawwin.release(); d_buildwin.release(); d_raw_idx.release(); d_fmask.release(); d_line_raw.release(); d_lflags.release(); d_item_base.release(); d_totals.release(); d_line_pos.release();
+    d_mid_keys.release(); d_mid_li.release(); d_mid_rows.release(); d_mid_next.release(); d_mid_trows.release(); d_mid_tptr.release(); d_mid.release();
     if (h_rawwin) (void)hipHostFree(h_rawwin); if (h_buildwin) (void)hipHostFree(h_buildwin); if (h_wins_dl) (void)hipHostFree(h_wins_dl);
     if (h_totals) (void)hipHostFree(h_totals); if (h_raw_stage) (void)hipHostFree(h_raw_stage);
+    if (d_stage_in) (void)hipFree(d_stage_in);
+    d_stage_in = nullptr; d_stage_bytes = 0;
     h_rawwin = nullptr; h_buildwin = nullptr; h_wins_dl = nullptr; h_totals = nullptr; h_raw_stage = nullptr; raw_stage_bytes = 0;
     d_big_ob_line.release(); d_big_cam_ptr.release(); d_big_cam_obs.release(); d_big_pair_ptr.release(); d_big_pair_row.release();
     d_big_pair_col.release(); d_big_pair_desc.release(); d_big_flags.release(); d_big_J.release(); d_big_F.release(); d_big_cost.release();
@@ -907,6 +915,10 @@ extern "C" int slslam_lba_batch_finalize(slslam_lba_batch* b, const slslam_solve
     ar.scratch(b->d_lflags, db ? cap_line : 0);
     ar.scratch(b->d_item_base, db ? (size_t)std::max(1, B) : 0);
     ar.scratch(b->d_totals, db ? 8 : 0);
+    ar.scratch(b->d_line_pos, db ? cap_line : 0);
+    ar.scratch(b->d_mid_keys, db ? cap_line : 0); ar.scratch(b->d_mid_li, db ? cap_line : 0); ar.scratch(b->d_mid_rows, db ? cap_line : 0);
+    ar.scratch(b->d_mid_next, db ? cap_line : 0); ar.scratch(b->d_mid_trows, db ? cap_line + 8 * (size_t)std::max(1, B) : 0);
+    ar.scratch(b->d_mid_tptr, db ? cap_line + 8 * (size_t)std::max(1, B) : 0); ar.scratch(b->d_mid, db ? (size_t)std::max(1, B) : 0);
   }
   ar.staged(b->d_ob_cam, cap_obs);
   ar.staged(b->d_ob_orig, cap_obs);
@@ -1409,24 +1421,18 @@ namespace {
 // Results of a device-built refill whose `parameters` arrays are page-locked go straight where the caller wants them (reference
 // src/slam.cpp:957-972 reads them there): thread <-> parameter block, the window's destination from the RawWin table.  A window that ended in
 // NUMERICAL_FAILURE is left untouched, as Ceres leaves the user's parameters.
-__global__ __launch_bounds__(256) void k_export_inplace(BatchPtrs p, const RawWin* raw, const int* cam_win, const int* line_orig) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < p.ncam) {
-    const int w = cam_win[i];
-    if (w < 0 || p.state[w].status == SLSLAM_NUMERICAL_FAILURE) return;
-    const WinDesc wd = p.wins[w];
-    const double* x = p.cam_x + ((long long)i * 2 + p.state[w].cur) * kCamRec;
-    double* o = raw[w].params + 6 * (long long)(i - wd.cam_off);
-    for (int a = 0; a < 6; ++a) o[a] = x[a];
-  } else if (i < p.ncam + p.nline) {
-    const int ls = i - p.ncam;
-    const int w = p.line_win[ls];
-    if (w < 0 || p.state[w].status == SLSLAM_NUMERICAL_FAILURE) return;
-    const WinDesc wd = p.wins[w];
-    const double* x = p.line_x + line_rec(p, ls, p.state[w].cur);
-    double* o = raw[w].params + 6 * (long long)wd.C + 4 * (long long)line_orig[ls];
-    for (int a = 0; a < 4; ++a) o[a] = x[a];
-  }
+__global__ __launch_bounds__(256) void k_export_inplace(BatchPtrs p, const RawWin* raw, const int* line_pos) {
+  // thread <-> one double of window blockIdx.y's parameter vector, in the CALLER'S order: consecutive lanes write consecutive addresses
+  // (the destination is host memory across the link: 8-byte stores scattered by the sorted line order ran at a sixth of its rate)
+  const int w = blockIdx.y;
+  const WinDesc wd = p.wins[w];
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= 6 * wd.C + 4 * wd.L || p.state[w].status == SLSLAM_NUMERICAL_FAILURE) return;
+  const int cur = p.state[w].cur;
+  double v;
+  if (q < 6 * wd.C) { const int c = q / 6; v = p.cam_x[((long long)(wd.cam_off + c) * 2 + cur) * kCamRec + (q - 6 * c)]; }
+  else { const int ql = q - 6 * wd.C, l = ql >> 2; v = p.line_x[line_rec(p, (long long)wd.line_off + line_pos[wd.line_off + l], cur) + (ql & 3)]; }
+  raw[w].params[q] = v;
 }
 
 int download_async_impl(slslam_lba_batch* b, void* stream, bool allow_inplace) {
@@ -1443,10 +1449,11 @@ int download_async_impl(slslam_lba_batch* b, void* stream, bool allow_inplace) {
   const bool inplace = allow_inplace && b->device_built && b->inplace_export;
   b->results_inplace = inplace;
   if (inplace) {
-    const int total = b->ncam + b->nline;
-    if (total > 0)
-      hipLaunchKernelGGL(k_export_inplace, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b->ptrs, (const RawWin*)b->d_rawwin.p,
-                         (const int*)b->d_cam_win.p, (const int*)b->d_line_orig.p);
+    long long maxp = 0;
+    for (const PackedWindow& P : b->wins) maxp = std::max(maxp, 6LL * P.C + 4LL * P.L);
+    if (maxp > 0 && !b->wins.empty())
+      hipLaunchKernelGGL(k_export_inplace, dim3((unsigned)((maxp + 255) / 256), (unsigned)b->wins.size()), dim3(256), 0, s, b->ptrs, (const RawWin*)b->d_rawwin.p,
+                         (const int*)b->d_line_pos.p);
     HIP_TRY(hipGetLastError());
   } else {
     int rc = slslam_lba_batch_export_device(b, b->d_params_out.p, stream);
@@ -1554,7 +1561,12 @@ unsigned long long copy_checked(double* dst, const double* src, size_t n) {
 
 // The LBAProblem::build stage of a refill ON THE DEVICE (lba_device_build.h).  SLSLAM_OK: taken; SLSLAM_ERR_UNSUPPORTED: not this path's
 // business - nothing was touched, the caller goes on with the host packer; anything else: the refill failed.
-int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, hipStream_t s) {
+// Two streams: the ingest (the host link's business: few workgroups for ~20 ms per 1024 x 2000-line batch) is enqueued on `s_in`, everything
+// after it on `s` behind an event.  One stream for both (the plain refill entry point) is fine; a STREAM of windows hands ONE ingest stream
+// and ONE solve stream to all its slots, so that batch k + 1 crosses the link while batch k is solved and neither shares its resource
+// (batches that ingest and solve at the same time on streams of their own fall into step: three ingests share the link, then three
+// solves share the chip - measured 37 ms per batch against 20).
+int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, hipStream_t s, hipStream_t s_in) {
   if (b->opt.device_build < 0 || b->d_rawwin.n < (size_t)std::max(1, B) || !b->d_ob_raw.p) return SLSLAM_ERR_UNSUPPORTED;
   if (std::getenv("SLSLAM_CHUNK_WEIGHTS")) return SLSLAM_ERR_UNSUPPORTED;          // (an experiment knob of the host-side cut)
   static const bool timing = std::getenv("SLSLAM_REFILL_TIMING") != nullptr;
@@ -1602,12 +1614,43 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
   if (b->results_pending) { HIP_TRY(hipEventSynchronize(b->ev_results)); b->results_pending = false; adopt_device_build(b); b->downloaded = true; if (b->profiling) b->harvest_events(); }
   const auto tt1 = std::chrono::steady_clock::now();
   RawWin* rw = b->h_rawwin;
+  b->host_src.assign((size_t)B, RawWin());
+  // copies the copy engine is to make before the ingest (host address, device offset in d_stage_in, bytes); empty: the ingest kernel reads
+  // the callers' arrays itself (zero copy)
+  struct Run { uintptr_t lo, hi; size_t dev_off; };
+  std::vector<Run> runs;
+  size_t dev_need = 0;
   if (all_pinned) {
     for (int i = 0; i < B; ++i) {
       const slslam_lba_window& w = windows[i];
-      RawWin& r = rw[i];
-      r.cam = w.camera_index; r.line = w.line_index; r.fixed = w.fixed_index; r.packed = nullptr; r.obs = w.observations; r.params = w.parameters;
+      RawWin& r = b->host_src[(size_t)i];
+      r.cam = w.camera_index; r.line = w.line_index; r.fixed = w.fixed_index; r.packed = nullptr; r.obs = w.observations; r.params_in = w.parameters; r.params = w.parameters;
+      rw[i] = r;
     }
+    // Arrays that lie next to each other in host memory (a caller that carves its windows out of an arena) go up in a few large copies of
+    // the copy engine, which does not travel through the shader's L2: a kernel that keeps the link full has ~0.5 MB of host reads
+    // outstanding in the L2 channels, and every latency-bound kernel beside it waits behind them (the window build 2.7 -> 11.6 ms, k_build_tiles
+    // 0.36 -> 6.4 ms measured).  Scattered arrays: zero-copy kernel reads.
+    static const bool no_dma = std::getenv("SLSLAM_INGEST_ZERO_COPY") != nullptr;         // (measurement switch)
+    struct Rg { uintptr_t lo, hi; };
+    std::vector<Rg> rg;
+    rg.reserve((size_t)5 * B);
+    size_t payload = 0;
+    for (int i = 0; i < B && !no_dma; ++i) {
+      const slslam_lba_window& w = windows[i];
+      const size_t M = (size_t)w.num_observations, np = (size_t)6 * w.num_cameras + (size_t)4 * w.num_lines;
+      if (M) { rg.push_back({ (uintptr_t)w.camera_index, (uintptr_t)w.camera_index + 4 * M }); rg.push_back({ (uintptr_t)w.line_index, (uintptr_t)w.line_index + 4 * M });
+               rg.push_back({ (uintptr_t)w.fixed_index, (uintptr_t)w.fixed_index + 8 * M }); rg.push_back({ (uintptr_t)w.observations, (uintptr_t)w.observations + 64 * M }); }
+      if (np) rg.push_back({ (uintptr_t)w.parameters, (uintptr_t)w.parameters + 8 * np });
+      payload += 80 * M + 8 * np;
+    }
+    std::sort(rg.begin(), rg.end(), [](const Rg& x, const Rg& y) { return x.lo < y.lo; });
+    for (const Rg& g : rg) {
+      if (!runs.empty() && g.lo <= runs.back().hi + 4096) runs.back().hi = std::max(runs.back().hi, g.hi);
+      else runs.push_back(Run{ g.lo, g.hi, 0 });
+    }
+    for (Run& r : runs) { r.dev_off = dev_need; dev_need += ((r.hi - r.lo) + 255) & ~(size_t)255; }
+    if (runs.size() > (size_t)std::max(8, B / 16) || dev_need > payload + payload / 8 + (1u << 20)) { runs.clear(); dev_need = 0; }     // scattered: zero copy
   } else {
     // staging: per window [observations 64 M | narrowed indices 4 M | parameters], 64-byte aligned pieces
     std::vector<size_t> st_off((size_t)B + 1, 0);
@@ -1640,16 +1683,45 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
         ix[q] = ((uint32_t)l & 0xffffu) | ((uint32_t)c & 0xffu) << 16 | (w.fixed_index[2 * q] ? 1u << 24 : 0u) | (w.fixed_index[2 * q + 1] ? 1u << 25 : 0u);
       }
       if (bad || oob) st[(size_t)i] = SLSLAM_ERR_INVALID_ARGUMENT;           // reported now, as the host packer does
-      RawWin& r = rw[i];
-      r.cam = nullptr; r.line = nullptr; r.fixed = nullptr; r.packed = ix; r.obs = ob; r.params = pr;
+      RawWin& r = b->host_src[(size_t)i];
+      r.cam = nullptr; r.line = nullptr; r.fixed = nullptr; r.packed = ix; r.obs = ob; r.params_in = pr;
+      r.params = params_pinned ? w.parameters : nullptr;                     // (written in place only where the GPU can reach the caller's array)
+      rw[i] = r;
     };
     if (!run_all(pool, B, stage_one)) return SLSLAM_ERR_NO_MEMORY;
     for (int v : st) if (v != SLSLAM_OK) return v;
+    // the whole staging copy goes up in ONE copy of the copy engine
+    if (st_off[(size_t)B] > 0) { runs.push_back(Run{ (uintptr_t)b->h_raw_stage, (uintptr_t)b->h_raw_stage + st_off[(size_t)B], 0 }); dev_need = (st_off[(size_t)B] + 255) & ~(size_t)255; }
   }
+  if (!runs.empty()) {
+    if (dev_need > b->d_stage_bytes) {
+      // (the previous refill's ingest has read the old block: ev_stage_free was waited for above)
+      if (b->d_stage_in) { (void)hipFree(b->d_stage_in); b->d_stage_in = nullptr; b->d_stage_bytes = 0; }
+      const size_t want = dev_need + dev_need / 8 + 4096;
+      HIP_TRY(hipMalloc((void**)&b->d_stage_in, want));
+      b->d_stage_bytes = want;
+    }
+    // the device reads every array at its place in the block
+    auto to_dev = [&](const void* p) -> const void* {
+      if (!p) return nullptr;
+      const uintptr_t a = (uintptr_t)p;
+      auto it = std::upper_bound(runs.begin(), runs.end(), a, [](uintptr_t v, const Run& r) { return v < r.lo; });
+      --it;
+      return b->d_stage_in + it->dev_off + (a - it->lo);
+    };
+    for (int i = 0; i < B; ++i) {
+      RawWin& r = rw[i];
+      r.cam = (const int*)to_dev(r.cam); r.line = (const int*)to_dev(r.line); r.fixed = (const int*)to_dev(r.fixed); r.packed = (const uint32_t*)to_dev(r.packed);
+      r.obs = (const double*)to_dev(r.obs); r.params_in = (const double*)to_dev(r.params_in);
+    }
+  }
+  b->ingest_mode = runs.empty() ? 0 : 1;
   for (int i = 0; i < B; ++i) {
     RawWin& r = rw[i];
     r.param_off = par_off[(size_t)i]; r.C = windows[i].num_cameras; r.L = windows[i].num_lines; r.M = windows[i].num_observations;
     r.cam_off = cam_off[(size_t)i]; r.line_off = line_off[(size_t)i]; r.obs_off = (int)obs_off[(size_t)i]; r.pad = 0;
+    RawWin& h = b->host_src[(size_t)i];
+    h.param_off = r.param_off; h.C = r.C; h.L = r.L; h.M = r.M; h.cam_off = r.cam_off; h.line_off = r.line_off; h.obs_off = r.obs_off; h.pad = 0;
   }
   const auto tt2 = std::chrono::steady_clock::now();
   // ---- commit: the batch now IS the new windows (what the device makes of them comes back with the results: slslam_lba_batch_wait)
@@ -1673,7 +1745,7 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
   b->h_win_graded.assign((size_t)std::max(1, B), 0);
   b->total_params = nparams; b->nobs = nobs;
   b->used_ncam = ncam; b->used_nline = nline; b->used_nobs = nobs; b->used_tiles = (long long)b->d_tiles.n; b->used_items = (long long)(b->d_items.n / 2);
-  b->device_built = true; b->inplace_export = all_pinned || params_pinned; b->results_inplace = false;
+  b->device_built = true; b->inplace_export = params_pinned; b->results_inplace = false;
   b->src_windows.assign(windows, windows + B);
   b->build_status.assign((size_t)B, SLSLAM_OK);
   b->downloaded = false;
@@ -1682,7 +1754,8 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
   BuildPtrs P;
   std::memset(&P, 0, sizeof(P));
   P.raw = b->d_rawwin.p; P.bw = b->d_buildwin.p; P.nwin = B; P.grouping = b->elim_grouped ? 1 : 0;
-  P.ob_raw = b->d_ob_raw.p; P.raw_idx = b->d_raw_idx.p; P.line_raw = b->d_line_raw.p; P.lflags = b->d_lflags.p; P.fmask = b->d_fmask.p;
+  P.ob_raw = b->d_ob_raw.p; P.raw_idx = b->d_raw_idx.p; P.line_raw = b->d_line_raw.p; P.lflags = b->d_lflags.p; P.fmask = b->d_fmask.p; P.line_pos = b->d_line_pos.p;
+  P.mid_keys = b->d_mid_keys.p; P.mid_li = b->d_mid_li.p; P.mid_rows = b->d_mid_rows.p; P.mid_next = b->d_mid_next.p; P.mid_trows = b->d_mid_trows.p; P.mid_tptr = b->d_mid_tptr.p; P.mid = b->d_mid.p;
   P.wins = b->d_wins.p; P.tiles = b->d_tiles.p; P.chunks = b->d_chunks.p; P.items = b->d_items.p; P.lane_map = b->d_lane_map.p; P.line_desc = b->d_line_desc.p;
   P.cam_x0 = b->d_cam_x0.p; P.cam_cf = b->d_cam_cf.p; P.cam_win = b->d_cam_win.p;
   P.line_x0 = b->d_line_x0.p; P.line_ptr = b->d_line_ptr.p; P.line_flags = b->d_line_flags.p; P.line_win = b->d_line_win.p; P.line_orig = b->d_line_orig.p;
@@ -1699,25 +1772,34 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
   {
     static bool attr_set = false;
     if (!attr_set) {
-      HIP_TRY(hipFuncSetAttribute((const void*)k_build_window, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_build_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_build_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_build_order, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_build_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
       attr_set = true;
     }
   }
-  HIP_TRY(hipMemcpyAsync(b->d_rawwin.p, rw, sizeof(RawWin) * (size_t)B, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(b->d_buildwin.p, 0, sizeof(BuildWin) * (size_t)B, s));
+  HIP_TRY(hipMemcpyAsync(b->d_rawwin.p, rw, sizeof(RawWin) * (size_t)B, hipMemcpyHostToDevice, s_in));
+  HIP_TRY(hipMemsetAsync(b->d_buildwin.p, 0, sizeof(BuildWin) * (size_t)B, s_in));
+  static const int ingest_wgs = std::getenv("SLSLAM_INGEST_WORKGROUPS") ? std::max(1, std::atoi(std::getenv("SLSLAM_INGEST_WORKGROUPS"))) : 32;
+  for (const Run& r : runs) HIP_TRY(hipMemcpyAsync(b->d_stage_in + r.dev_off, (const void*)r.lo, r.hi - r.lo, hipMemcpyHostToDevice, s_in));
+  // zero copy: the ingest kernel IS the transfer (32 workgroups keep the link full: tools/micro/zero_copy_bench.hip; more only queue in the L2)
+  if (B > 0 && runs.empty()) hipLaunchKernelGGL(k_ingest, dim3((unsigned)std::min(B, ingest_wgs)), dim3(256), 0, s_in, P);
+  if (!b->ev_stage_free) HIP_TRY(hipEventCreateWithFlags(&b->ev_stage_free, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(b->ev_stage_free, s_in));
+  if (s_in != s) HIP_TRY(hipStreamWaitEvent(s, b->ev_stage_free, 0));
+  // copy engine: the ingest reads the block in HBM (a fraction of a millisecond), on the solve stream
+  if (B > 0 && !runs.empty()) hipLaunchKernelGGL(k_ingest, dim3((unsigned)std::min(B, 1024)), dim3(256), 0, s, P);
   // the records beyond the refill's lines / cameras belong to no window
   if ((size_t)nline < b->d_line_win.n) HIP_TRY(hipMemsetAsync(b->d_line_win.p + nline, 0xFF, (b->d_line_win.n - (size_t)nline) * sizeof(int), s));
   if ((size_t)ncam < b->d_cam_win.n) {
     HIP_TRY(hipMemsetAsync(b->d_cam_win.p + ncam, 0xFF, (b->d_cam_win.n - (size_t)ncam) * sizeof(int), s));
     HIP_TRY(hipMemsetAsync(b->d_cam_cf.p + ncam, 0xFF, (b->d_cam_cf.n - (size_t)ncam) * sizeof(int), s));
   }
-  static const int ingest_wgs = std::getenv("SLSLAM_INGEST_WORKGROUPS") ? std::max(1, std::atoi(std::getenv("SLSLAM_INGEST_WORKGROUPS"))) : 64;
   if (B > 0) {
-    hipLaunchKernelGGL(k_ingest, dim3((unsigned)std::min(B, ingest_wgs)), dim3(256), 0, s, P);
-    if (!b->ev_stage_free) HIP_TRY(hipEventCreateWithFlags(&b->ev_stage_free, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(b->ev_stage_free, s));
-    hipLaunchKernelGGL(k_build_window, dim3((unsigned)B), dim3(256), lds_build, s, P);
+    hipLaunchKernelGGL(k_build_lines, dim3((unsigned)B), dim3(256), build_lines_lds_bytes(maxL), s, P);
+    hipLaunchKernelGGL(k_build_rows, dim3((unsigned)B), dim3(64), build_rows_lds_bytes(maxL), s, P);
+    hipLaunchKernelGGL(k_build_order, dim3((unsigned)B), dim3(256), lds_build, s, P);
     hipLaunchKernelGGL(k_build_layout, dim3(1), dim3(256), 0, s, P, a);
     hipLaunchKernelGGL(k_build_tiles, dim3((unsigned)B), dim3(256), lds_tiles, s, P, (const int*)b->d_cam_cf.p);
   }
@@ -1735,7 +1817,7 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
     const auto tt3 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
     std::fprintf(stderr, "slslam refill (device build, %s): sizes + wait %.2f  stage %.2f  commit + enqueue %.2f ms  (%d windows)\n",
-                 all_pinned ? "zero copy" : "staged", ms(tt0, tt1), ms(tt1, tt2), ms(tt2, tt3), B);
+                 all_pinned ? (runs.empty() ? "zero copy" : "pinned arrays, copy engine") : "staged", ms(tt0, tt1), ms(tt1, tt2), ms(tt2, tt3), B);
   }
   return rc;
 }
@@ -1754,7 +1836,7 @@ extern "C" int slslam_lba_batch_refill(slslam_lba_batch* b, const slslam_lba_win
   hipStream_t s = (hipStream_t)stream;
   {
     // the build stage on the device when the windows allow it (lba_device_build.h); UNSUPPORTED: not that path's business, nothing touched
-    const int drc = refill_device(b, windows, n, s);
+    const int drc = refill_device(b, windows, n, s, s);
     if (drc != SLSLAM_ERR_UNSUPPORTED) return drc;
   }
   static const bool timing = std::getenv("SLSLAM_REFILL_TIMING") != nullptr;      // host-side split of a refill on stderr
@@ -2095,13 +2177,18 @@ extern "C" int slslam_pack_indices(int n, const int* camera_index, const int* li
   return SLSLAM_OK;
 }
 
-// Test hook (tests/test_gpu_device_build.py): ONE window through the device build alone - k_ingest, k_build_window, k_build_layout,
+// Test hook (tests/test_gpu_device_build.py): ONE window through the device build alone - k_ingest, k_build_lines / _rows / _order, k_build_layout,
 // k_build_tiles on temporary device arrays - everything pack_window emits comes back in the form tests/host_math::hm_pack_g returns the
 // host packer's output in, so that the two are compared byte for byte.  status_out: the BuildWin.status bits (0: built).
 extern "C" int slslam_debug_device_pack(const slslam_lba_window* w, int grouping, int* out_counts /*Cf, ntiles, nitems, nfree_params, nkept*/,
                                         int* line_order, int* line_ptr, int* ob_orig, int* ob_cam, int* tiles /*4 per tile: line_begin, nlines, flags, nitems*/,
                                         unsigned char* items, int* cam_cf, int max_tiles, int max_items, unsigned short* lane_map, unsigned* line_desc,
                                         int* status_out) {
+  return slslam_debug_device_pack_timed(w, grouping, out_counts, line_order, line_ptr, ob_orig, ob_cam, tiles, items, cam_cf, max_tiles, max_items, lane_map, line_desc, status_out, nullptr);
+}
+extern "C" int slslam_debug_device_pack_timed(const slslam_lba_window* w, int grouping, int* out_counts, int* line_order, int* line_ptr, int* ob_orig, int* ob_cam, int* tiles,
+                                              unsigned char* items, int* cam_cf, int max_tiles, int max_items, unsigned short* lane_map, unsigned* line_desc,
+                                              int* status_out, unsigned long long* phase_clocks /*[16] or NULL*/) {
   if (!w || !out_counts || !status_out) return SLSLAM_ERR_INVALID_ARGUMENT;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SLSLAM_ERR_NO_DEVICE;
@@ -2116,6 +2203,8 @@ extern "C" int slslam_debug_device_pack(const slslam_lba_window* w, int grouping
   DevBuf<double> d_obs, d_params, d_ob_raw, d_line_raw, d_cam_x0, d_line_x0;
   DevBuf<uint32_t> d_raw_idx, d_fmask, d_line_desc; DevBuf<uint8_t> d_lflags, d_items; DevBuf<uint16_t> d_lane_map;
   DevBuf<RawWin> d_raw; DevBuf<BuildWin> d_bw; DevBuf<WinDesc> d_wins; DevBuf<Tile> d_tiles; DevBuf<Chunk> d_chunks; DevBuf<long long> d_param_off;
+  DevBuf<unsigned long long> d_dbg;
+  DevBuf<uint32_t> d_mid_keys; DevBuf<BuildLine> d_mid_li; DevBuf<uint4> d_mid_rows; DevBuf<uint16_t> d_mid_next, d_mid_trows, d_mid_tptr; DevBuf<BuildMid> d_mid;
   ar.add(d_cam, Mq, w->camera_index, (size_t)M, 0); ar.add(d_line, Mq, w->line_index, (size_t)M, 0); ar.add(d_fixed, 2 * Mq, w->fixed_index, 2 * (size_t)M, 0);
   ar.add(d_obs, 8 * Mq, w->observations, 8 * (size_t)M, 0); ar.add(d_params, std::max<size_t>(1, np), (const double*)w->parameters, np, 0);
   ar.scratch(d_ob_raw, 8 * Mq); ar.scratch(d_raw_idx, Mq); ar.scratch(d_line_raw, 4 * Lq); ar.scratch(d_lflags, Lq); ar.scratch(d_fmask, Lq);
@@ -2123,12 +2212,13 @@ extern "C" int slslam_debug_device_pack(const slslam_lba_window* w, int grouping
   ar.scratch(d_line_desc, Lq); ar.scratch(d_cam_x0, 6 * Cq); ar.scratch(d_cam_cf, Cq); ar.scratch(d_cam_win, Cq);
   ar.scratch(d_line_x0, 4 * Lq); ar.scratch(d_line_ptr, Lq + 1); ar.scratch(d_line_flags, Lq); ar.scratch(d_line_win, Lq); ar.scratch(d_line_orig, Lq);
   ar.scratch(d_ob_cam, Mq); ar.scratch(d_ob_orig, Mq); ar.scratch(d_param_off, 1); ar.scratch(d_item_base, 1); ar.zeroed(d_totals, 8);
-  ar.scratch(d_raw, 1); ar.zeroed(d_bw, 1);
+  ar.scratch(d_raw, 1); ar.zeroed(d_bw, 1); ar.zeroed(d_dbg, 16);
+  ar.scratch(d_mid_keys, Lq); ar.scratch(d_mid_li, Lq); ar.scratch(d_mid_rows, Lq); ar.scratch(d_mid_next, Lq); ar.scratch(d_mid_trows, Lq + 8); ar.scratch(d_mid_tptr, Lq + 8); ar.scratch(d_mid, 1);
   int rc = ar.commit();
   if (rc != SLSLAM_OK) { ar.release(); return rc; }
   RawWin r;
   std::memset(&r, 0, sizeof(r));
-  r.cam = d_cam.p; r.line = d_line.p; r.fixed = d_fixed.p; r.packed = nullptr; r.obs = d_obs.p; r.params = d_params.p;
+  r.cam = d_cam.p; r.line = d_line.p; r.fixed = d_fixed.p; r.packed = nullptr; r.obs = d_obs.p; r.params_in = d_params.p; r.params = d_params.p;
   r.C = C; r.L = L; r.M = M;
   hipError_t e = hipMemcpy(d_raw.p, &r, sizeof(r), hipMemcpyHostToDevice);
   BuildPtrs P;
@@ -2139,15 +2229,21 @@ extern "C" int slslam_debug_device_pack(const slslam_lba_window* w, int grouping
   P.cam_x0 = d_cam_x0.p; P.cam_cf = d_cam_cf.p; P.cam_win = d_cam_win.p;
   P.line_x0 = d_line_x0.p; P.line_ptr = d_line_ptr.p; P.line_flags = d_line_flags.p; P.line_win = d_line_win.p; P.line_orig = d_line_orig.p;
   P.ob_cam = d_ob_cam.p; P.ob_orig = d_ob_orig.p; P.param_off = d_param_off.p; P.item_base = d_item_base.p; P.totals = d_totals.p;
+  P.dbg = phase_clocks ? d_dbg.p : nullptr;
+  P.mid_keys = d_mid_keys.p; P.mid_li = d_mid_li.p; P.mid_rows = d_mid_rows.p; P.mid_next = d_mid_next.p; P.mid_trows = d_mid_trows.p; P.mid_tptr = d_mid_tptr.p; P.mid = d_mid.p;
   LayoutArgs a;
   std::memset(&a, 0, sizeof(a));
   a.chunks_per_window = 1; a.elim_waves = 1; a.cap_tiles = (int)cap_tiles; a.cap_items = (int)cap_items; a.cap_chunks = 16; a.cap_maxn = 6 * kMaxFreeCams;
   a.slab_sum = 0; a.cap_slab = 1LL << 40; a.cap_sys = 1LL << 40; a.nline = L; a.nobs = M; a.max_free = kMaxFreeCams;
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_build_window, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_build_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_build_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_build_order, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_build_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_ingest, dim3(1), dim3(256), 0, 0, P);
-    hipLaunchKernelGGL(k_build_window, dim3(1), dim3(256), lds_build, 0, P);
+    hipLaunchKernelGGL(k_build_lines, dim3(1), dim3(256), build_lines_lds_bytes(L), 0, P);
+    hipLaunchKernelGGL(k_build_rows, dim3(1), dim3(64), build_rows_lds_bytes(L), 0, P);
+    hipLaunchKernelGGL(k_build_order, dim3(1), dim3(256), lds_build, 0, P);
     hipLaunchKernelGGL(k_build_layout, dim3(1), dim3(256), 0, 0, P, a);
     hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), lds_tiles, 0, P, (const int*)d_cam_cf.p);
     e = hipDeviceSynchronize();
@@ -2158,6 +2254,7 @@ extern "C" int slslam_debug_device_pack(const slslam_lba_window* w, int grouping
   if (e == hipSuccess) e = hipMemcpy(&bw, d_bw.p, sizeof(bw), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(&wd, d_wins.p, sizeof(wd), hipMemcpyDeviceToHost);
   *status_out = bw.status;
+  if (e == hipSuccess && phase_clocks) e = hipMemcpy(phase_clocks, d_dbg.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   if (e == hipSuccess && bw.status == 0) {
     out_counts[0] = bw.Cf; out_counts[1] = bw.ntiles; out_counts[2] = bw.nitems; out_counts[3] = bw.nfree_params; out_counts[4] = bw.nkept;
     if (bw.ntiles > max_tiles || bw.nitems > max_items) { ar.release(); return SLSLAM_ERR_UNSUPPORTED; }
@@ -2192,6 +2289,9 @@ struct slslam_lba_stream {
     std::vector<double*> out_params;            // the callers' parameter arrays (solved in place, written by collect)
   };
   std::vector<Slot> slots;
+  hipStream_t ingest_stream = nullptr, solve_stream = nullptr;      // shared by the slots whose refills are built on the device (see refill_device)
+  hipStream_t result_stream = nullptr;       // ... and where their results leave: the export over the link and the state / trace copies of batch k run beside the build of batch k + 1
+  hipEvent_t ev_solved = nullptr;
   long long next_ticket = 0;
   // host-side accounting (ms, wall clock of the calling thread)
   double ms_submit = 0, ms_collect_wait = 0, ms_collect_copy = 0;
@@ -2218,12 +2318,20 @@ extern "C" int slslam_lba_stream_create(int device, const slslam_solver_options*
   st->pool.reset(new HostPool(threads));
   st->slots.resize((size_t)depth);
   if (hipSetDevice(device) != hipSuccess) { delete st; return SLSLAM_ERR_NO_DEVICE; }
-  for (auto& sl : st->slots)
-    if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) {
-      for (auto& x : st->slots) if (x.stream) (void)hipStreamDestroy(x.stream);
-      delete st;
-      return SLSLAM_ERR_HIP;
-    }
+  // TWO streams serve every slot whose batches are built on the device: ingest (the host link) and build + solve + results.  A process has
+  // few hardware queues (4 unless GPU_MAX_HW_QUEUES says otherwise) and streams that share one run one behind the other: the slots' own
+  // streams - what the host-packer path overlaps its uploads with - are made when that path is first taken, not before.
+  // The ingest stream gets the highest priority: its few workgroups must find wave slots while a solve's thousands are queued.
+  int pr_lo = 0, pr_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+  if (hipStreamCreateWithPriority(&st->ingest_stream, hipStreamNonBlocking, pr_hi) != hipSuccess || hipStreamCreateWithFlags(&st->solve_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&st->result_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&st->ev_solved, hipEventDisableTiming) != hipSuccess) {
+    if (st->ingest_stream) (void)hipStreamDestroy(st->ingest_stream);
+    if (st->solve_stream) (void)hipStreamDestroy(st->solve_stream);
+    if (st->result_stream) (void)hipStreamDestroy(st->result_stream);
+    delete st;
+    return SLSLAM_ERR_HIP;
+  }
   *out = st;
   return SLSLAM_OK;
 }
@@ -2231,11 +2339,18 @@ extern "C" int slslam_lba_stream_create(int device, const slslam_solver_options*
 extern "C" void slslam_lba_stream_destroy(slslam_lba_stream* st) {
   if (!st) return;
   (void)hipSetDevice(st->device);
+  if (st->ingest_stream) (void)hipStreamSynchronize(st->ingest_stream);
+  if (st->solve_stream) (void)hipStreamSynchronize(st->solve_stream);
+  if (st->result_stream) (void)hipStreamSynchronize(st->result_stream);
   for (auto& sl : st->slots) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     if (sl.batch) { sl.batch->ext_pool = nullptr; slslam_lba_batch_destroy(sl.batch); }
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
+  if (st->ingest_stream) (void)hipStreamDestroy(st->ingest_stream);
+  if (st->solve_stream) (void)hipStreamDestroy(st->solve_stream);
+  if (st->result_stream) (void)hipStreamDestroy(st->result_stream);
+  if (st->ev_solved) (void)hipEventDestroy(st->ev_solved);
   delete st;
 }
 
@@ -2246,11 +2361,25 @@ extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_
   if (sl.in_flight) return SLSLAM_ERR_STATE;             // its results have not been collected
   HIP_TRY(hipSetDevice(st->device));
   int rc = SLSLAM_ERR_UNSUPPORTED;
-  if (sl.batch && sl.n == n) rc = slslam_lba_batch_refill(sl.batch, windows, n, (void*)sl.stream);
-  if (rc == SLSLAM_OK) { ++st->n_refills; if (sl.batch->device_built) { ++st->n_device_builds; if (sl.batch->inplace_export && sl.batch->h_rawwin && !sl.batch->h_rawwin[0].packed) ++st->n_zero_copy; } }
+  hipStream_t run = st->solve_stream;                     // where this ticket's solve and download go
+  if (sl.batch && sl.n == n) {
+    slslam_lba_batch* b = sl.batch;
+    // the build stage on the device: ingest on the stream's ONE ingest stream, build + solve + results on its ONE solve stream
+    if (b->finalized && b->refillable && !b->part[0] && !b->big_mode && !b->fused_motion_only && !b->opt.reuse_elimination && (int)b->wins.size() == n) {
+      rc = refill_device(b, windows, n, st->solve_stream, st->ingest_stream);
+      if (rc == SLSLAM_OK) run = st->solve_stream;
+    }
+    if (rc == SLSLAM_ERR_UNSUPPORTED) {
+      // the host packer (or refused: a new batch below): its uploads overlap the other slots' solves on a stream of the slot's own
+      if (!sl.stream) HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+      rc = slslam_lba_batch_refill(b, windows, n, (void*)sl.stream);
+      if (rc == SLSLAM_OK) run = sl.stream;
+    }
+  }
+  if (rc == SLSLAM_OK) { ++st->n_refills; if (sl.batch->device_built) { ++st->n_device_builds; if (!sl.batch->host_src.empty() && !sl.batch->host_src[0].packed) ++st->n_zero_copy; } }
   else if (rc == SLSLAM_ERR_UNSUPPORTED) {
     // the first batch of the slot, another number of windows, or windows that do not fit the room the slot's arrays have: a new batch
-    if (sl.batch) { HIP_TRY(hipStreamSynchronize(sl.stream)); sl.batch->ext_pool = nullptr; slslam_lba_batch_destroy(sl.batch); sl.batch = nullptr; }
+    if (sl.batch) { if (sl.stream) HIP_TRY(hipStreamSynchronize(sl.stream)); HIP_TRY(hipStreamSynchronize(st->solve_stream)); HIP_TRY(hipStreamSynchronize(st->result_stream)); sl.batch->ext_pool = nullptr; slslam_lba_batch_destroy(sl.batch); sl.batch = nullptr; }
     slslam_lba_batch* b = nullptr;
     if ((rc = slslam_lba_batch_create(st->device, &b)) != SLSLAM_OK) return rc;
     b->ext_pool = st->pool.get();
@@ -2263,8 +2392,14 @@ extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_
     sl.batch = b; sl.n = n;
     ++st->n_builds;
   } else return rc;
-  if ((rc = slslam_lba_batch_solve(sl.batch, (void*)sl.stream)) != SLSLAM_OK) return rc;
-  if ((rc = download_async_impl(sl.batch, (void*)sl.stream, /*allow_inplace=*/true)) != SLSLAM_OK) return rc;
+  if ((rc = slslam_lba_batch_solve(sl.batch, (void*)run)) != SLSLAM_OK) return rc;
+  if (run == st->solve_stream) {
+    // the results leave on a stream of their own, behind the solve: the next batch's build does not wait for this batch's export
+    HIP_TRY(hipEventRecord(st->ev_solved, run));
+    HIP_TRY(hipStreamWaitEvent(st->result_stream, st->ev_solved, 0));
+    run = st->result_stream;
+  }
+  if ((rc = download_async_impl(sl.batch, (void*)run, /*allow_inplace=*/true)) != SLSLAM_OK) return rc;
   sl.out_params.resize((size_t)n);
   for (int i = 0; i < n; ++i) sl.out_params[(size_t)i] = windows[i].parameters;
   sl.ticket = st->next_ticket; sl.in_flight = true;
@@ -2306,7 +2441,7 @@ extern "C" int slslam_lba_stream_collect(slslam_lba_stream* st, int ticket, slsl
   // no room in the slot's arrays, bad input): solved here through the host path, one by one, from what the device read (the caller's
   // page-locked arrays, or the staging copy) - their status is whatever that path says
   for (int i : flagged) {
-    const RawWin& r = bt->h_rawwin[i];
+    const RawWin& r = bt->host_src[(size_t)i];
     std::vector<int> cam, line, fixed;
     slslam_lba_window w;
     w.num_cameras = r.C; w.num_lines = r.L; w.num_observations = r.M; w.observations = r.obs; w.parameters = sl.out_params[(size_t)i];

@@ -9,10 +9,12 @@
 //   k_ingest        few workgroups read the callers' arrays straight from PINNED host memory (zero copy, 57 GB/s with 32 workgroups:
 //                   tools/micro/zero_copy_bench.hip) - observations with the NaN / Inf test, the three index arrays narrowed to one
 //                   32-bit word per observation with the range test, cameras and lines
-//   k_build_window  one workgroup per window: counting, constness, free-camera masks, the counting sort as a bitonic sort of
-//                   (cell | line) keys, the best-fit packing of lines into rows - inherently sequential: ONE wave walks the lines, the
-//                   17 open-row lists live one per lane (ballots pick the list, the rows of a list are chained through LDS) - row order,
-//                   line order, line pointers, the stable sort of every line's observations by camera
+//   k_build_lines   one workgroup per window: counting, constness, free-camera masks, the counting sort as a bitonic sort of
+//                   (cell | line) keys
+//   k_build_rows    ONE WAVE per window (four windows to a CU): the best-fit packing of lines into rows - inherently sequential: the wave
+//                   walks the lines, the 17 open-row lists live one per lane (ballots pick the list, the rows of a list are chained
+//                   through LDS)
+//   k_build_order   one workgroup per window: row order, line order, line pointers, the stable sort of every line's observations by camera
 //   k_build_layout  one workgroup: prefix sums over the windows, the (graded) chunk cuts and the dispatch order of plan_layout, the
 //                   fit test against the room the batch's arrays have
 //   k_build_tiles   thread <-> tile: lane map, skew flags, line descriptors (sorted per tile for the grouped sweep), pair items
@@ -41,7 +43,8 @@ struct RawWin {
   const int* fixed;           // [2M] fixed_index
   const uint32_t* packed;     // [M] line | camera << 16 | camera constant << 24 | line constant << 25 (the narrowed form), or nullptr
   const double* obs;          // [8M]
-  double* params;             // [6C + 4L] in / out
+  const double* params_in;    // [6C + 4L] the initial parameters (where the ingest reads them)
+  double* params;             // [6C + 4L] where the solved parameters go when they are written in place (the caller's array), or null
   long long param_off;        // offset of the window in the batch's exported parameter vector
   int C, L, M;
   int cam_off, line_off, obs_off;     // the window's place in the batch arrays
@@ -53,6 +56,16 @@ struct BuildWin {
   int status;                 // 0, or why the window was not built (emitted empty)
   int Cf, ntiles, nitems, nfree_params, nkept;
   int nchunks, graded;        // (k_build_layout) the cut: chunk count and, for graded sizes, the number of slot rounds
+};
+
+struct BuildLine;
+// What the stages of a window's build hand to each other (device only).
+struct BuildMid {
+  unsigned long long freeset, constset;   // cameras: free (used and not constant) | constant
+  int ok;                     // 0: the window was flagged, the later stages skip it
+  int Cf, free_lines, nitems;
+  int nrows, ntr, ntp, cls_row[4];        // (k_build_rows) rows made | row entries and tile ranges of the long lines | row range of each length class
+  int pad;
 };
 
 // Everything the build kernels touch, by value.
@@ -68,6 +81,15 @@ struct BuildPtrs {
   // per-line scratch (sorted order)
   uint8_t* lflags;            // bit 0: first line of a row entry, bit 1: first line of a tile
   uint32_t* fmask;            // free cameras that see the line
+  int* line_pos;              // [nline] caller's line -> sorted position in its window (the export in the caller's order), may be null
+  // between the stages of a window's build (k_build_lines -> k_build_rows -> k_build_order), at the window's line offset
+  uint32_t* mid_keys;         // [nline] the lines in packing order: sort key << 16 | line
+  BuildLine* mid_li;          // [nline] per line: free-camera mask | flags, lanes, pair items
+  uint4* mid_rows;            // [nline] the rows
+  uint16_t* mid_next;         // [nline] next line of a line's row
+  uint16_t* mid_trows;        // [nline + 8 nwin] row entries in tile order (the long lines')
+  uint16_t* mid_tptr;         // [nline + 8 nwin] row range of each tile (the long lines')
+  BuildMid* mid;              // [nwin]
   // batch arrays (as BatchPtrs / slslam_lba_batch)
   WinDesc* wins; Tile* tiles; Chunk* chunks; uint8_t* items; uint16_t* lane_map; uint32_t* line_desc;
   double* cam_x0; int* cam_cf; int* cam_win;
@@ -76,6 +98,7 @@ struct BuildPtrs {
   long long* param_off;
   int* item_base;             // [nwin] first pair item of each window (k_build_layout -> k_build_tiles)
   int* totals;                // [8]: tiles | items | chunks | fit (1 ok) | lines | observations
+  unsigned long long* dbg;    // timing experiments (tools/build_phases.py): constant-clock (100 MHz) stamps of window 0's build, or null
 };
 
 // How k_build_layout cuts (the batch-wide numbers slslam_lba_batch_finalize resolved: plan_layout with frozen = true) and what has to fit.
@@ -140,16 +163,16 @@ __global__ __launch_bounds__(256) void k_ingest(BuildPtrs P) {
         }
       }
     }
-    // parameters: cameras to their place, lines in the caller's order (k_build_window sorts them)
-    for (int i = tid; i < 6 * r.C; i += 256) { const double v = r.params[i]; P.cam_x0[6LL * r.cam_off + i] = v; bad |= bad_exponent(v); }
-    for (int i = tid; i < 4 * r.L; i += 256) { const double v = r.params[6 * r.C + i]; P.line_raw[4LL * r.line_off + i] = v; bad |= bad_exponent(v); }
+    // parameters: cameras to their place, lines in the caller's order (k_build_order sorts them)
+    for (int i = tid; i < 6 * r.C; i += 256) { const double v = r.params_in[i]; P.cam_x0[6LL * r.cam_off + i] = v; bad |= bad_exponent(v); }
+    for (int i = tid; i < 4 * r.L; i += 256) { const double v = r.params_in[6 * r.C + i]; P.line_raw[4LL * r.line_off + i] = v; bad |= bad_exponent(v); }
     if (bad) atomicOr(&P.bw[w].status, (int)kBuildInvalid);
   }
 }
 
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// LDS of k_build_window for a window of L lines (Lp = L rounded up to a power of two, at least 256), by phase:
+// LDS of k_build_lines / k_build_order for a window of L lines (Lp = L rounded up to a power of two, at least 256), by phase:
 //   A  [Lp]     u32   pass 1: observation count (bits 0-23) | constant (bit 31) per line; then the sort keys; row sort keys; first line of
 //                     every row entry; last: position of every line (u16)
 //   LI [L]      8 B   pass 1: camera mask (u64); then per line: free-camera mask | flags, lanes, pair items, next line of its row
@@ -158,7 +181,8 @@ __global__ __launch_bounds__(256) void k_ingest(BuildPtrs P) {
 //   T  [2L + 8] u16   tile_rows [L + 2] | tile_ptr [L + 6]
 //   part [257]  u32   scan partials
 __host__ __device__ inline int build_pow2(int L) { int p = 256; while (p < L) p <<= 1; return p; }
-__host__ __device__ inline size_t build_lds_bytes(int L) {
+__host__ __device__ inline size_t build_lines_lds_bytes(int L) { return 4 * (size_t)build_pow2(L) + 8 * (size_t)(L > 0 ? L : 1) + 64; }      // k_build_lines: A | CM
+__host__ __device__ inline size_t build_lds_bytes(int L) {                                                                                // k_build_order: everything
   const size_t Lq = (size_t)(L > 0 ? L : 1);
   return 4 * (size_t)build_pow2(L) + 8 * Lq + 16 * Lq + 2 * (2 * Lq + 8) + 4 * 260;
 }
@@ -212,7 +236,7 @@ __device__ __forceinline__ int build_group_key(uint32_t fm) {
   return 2 * a + ((hi - a + 1) > 8 ? 0 : 1);
 }
 
-__global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
+__global__ __launch_bounds__(256) void k_build_lines(BuildPtrs P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char build_smem[];
   const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const RawWin r = P.raw[w];
@@ -221,16 +245,13 @@ __global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
   unsigned* A = reinterpret_cast<unsigned*>(build_smem);
   unsigned long long* CM = reinterpret_cast<unsigned long long*>(A + Lp);
   BuildLine* LI = reinterpret_cast<BuildLine*>(CM);
-  BuildRow* R = reinterpret_cast<BuildRow*>(CM + Lq);
-  uint16_t* T = reinterpret_cast<uint16_t*>(R + Lq);
-  uint16_t* tile_rows = T;
-  uint16_t* tile_ptr = T + Lq + 2;
-  unsigned* part = reinterpret_cast<unsigned*>(T + 2 * Lq + 8);
   __shared__ unsigned long long s_cam_used, s_cam_const;
-  __shared__ int s_flags, s_ntr, s_ntiles, s_cls_row[4], s_free_lines, s_nkept, s_nitems;
+  __shared__ int s_flags, s_free_lines, s_nitems;
   __shared__ signed char s_cam_cf[64];
+#define BUILD_STAMP(i) do { if (P.dbg && w == 0 && tid == 0) P.dbg[i] = (unsigned long long)wall_clock64(); } while (0)
+  BUILD_STAMP(0);
   BuildWin* bw = P.bw + w;
-  if (tid == 0) { s_cam_used = 0; s_cam_const = 0; s_flags = 0; s_free_lines = 0; s_nkept = 0; s_nitems = 0; }
+  if (tid == 0) { s_cam_used = 0; s_cam_const = 0; s_flags = 0; s_free_lines = 0; s_nitems = 0; }
   for (int l = tid; l < L; l += 256) { A[l] = 0; CM[l] = 0; }
   __syncthreads();
   const bool alive = bw->status == 0 && C <= kMaxCams;        // (else: the ingest flagged the window - a bad index, a non-finite value)
@@ -254,9 +275,11 @@ __global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
     if (cconst) atomicOr(&s_cam_const, cconst);
   }
   __syncthreads();
+  BUILD_STAMP(1);
   // free cameras: used and not constant, numbered in camera order
   const unsigned long long freeset = s_cam_used & ~s_cam_const;
   const unsigned long long constset = s_cam_const;
+  (void)lane;
   const int Cf = __popcll(freeset);
   if (tid < 64) s_cam_cf[tid] = (tid < C && ((freeset >> tid) & 1ull)) ? (signed char)__popcll(freeset & ((1ull << tid) - 1ull)) : (signed char)-1;
   if (alive) for (int l = tid; l < L; l += 256) if ((A[l] & 0xffffffu) > 64u) atomicOr(&s_flags, 2);     // a line with more than 64 observations
@@ -268,6 +291,7 @@ __global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
     for (int l = tid; l < L; l += 256) { P.line_win[r.line_off + l] = -1; P.line_ptr[r.line_off + l] = r.obs_off; }
     for (int c = tid; c < C; c += 256) { P.cam_win[r.cam_off + c] = -1; P.cam_cf[r.cam_off + c] = -1; }
     if (tid == 0) {
+      P.mid[w].ok = 0;
       if (bw->status == 0) bw->status = kBuildHostPath;
       bw->Cf = 0; bw->ntiles = 0; bw->nitems = 0; bw->nfree_params = 0; bw->nkept = 0;
     }
@@ -308,43 +332,58 @@ __global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
     A[l] = key;
   }
   __syncthreads();
+  BUILD_STAMP(2);
   block_bitonic_sort(A, Lp);
+  BUILD_STAMP(3);
+  // ---- to the next stage: the sorted keys, the line records, the window's scalars
+  unsigned* g_keys = P.mid_keys + r.line_off;
+  unsigned long long* g_li = reinterpret_cast<unsigned long long*>(P.mid_li + r.line_off);
+  for (int l = tid; l < L; l += 256) { g_keys[l] = A[l]; g_li[l] = CM[l]; }
+  if (tid == 0) {
+    BuildMid& m = P.mid[w];
+    m.freeset = freeset; m.constset = constset; m.Cf = Cf; m.free_lines = s_free_lines; m.nitems = s_nitems; m.ok = 1;
+  }
+#undef BUILD_STAMP
+}
 
-  // ---- rows: best fit over the sorted lines (lba_pack.cpp:153-172), ONE wave.  The 17 lists of open rows - by the lanes a row has left -
-  // live one per lane: head, tail, size and the and-mask of lane q are list q's; the rows of a list are chained through R[].lprev / lnext
-  // (a row sits in at most one list).  Everything read from LDS here is wave-uniform; LDS is written by lane 0 and read through volatile
-  // pointers (one wave, in-order LDS: a later read sees an earlier write).
-  if (tid < 64) {
-    volatile BuildRow* VR = R;
-    volatile BuildLine* VL = LI;
-    volatile uint16_t* v_tile_rows = tile_rows;
-    volatile uint16_t* v_tile_ptr = tile_ptr;
+// The rows: best fit over the sorted lines (lba_pack.cpp:153-172) - the one sequential stage of the build, ONE wave per window so that four
+// windows share a CU (36 KB of LDS each for 2000 lines: the whole batch of 1024 windows is resident at once).
+// LDS: R [L] 16 B row records | NX [L] u16 next line of a line's row.
+__host__ __device__ inline size_t build_rows_lds_bytes(int L) { const size_t Lq = (size_t)(L > 0 ? L : 1); return 16 * Lq + 2 * Lq + 64; }
+__global__ __launch_bounds__(64) void k_build_rows(BuildPtrs P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rows_smem[];
+  const int w = blockIdx.x, tid = threadIdx.x, lane = tid;
+  const RawWin r = P.raw[w];
+  const int L = r.L, grouping = P.grouping;
+  const int Lq = L > 0 ? L : 1;
+  if (!P.mid[w].ok) return;
+  BuildRow* R = reinterpret_cast<BuildRow*>(rows_smem);
+  uint16_t* NX = reinterpret_cast<uint16_t*>(R + Lq);
+  const unsigned* A = P.mid_keys + r.line_off;
+  const BuildLine* LI = P.mid_li + r.line_off;
+  uint16_t* tile_rows = P.mid_trows + r.line_off + 8 * w;
+  uint16_t* tile_ptr = P.mid_tptr + r.line_off + 8 * w;
+#define BUILD_STAMP(i) do { if (P.dbg && w == 0 && tid == 0) P.dbg[i] = (unsigned long long)wall_clock64(); } while (0)
+  BUILD_STAMP(3);
+  for (int l = lane; l < L; l += 64) NX[l] = (uint16_t)kNoRow;
+  __syncthreads();
+    // (plain LDS pointers + compiler barriers: `volatile` would turn every access into a FLAT instruction with a full wait behind it - measured
+    // 1300 cycles per line)
+    uint4* R4 = reinterpret_cast<uint4*>(R);
     int q_head = -1, q_tail = -1, q_size = 0;
     unsigned q_and = ~0u;
     int nrows = 0, ntr = 0, ntp = 1;
-    if (lane == 0) v_tile_ptr[0] = 0;
-    auto new_row = [&]() -> int {
-      const int rr = nrows++;
-      if (lane == 0) { VR[rr].used = 0; VR[rr].nl = 0; VR[rr].items = 0; VR[rr].head = kNoRow; VR[rr].tail = kNoRow; VR[rr].lprev = kNoRow; VR[rr].lnext = kNoRow; VR[rr].mask = 0; }
-      return rr;
-    };
-    auto append = [&](int rr, int l, int len, int itm, unsigned fm) {
-      const int tail = VR[rr].tail;
-      if (lane == 0) {
-        if (tail == kNoRow) VR[rr].head = (uint16_t)l; else VL[tail].next = (uint16_t)l;
-        VR[rr].tail = (uint16_t)l; VR[rr].used = (uint8_t)(VR[rr].used + len); VR[rr].nl = (uint8_t)(VR[rr].nl + 1);
-        VR[rr].items = (uint16_t)(VR[rr].items + itm); VR[rr].mask = VR[rr].mask | fm;
-      }
-    };
-    auto unlink = [&](int room, int rr) {
-      const int p = VR[rr].lprev, n = VR[rr].lnext;
-      if (lane == 0) { if (p != kNoRow) VR[p].lnext = (uint16_t)n; if (n != kNoRow) VR[n].lprev = (uint16_t)p; }
-      if (lane == room) { if (p == kNoRow) q_head = n == kNoRow ? -1 : n; if (n == kNoRow) q_tail = p == kNoRow ? -1 : p; --q_size; }
-    };
-    auto push = [&](int room, int rr, unsigned mask) {
-      const int t = __shfl(q_tail, room);
-      if (lane == 0) { VR[rr].lprev = (uint16_t)(t < 0 ? kNoRow : t); VR[rr].lnext = (uint16_t)kNoRow; if (t >= 0) VR[t].lnext = (uint16_t)rr; }
-      if (lane == room) { if (t < 0) q_head = rr; q_tail = rr; q_and = q_size == 0 ? mask : (q_and & mask); ++q_size; }
+    if (lane == 0) tile_ptr[0] = 0;
+#define RL(v, i) __builtin_amdgcn_readlane((int)(v), (i))
+#define WL(v, val, i) do { if (lane == (i)) (v) = (val); } while (0)      /* (no v_writelane builtin in this compiler: a compare + select) */
+#define LDS_FENCE() asm volatile("" ::: "memory")
+    // row record in registers: x = used | nl << 8 | items << 16, y = head | tail << 16, z = lprev | lnext << 16, w = mask
+    auto store_row = [&](int rr, unsigned x, unsigned y, unsigned z, unsigned wv) { if (lane == 0) { uint4 v; v.x = x; v.y = y; v.z = z; v.w = wv; R4[rr] = v; } };
+    auto unlink = [&](int room, int rr, int p, int n) {
+      if (lane == 0) { if (p != kNoRow) R[p].lnext = (uint16_t)n; if (n != kNoRow) R[n].lprev = (uint16_t)p; }
+      if (p == kNoRow) WL(q_head, n == kNoRow ? -1 : n, room);
+      if (n == kNoRow) WL(q_tail, p == kNoRow ? -1 : p, room);
+      WL(q_size, RL(q_size, room) - 1, room);
     };
     // long lines: a row entry of their own that spans (k + 15) / 16 rows of one tile
     int i = 0;
@@ -354,79 +393,188 @@ __global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
         const unsigned key = A[i];
         if ((key >> 16) >= 64u) break;
         const int l = (int)(key & 0xffffu);
-        const int len = VL[l].len, nr = (len + 15) / 16;
-        if (used_rows + nr > 4) { if (ntr > 0) { if (lane == 0) v_tile_ptr[ntp] = (uint16_t)ntr; ++ntp; } used_rows = 0; }
-        const int rr = new_row();
-        append(rr, l, len, VL[l].items, VL[l].fm & kLineMask);
-        if (lane == 0) v_tile_rows[ntr] = (uint16_t)rr;
+        const BuildLine li = LI[l];
+        const int len = li.len, nr = (len + 15) / 16;
+        if (used_rows + nr > 4) { if (ntr > 0) { if (lane == 0) tile_ptr[ntp] = (uint16_t)ntr; ++ntp; } used_rows = 0; }
+        const int rr = nrows++;
+        store_row(rr, (unsigned)len | 1u << 8 | (unsigned)li.items << 16, (unsigned)l | (unsigned)l << 16, (unsigned)kNoRow | (unsigned)kNoRow << 16, li.fm & kLineMask);
+        if (lane == 0) tile_rows[ntr] = (uint16_t)rr;
         ++ntr;
         used_rows += nr;
       }
-      if (ntr > 0) { if (lane == 0) v_tile_ptr[ntp] = (uint16_t)ntr; ++ntp; }
+      if (ntr > 0) { if (lane == 0) tile_ptr[ntp] = (uint16_t)ntr; ++ntp; }
     }
-    const int nb = grouping ? kBuildBuckets : 1;
+    i = __builtin_amdgcn_readfirstlane(i);
+    LDS_FENCE();
     int cur_cls = -1, cur_bucket = -1, prev_first = nrows;
     int row0[2] = { nrows, nrows }, row1[2] = { nrows, nrows };
-    for (; i < L; ++i) {
-      const unsigned key = A[i];
-      const int l = (int)(key & 0xffffu);
-      const int cell = (int)(key >> 16) - 64, bucket = cell >> 4, cls = bucket / nb;
-      if (cls != cur_cls) {
-        if (cur_cls == 0) row1[0] = nrows;
-        if (cls == 1 && cur_cls < 0) { row0[0] = nrows; row1[0] = nrows; }
-        row0[cls] = nrows;
-        q_head = -1; q_tail = -1; q_size = 0; q_and = ~0u;       // open.clear(): the lists live through a class
-        prev_first = nrows;
-        cur_cls = cls;
+    // lane j: the record of sorted line base + j - fetched from memory one block of 64 lines ahead of the walk
+    auto fetch = [&](int base, unsigned& k, unsigned& f, unsigned& q) {
+      k = 0xffffffffu; f = 0; q = 0;
+      if (base + lane < L) {
+        k = A[base + lane];
+        const BuildLine li = LI[k & 0xffffu];
+        f = li.fm; q = (unsigned)li.len | (unsigned)li.items << 8;
       }
-      if (bucket != cur_bucket) {
-        if (grouping) {
-          // only the rows the previous group left open stay in the lists (lba_pack.cpp:229-236)
-          for (int q = 0; q <= 16; ++q) {
-            int cur = __shfl(q_head, q);
-            while (cur >= 0) {
-              const int nx = VR[cur].lnext;
-              if (cur < prev_first) unlink(q, cur);
-              cur = nx == kNoRow ? -1 : nx;
-            }
-          }
+    };
+    unsigned nx_key, nx_fm, nx_li;
+    fetch(i, nx_key, nx_fm, nx_li);
+    for (int base = i; base < L; base += 64) {
+      const unsigned my_key = nx_key, my_fm = nx_fm, my_li = nx_li;
+      fetch(base + 64, nx_key, nx_fm, nx_li);
+      const int nhere = min(64, L - base);
+      for (int j = 0; j < nhere; ++j) {
+        LDS_FENCE();
+        const int jj = __builtin_amdgcn_readfirstlane(j);
+        const unsigned key = (unsigned)RL(my_key, jj);
+        const int l = (int)(key & 0xffffu);
+        const int cell = (int)(key >> 16) - 64, bucket = cell >> 4, cls = grouping ? (bucket >= kBuildBuckets ? 1 : 0) : bucket;
+        if (cls != cur_cls) {
+          if (cur_cls == 0) row1[0] = nrows;
+          if (cls == 1 && cur_cls < 0) { row0[0] = nrows; row1[0] = nrows; }
+          row0[cls] = nrows;
+          q_head = -1; q_tail = -1; q_size = 0; q_and = ~0u;       // open.clear(): the lists live through a class
           prev_first = nrows;
+          cur_cls = cls;
         }
-        cur_bucket = bucket;
-      }
-      const int len = VL[l].len, itm = VL[l].items;
-      const unsigned fm = VL[l].fm & kLineMask;
-      int rr = -1;
-      // pass 0: the fullest open row that holds the line and shares no free camera with it (at most 32 candidates per list, newest first;
-      // a list whose and-mask meets the line's cameras cannot hold such a row and is not read)
-      unsigned long long m0 = __ballot(lane >= len && lane <= 16 && q_size > 0 && !(q_and & fm));
-      while (m0 && rr < 0) {
-        const int room = __ffsll((long long)m0) - 1;
-        m0 &= m0 - 1;
-        int cur = __shfl(q_tail, room);
-        for (int steps = 0; cur >= 0 && steps < 32; ++steps) {
-          if (!(VR[cur].mask & fm)) { rr = cur; break; }
-          const int pv = VR[cur].lprev;
-          cur = pv == kNoRow ? -1 : pv;
+        if (bucket != cur_bucket) {
+          if (grouping) {
+            // only the rows the previous group left open stay in the lists (lba_pack.cpp:229-236)
+            for (int q = 0; q <= 16; ++q) {
+              int cur = RL(q_head, q);
+              while (cur >= 0) {
+                const uint4 v = R4[cur];
+                const int pv = (int)(v.z & 0xffffu), nx = (int)(v.z >> 16);
+                if (cur < prev_first) unlink(q, cur, pv, nx);
+                LDS_FENCE();
+                cur = nx == kNoRow ? -1 : nx;
+              }
+            }
+            prev_first = nrows;
+          }
+          cur_bucket = bucket;
         }
-        if (rr >= 0) unlink(room, rr);
+        const unsigned li = (unsigned)RL(my_li, jj), fmw = (unsigned)RL(my_fm, jj);
+        const int len = (int)(li & 0xffu), itm = (int)(li >> 8);
+        const unsigned fm = fmw & kLineMask;
+        int rr = -1, room = 0;
+        unsigned rx = 0, ry = 0, rz = 0, rw = 0;
+        // pass 0: the fullest open row that holds the line and shares no free camera with it (at most 32 candidates per list, newest first;
+        // a list whose and-mask meets the line's cameras cannot hold such a row and is not read)
+        unsigned long long m0 = __ballot(lane >= len && lane <= 16 && q_size > 0 && !(q_and & fm));
+        while (m0 && rr < 0) {
+          room = __ffsll((long long)m0) - 1;
+          m0 &= m0 - 1;
+          int cur = RL(q_tail, room);
+          for (int steps = 0; cur >= 0 && steps < 32; ++steps) {
+            const uint4 v = R4[cur];
+            if (!(v.w & fm)) { rr = cur; rx = v.x; ry = v.y; rz = v.z; rw = v.w; break; }
+            const int pv = (int)(v.z & 0xffffu);
+            cur = pv == kNoRow ? -1 : pv;
+          }
+        }
+        if (rr < 0) {
+          // pass 1: the fullest open row that holds it
+          const unsigned long long m1 = __ballot(lane >= len && lane <= 16 && q_size > 0);
+          if (m1) {
+            room = __ffsll((long long)m1) - 1;
+            rr = RL(q_tail, room);
+            const uint4 v = R4[rr];
+            rx = v.x; ry = v.y; rz = v.z; rw = v.w;
+          }
+        }
+        if (rr >= 0) {
+          rr = __builtin_amdgcn_readfirstlane(rr);
+          rx = (unsigned)__builtin_amdgcn_readfirstlane((int)rx); ry = (unsigned)__builtin_amdgcn_readfirstlane((int)ry);
+          rz = (unsigned)__builtin_amdgcn_readfirstlane((int)rz); rw = (unsigned)__builtin_amdgcn_readfirstlane((int)rw);
+          unlink(room, rr, (int)(rz & 0xffffu), (int)(rz >> 16));
+          // append (the row has a line already)
+          const int tail = (int)(ry >> 16);
+          if (lane == 0) NX[tail] = (uint16_t)l;
+          ry = (ry & 0xffffu) | (unsigned)l << 16;
+          rx = ((rx & 0xffu) + (unsigned)len) | (((rx >> 8) & 0xffu) + 1u) << 8 | ((rx >> 16) + (unsigned)itm) << 16;
+          rw |= fm;
+        } else {
+          rr = nrows++;
+          rx = (unsigned)len | 1u << 8 | (unsigned)itm << 16; ry = (unsigned)l | (unsigned)l << 16; rw = fm;
+        }
+        const int used = (int)(rx & 0xffu);
+        if (used < 16) {
+          // push: the row joins the list of its remaining room, at the tail
+          const int room2 = 16 - used;
+          const int t = RL(q_tail, room2), sz = RL(q_size, room2);
+          rz = (unsigned)(t < 0 ? kNoRow : t) | (unsigned)kNoRow << 16;
+          if (t >= 0) { if (lane == 0) R[t].lnext = (uint16_t)rr; } else WL(q_head, rr, room2);
+          WL(q_tail, rr, room2);
+          WL(q_and, sz == 0 ? rw : ((unsigned)RL(q_and, room2) & rw), room2);
+          WL(q_size, sz + 1, room2);
+        } else rz = (unsigned)kNoRow | (unsigned)kNoRow << 16;
+        store_row(rr, rx, ry, rz, rw);
       }
-      if (rr < 0) {
-        // pass 1: the fullest open row that holds it
-        const unsigned long long m1 = __ballot(lane >= len && lane <= 16 && q_size > 0);
-        if (m1) { const int room = __ffsll((long long)m1) - 1; rr = __shfl(q_tail, room); unlink(room, rr); }
-      }
-      if (rr < 0) rr = new_row();
-      append(rr, l, len, itm, fm);
-      const int used = VR[rr].used;
-      if (used < 16) push(16 - used, rr, VR[rr].mask);
     }
+    LDS_FENCE();
+#undef RL
+#undef WL
     if (cur_cls == 0) { row1[0] = nrows; row0[1] = nrows; row1[1] = nrows; }
     if (cur_cls == 1) row1[1] = nrows;
-    if (lane == 0) { s_ntr = ntr; s_ntiles = ntp - 1; s_cls_row[0] = row0[0]; s_cls_row[1] = row1[0]; s_cls_row[2] = row0[1]; s_cls_row[3] = row1[1]; }
+    BUILD_STAMP(4);
+    // ---- to the next stage: the rows, the chains, the window's counts
+    LDS_FENCE();
+#undef LDS_FENCE
+    uint4* g_rows = P.mid_rows + r.line_off;
+    for (int q = lane; q < nrows; q += 64) g_rows[q] = reinterpret_cast<uint4*>(R)[q];
+    uint16_t* g_next = P.mid_next + r.line_off;
+    for (int l = lane; l < L; l += 64) g_next[l] = NX[l];
+    if (lane == 0) {
+      BuildMid& m = P.mid[w];
+      m.nrows = nrows; m.ntr = ntr; m.ntp = ntp; m.cls_row[0] = row0[0]; m.cls_row[1] = row1[0]; m.cls_row[2] = row0[1]; m.cls_row[3] = row1[1];
+    }
+#undef BUILD_STAMP
+}
+
+// Row order, tile ranges, line order, line pointers, the observations of every line sorted by camera, the window's line-level arrays
+// (lba_pack.cpp:238-333): parallel again, 256 threads per window.  LDS as k_build_lines plus the rows and the tile tables read back.
+__global__ __launch_bounds__(256) void k_build_order(BuildPtrs P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char build_smem[];
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const RawWin r = P.raw[w];
+  const int L = r.L, M = r.M, grouping = P.grouping;
+  const int Lp = build_pow2(L), Lq = L > 0 ? L : 1;
+  const BuildMid mid = P.mid[w];
+  if (!mid.ok) return;
+  unsigned* A = reinterpret_cast<unsigned*>(build_smem);
+  unsigned long long* CM = reinterpret_cast<unsigned long long*>(A + Lp);
+  BuildLine* LI = reinterpret_cast<BuildLine*>(CM);
+  BuildRow* R = reinterpret_cast<BuildRow*>(CM + Lq);
+  uint16_t* T = reinterpret_cast<uint16_t*>(R + Lq);
+  uint16_t* tile_rows = T;
+  uint16_t* tile_ptr = T + Lq + 2;
+  unsigned* part = reinterpret_cast<unsigned*>(T + 2 * Lq + 8);
+  __shared__ int s_ntr, s_ntiles, s_cls_row[4], s_nkept;
+  __shared__ signed char s_cam_cf[64];
+  BuildWin* bw = P.bw + w;
+  const uint32_t* ridx = P.raw_idx + r.obs_off;
+  const unsigned long long freeset = mid.freeset, constset = mid.constset;
+  const int Cf = mid.Cf;
+#define BUILD_STAMP(i) do { if (P.dbg && w == 0 && tid == 0) P.dbg[i] = (unsigned long long)wall_clock64(); } while (0)
+  // the line records (with the chains the row stage made), the rows, the tile tables of the long lines
+  {
+    const unsigned long long* g_li = reinterpret_cast<const unsigned long long*>(P.mid_li + r.line_off);
+    const uint16_t* g_next = P.mid_next + r.line_off;
+    for (int l = tid; l < L; l += 256) { CM[l] = g_li[l]; }
+    __syncthreads();
+    for (int l = tid; l < L; l += 256) LI[l].next = g_next[l];
+    const uint4* g_rows = P.mid_rows + r.line_off;
+    for (int q = tid; q < mid.nrows; q += 256) reinterpret_cast<uint4*>(R)[q] = g_rows[q];
+    const uint16_t* g_tr = P.mid_trows + r.line_off + 8 * w;
+    const uint16_t* g_tp = P.mid_tptr + r.line_off + 8 * w;
+    for (int q = tid; q < mid.ntr; q += 256) tile_rows[q] = g_tr[q];
+    for (int q = tid; q < mid.ntp; q += 256) tile_ptr[q] = g_tp[q];
+    if (tid < 64) s_cam_cf[tid] = (tid < r.C && ((freeset >> tid) & 1ull)) ? (signed char)__popcll(freeset & ((1ull << tid) - 1ull)) : (signed char)-1;
+    if (tid == 0) { s_ntr = mid.ntr; s_ntiles = mid.ntp - 1; for (int q = 0; q < 4; ++q) s_cls_row[q] = mid.cls_row[q]; s_nkept = 0; }
   }
   __syncthreads();
-
+  BUILD_STAMP(4);
   // ---- the rows of each class in tile order (lba_pack.cpp:238-283), then the tiles' row ranges
   for (int cls = 0; cls < 2; ++cls) {
     const int r0 = s_cls_row[2 * cls], r1 = s_cls_row[2 * cls + 1], nr = r1 - r0;
@@ -452,11 +600,10 @@ __global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
       __syncthreads();
       block_bitonic_sort(A, np);
     }
-    if (tid == 0) {
-      int ntr = s_ntr, ntp = s_ntiles + 1;
-      const int first = ntr;
-      if (!grouping && cls == 0) {
+    if (!grouping && cls == 0) {
+      if (tid == 0) {
         // boustrophedon deal: heavy rows meet light rows (the rows in order of falling pair-item count)
+        int ntr = s_ntr, ntp = s_ntiles + 1;
         const int Tn = (nr + 3) / 4;
         for (int t = 0; t < Tn; ++t) {
           for (int pass = 0; pass < 4; ++pass) {
@@ -465,18 +612,21 @@ __global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
           }
           tile_ptr[ntp++] = (uint16_t)ntr;
         }
-      } else {
-        for (int q = 0; q < nr; ++q) {
-          tile_rows[ntr++] = (uint16_t)(by_key ? r0 + (int)(A[q] & 0xffffu) : r0 + q);
-          if ((ntr - first) % 4 == 0 || q + 1 == nr) tile_ptr[ntp++] = (uint16_t)ntr;
-        }
+        s_ntr = ntr; s_ntiles = ntp - 1;
       }
-      s_ntr = ntr; s_ntiles = ntp - 1;
+    } else {
+      // four rows to a tile, in order
+      const int first = s_ntr, tp0 = s_ntiles + 1, nt = (nr + 3) / 4;
+      for (int q = tid; q < nr; q += 256) tile_rows[first + q] = (uint16_t)(by_key ? r0 + (int)(A[q] & 0xffffu) : r0 + q);
+      for (int t = tid; t < nt; t += 256) tile_ptr[tp0 + t] = (uint16_t)(first + min(4 * (t + 1), nr));
+      __syncthreads();
+      if (tid == 0) { s_ntr = first + nr; s_ntiles = tp0 + nt - 1; }
     }
     __syncthreads();
   }
   const int ntr = s_ntr, ntiles = s_ntiles;
 
+  BUILD_STAMP(5);
   // ---- line order: the rows in tile order, the lines of a row as they were appended
   int* g_line_orig = P.line_orig + r.line_off;
   uint8_t* g_lflags = P.lflags + r.line_off;
@@ -505,11 +655,12 @@ __global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
     fill[s] = 0;
   }
   __syncthreads();
-  for (int s = tid; s < L; s += 256) line_pos[g_line_orig[s]] = (uint16_t)s;
+  for (int s = tid; s < L; s += 256) { const int l = g_line_orig[s]; line_pos[l] = (uint16_t)s; if (P.line_pos) P.line_pos[r.line_off + l] = s; }
   block_scan_excl(lptr, L, part);
   if (tid == 0) lptr[L] = (unsigned)M;
   __syncthreads();
 
+  BUILD_STAMP(6);
   // ---- the observations of every line, free cameras first (ascending free index), then the others by id; ties in the caller's order
   // (lba_pack.cpp:308-333): keys camera key << 24 | index dropped into the line's range, then sorted per line
   unsigned* okey = reinterpret_cast<unsigned*>(P.ob_orig + r.obs_off);
@@ -526,6 +677,7 @@ __global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
   }
   if (kept) atomicAdd(&s_nkept, kept);
   __syncthreads();
+  BUILD_STAMP(7);
   int* g_ob_cam = P.ob_cam + r.obs_off;
   for (int s = tid; s < L; s += 256) {
     const int o0 = (int)lptr[s], k = (int)lptr[s + 1] - o0;
@@ -542,6 +694,7 @@ __global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
       g_ob_cam[o0 + a] = (int)((ridx[i] >> 16) & 0xffu);
     }
   }
+  BUILD_STAMP(8);
   // ---- the window's line-level arrays
   for (int s = tid; s < L; s += 256) {
     const int l = g_line_orig[s];
@@ -555,8 +708,10 @@ __global__ __launch_bounds__(256) void k_build_window(BuildPtrs P) {
     dst[0] = src[0]; dst[1] = src[1];
   }
   if (tid == 0) {
-    bw->Cf = Cf; bw->ntiles = ntiles; bw->nitems = s_nitems; bw->nfree_params = 6 * Cf + 4 * s_free_lines; bw->nkept = s_nkept;
+    bw->Cf = Cf; bw->ntiles = ntiles; bw->nitems = mid.nitems; bw->nfree_params = 6 * Cf + 4 * mid.free_lines; bw->nkept = s_nkept;
   }
+  BUILD_STAMP(9);
+#undef BUILD_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

@@ -113,7 +113,9 @@ def test_device_build_flags_what_it_leaves_to_the_host_path(hip):
     cam[same[1]] = cam[same[0]]                                          # camera sees line twice
     assert hip.debug_device_pack(dict(w, camera_index=cam))[0] == 2
     assert hip.debug_device_pack(synth.make_window(72, num_lines=40, num_kf=30, num_free=24, mean_track=10.0))[0] == 2      # 24 free cameras
-    assert hip.debug_device_pack(synth.make_window(31, num_lines=100, num_kf=80, num_free=40, mean_track=30.0))[0] != 0     # 80 cameras: refused or flagged
+    with pytest.raises(hip.SlslamError) as e:                            # 80 cameras: refused before anything is launched
+        hip.debug_device_pack(synth.make_window(31, num_lines=100, num_kf=80, num_free=40, mean_track=30.0))
+    assert e.value.status == 4
     assert hip.debug_device_pack(w)[0] == 0
 
 

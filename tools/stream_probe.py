@@ -21,12 +21,14 @@ def main():
     ap.add_argument("--batches", type=int, default=8)
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--mode", default="pinned", help="pinned: page-locked arrays, zero-copy ingest + device build; pageable: staging copy + device build; host: the host packer")
     args = ap.parse_args()
     B = args.windows
     windows = [synth.make_window(i, num_lines=args.lines) for i in range(B)]
     nsets = args.depth + 1 + args.batches
-    sets = [capi.WindowSet(windows[(k * 37) % B:] + windows[:(k * 37) % B]) for k in range(nsets)]
-    st = capi.LBAStream(depth=args.depth, host_threads=args.host_threads)
+    base = capi.WindowSet(windows, pinned=(args.mode == "pinned"))
+    sets = [base.derive(list(range((k * 37) % B, B)) + list(range((k * 37) % B))) for k in range(nsets)]
+    st = capi.LBAStream(depth=args.depth, host_threads=args.host_threads, **({"device_build": -1} if args.mode == "host" else {}))
     tick = []
     for k in range(args.depth + 1):
         if k >= args.depth:
@@ -47,7 +49,7 @@ def main():
     dt = time.perf_counter() - t00
     for r in rows:
         print("batch %2d  collect %.2f ms  submit %.2f ms" % r)
-    print(json.dumps({"ms_per_batch": 1e3 * dt / args.batches, "stats": st.stats()}))
+    print(json.dumps({"ms_per_batch": 1e3 * dt / args.batches, "stats": st.stats(), "build_stats": st.build_stats()}))
     st.close()
 
 
