@@ -1798,7 +1798,7 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
   }
   if (B > 0) {
     hipLaunchKernelGGL(k_build_lines, dim3((unsigned)B), dim3(256), build_lines_lds_bytes(maxL), s, P);
-    hipLaunchKernelGGL(k_build_rows, dim3((unsigned)B), dim3(64), build_rows_lds_bytes(maxL), s, P);
+    hipLaunchKernelGGL(k_build_rows, dim3((unsigned)B), dim3(128), build_rows_lds_bytes(maxL), s, P);
     hipLaunchKernelGGL(k_build_order, dim3((unsigned)B), dim3(256), lds_build, s, P);
     hipLaunchKernelGGL(k_build_layout, dim3(1), dim3(256), 0, s, P, a);
     hipLaunchKernelGGL(k_build_tiles, dim3((unsigned)B), dim3(256), lds_tiles, s, P, (const int*)b->d_cam_cf.p);
@@ -2242,7 +2242,7 @@ extern "C" int slslam_debug_device_pack_timed(const slslam_lba_window* w, int gr
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_ingest, dim3(1), dim3(256), 0, 0, P);
     hipLaunchKernelGGL(k_build_lines, dim3(1), dim3(256), build_lines_lds_bytes(L), 0, P);
-    hipLaunchKernelGGL(k_build_rows, dim3(1), dim3(64), build_rows_lds_bytes(L), 0, P);
+    hipLaunchKernelGGL(k_build_rows, dim3(1), dim3(128), build_rows_lds_bytes(L), 0, P);
     hipLaunchKernelGGL(k_build_order, dim3(1), dim3(256), lds_build, 0, P);
     hipLaunchKernelGGL(k_build_layout, dim3(1), dim3(256), 0, 0, P, a);
     hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), lds_tiles, 0, P, (const int*)d_cam_cf.p);
@@ -2290,8 +2290,11 @@ struct slslam_lba_stream {
   };
   std::vector<Slot> slots;
   hipStream_t ingest_stream = nullptr, solve_stream = nullptr;      // shared by the slots whose refills are built on the device (see refill_device)
-  hipStream_t result_stream = nullptr;       // ... and where their results leave: the export over the link and the state / trace copies of batch k run beside the build of batch k + 1
-  hipEvent_t ev_solved = nullptr;
+  hipStream_t build_stream = nullptr;        // ... the build kernels of batch k + 1 run BESIDE the solve of batch k: they are latency-bound (one wave walks a window's lines) and
+                                             // leave the chip mostly idle - and a chip that idles for 3 ms between two solves starts the next one at lower clocks (measured: the
+                                             // first solve after a light-load gap 16.6 ms against 15.0 back to back, tools/first_solve_after_refill.py)
+  hipStream_t result_stream = nullptr;       // ... and where their results leave: the export over the link and the state / trace copies of batch k
+  hipEvent_t ev_solved = nullptr, ev_built = nullptr;
   long long next_ticket = 0;
   // host-side accounting (ms, wall clock of the calling thread)
   double ms_submit = 0, ms_collect_wait = 0, ms_collect_copy = 0;
@@ -2325,9 +2328,12 @@ extern "C" int slslam_lba_stream_create(int device, const slslam_solver_options*
   int pr_lo = 0, pr_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
   if (hipStreamCreateWithPriority(&st->ingest_stream, hipStreamNonBlocking, pr_hi) != hipSuccess || hipStreamCreateWithFlags(&st->solve_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&st->result_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&st->ev_solved, hipEventDisableTiming) != hipSuccess) {
+      hipStreamCreateWithFlags(&st->build_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&st->result_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&st->ev_solved, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&st->ev_built, hipEventDisableTiming) != hipSuccess) {
     if (st->ingest_stream) (void)hipStreamDestroy(st->ingest_stream);
     if (st->solve_stream) (void)hipStreamDestroy(st->solve_stream);
+    if (st->build_stream) (void)hipStreamDestroy(st->build_stream);
     if (st->result_stream) (void)hipStreamDestroy(st->result_stream);
     delete st;
     return SLSLAM_ERR_HIP;
@@ -2341,6 +2347,7 @@ extern "C" void slslam_lba_stream_destroy(slslam_lba_stream* st) {
   (void)hipSetDevice(st->device);
   if (st->ingest_stream) (void)hipStreamSynchronize(st->ingest_stream);
   if (st->solve_stream) (void)hipStreamSynchronize(st->solve_stream);
+  if (st->build_stream) (void)hipStreamSynchronize(st->build_stream);
   if (st->result_stream) (void)hipStreamSynchronize(st->result_stream);
   for (auto& sl : st->slots) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
@@ -2349,8 +2356,10 @@ extern "C" void slslam_lba_stream_destroy(slslam_lba_stream* st) {
   }
   if (st->ingest_stream) (void)hipStreamDestroy(st->ingest_stream);
   if (st->solve_stream) (void)hipStreamDestroy(st->solve_stream);
+  if (st->build_stream) (void)hipStreamDestroy(st->build_stream);
   if (st->result_stream) (void)hipStreamDestroy(st->result_stream);
   if (st->ev_solved) (void)hipEventDestroy(st->ev_solved);
+  if (st->ev_built) (void)hipEventDestroy(st->ev_built);
   delete st;
 }
 
@@ -2366,8 +2375,13 @@ extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_
     slslam_lba_batch* b = sl.batch;
     // the build stage on the device: ingest on the stream's ONE ingest stream, build + solve + results on its ONE solve stream
     if (b->finalized && b->refillable && !b->part[0] && !b->big_mode && !b->fused_motion_only && !b->opt.reuse_elimination && (int)b->wins.size() == n) {
-      rc = refill_device(b, windows, n, st->solve_stream, st->ingest_stream);
-      if (rc == SLSLAM_OK) run = st->solve_stream;
+      static const bool serial_build = std::getenv("SLSLAM_STREAM_SERIAL_BUILD") != nullptr;      // (measurement switch: build and solve on one stream)
+      hipStream_t bs = serial_build ? st->solve_stream : st->build_stream;
+      rc = refill_device(b, windows, n, bs, st->ingest_stream);
+      if (rc == SLSLAM_OK) {
+        run = st->solve_stream;
+        if (bs != run) { HIP_TRY(hipEventRecord(st->ev_built, bs)); HIP_TRY(hipStreamWaitEvent(run, st->ev_built, 0)); }
+      }
     }
     if (rc == SLSLAM_ERR_UNSUPPORTED) {
       // the host packer (or refused: a new batch below): its uploads overlap the other slots' solves on a stream of the slot's own
@@ -2379,7 +2393,7 @@ extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_
   if (rc == SLSLAM_OK) { ++st->n_refills; if (sl.batch->device_built) { ++st->n_device_builds; if (!sl.batch->host_src.empty() && !sl.batch->host_src[0].packed) ++st->n_zero_copy; } }
   else if (rc == SLSLAM_ERR_UNSUPPORTED) {
     // the first batch of the slot, another number of windows, or windows that do not fit the room the slot's arrays have: a new batch
-    if (sl.batch) { if (sl.stream) HIP_TRY(hipStreamSynchronize(sl.stream)); HIP_TRY(hipStreamSynchronize(st->solve_stream)); HIP_TRY(hipStreamSynchronize(st->result_stream)); sl.batch->ext_pool = nullptr; slslam_lba_batch_destroy(sl.batch); sl.batch = nullptr; }
+    if (sl.batch) { if (sl.stream) HIP_TRY(hipStreamSynchronize(sl.stream)); HIP_TRY(hipStreamSynchronize(st->solve_stream)); HIP_TRY(hipStreamSynchronize(st->build_stream)); HIP_TRY(hipStreamSynchronize(st->result_stream)); sl.batch->ext_pool = nullptr; slslam_lba_batch_destroy(sl.batch); sl.batch = nullptr; }
     slslam_lba_batch* b = nullptr;
     if ((rc = slslam_lba_batch_create(st->device, &b)) != SLSLAM_OK) return rc;
     b->ext_pool = st->pool.get();

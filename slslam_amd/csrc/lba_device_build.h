@@ -64,8 +64,8 @@ struct BuildMid {
   unsigned long long freeset, constset;   // cameras: free (used and not constant) | constant
   int ok;                     // 0: the window was flagged, the later stages skip it
   int Cf, free_lines, nitems;
+  int n_long, n_cls0;         // (k_build_lines) lines with more than 16 observations | of at least 4 lanes among the others: their runs in the packing order
   int nrows, ntr, ntp, cls_row[4];        // (k_build_rows) rows made | row entries and tile ranges of the long lines | row range of each length class
-  int pad;
 };
 
 // Everything the build kernels touch, by value.
@@ -246,12 +246,12 @@ __global__ __launch_bounds__(256) void k_build_lines(BuildPtrs P) {
   unsigned long long* CM = reinterpret_cast<unsigned long long*>(A + Lp);
   BuildLine* LI = reinterpret_cast<BuildLine*>(CM);
   __shared__ unsigned long long s_cam_used, s_cam_const;
-  __shared__ int s_flags, s_free_lines, s_nitems;
+  __shared__ int s_flags, s_free_lines, s_nitems, s_nlong, s_ncls0;
   __shared__ signed char s_cam_cf[64];
 #define BUILD_STAMP(i) do { if (P.dbg && w == 0 && tid == 0) P.dbg[i] = (unsigned long long)wall_clock64(); } while (0)
   BUILD_STAMP(0);
   BuildWin* bw = P.bw + w;
-  if (tid == 0) { s_cam_used = 0; s_cam_const = 0; s_flags = 0; s_free_lines = 0; s_nitems = 0; }
+  if (tid == 0) { s_cam_used = 0; s_cam_const = 0; s_flags = 0; s_free_lines = 0; s_nitems = 0; s_nlong = 0; s_ncls0 = 0; }
   for (int l = tid; l < L; l += 256) { A[l] = 0; CM[l] = 0; }
   __syncthreads();
   const bool alive = bw->status == 0 && C <= kMaxCams;        // (else: the ingest flagged the window - a bad index, a non-finite value)
@@ -320,9 +320,10 @@ __global__ __launch_bounds__(256) void k_build_lines(BuildPtrs P) {
       if (!is_const && cnt > 0) atomicAdd(&s_free_lines, 1);
       if (!grouping && itm) atomicAdd(&s_nitems, itm);
       unsigned ck;
-      if (cnt > 16) ck = (unsigned)(64 - cnt);
+      if (cnt > 16) { ck = (unsigned)(64 - cnt); atomicAdd(&s_nlong, 1); }
       else {
         const int cls = len < 4 ? 1 : 0, nb = grouping ? kBuildBuckets : 1;
+        if (!cls) atomicAdd(&s_ncls0, 1);
         int bq = 0;
         if (grouping) { const int gk = build_group_key(li.fm); bq = gk >= 1000 ? kBuildBuckets - 1 : gk; }
         ck = 64u + (unsigned)((cls * nb + bq) * 16 + (16 - len));
@@ -341,194 +342,210 @@ __global__ __launch_bounds__(256) void k_build_lines(BuildPtrs P) {
   for (int l = tid; l < L; l += 256) { g_keys[l] = A[l]; g_li[l] = CM[l]; }
   if (tid == 0) {
     BuildMid& m = P.mid[w];
-    m.freeset = freeset; m.constset = constset; m.Cf = Cf; m.free_lines = s_free_lines; m.nitems = s_nitems; m.ok = 1;
+    m.freeset = freeset; m.constset = constset; m.Cf = Cf; m.free_lines = s_free_lines; m.nitems = s_nitems; m.n_long = s_nlong; m.n_cls0 = s_ncls0; m.ok = 1;
   }
 #undef BUILD_STAMP
 }
 
-// The rows: best fit over the sorted lines (lba_pack.cpp:153-172) - the one sequential stage of the build, ONE wave per window so that four
-// windows share a CU (36 KB of LDS each for 2000 lines: the whole batch of 1024 windows is resident at once).
-// LDS: R [L] 16 B row records | NX [L] u16 next line of a line's row.
+// The rows: best fit over the sorted lines (lba_pack.cpp:153-172) - the one sequential stage of the build, so it is written for latency and
+// runs TWO WAVES per window: the two length classes (lines of at least 4 lanes; shorter ones) are packed independently of each other
+// (lba_pack.cpp:221-251: the open lists are cleared between them), wave 0 takes the long lines and class 0, wave 1 class 1, four windows to a
+// CU (36 KB of LDS each for 2000 lines: the whole batch of 1024 windows is resident at once).
+//   * the 17 lists of open rows (by the lanes a row has left) live one per lane: tail and and-mask of lane q are list q's, read with
+//     v_readlane and written under a lane compare (the list index is wave-uniform: no LDS round trip); the rows of a list are chained
+//     through R[].lprev / lnext (a row sits in at most one list; a list is walked from its tail);
+//   * the sorted lines come 64 at a time, one block ahead of the walk: lane j fetches line b + j's record, the walk reads it with v_readlane;
+//   * what is left per line is ONE dependent LDS read - the 16-byte record of the chosen row - and one block of stores by lane 0.
+// Wave 1 keeps its rows at the top of R going down (row j of class 1 at R[L - 1 - j]): the two waves never meet (a row holds at least one
+// line).  LDS: R [L] 16 B row records | NX [L] u16 next line of a line's row.
 __host__ __device__ inline size_t build_rows_lds_bytes(int L) { const size_t Lq = (size_t)(L > 0 ? L : 1); return 16 * Lq + 2 * Lq + 64; }
-__global__ __launch_bounds__(64) void k_build_rows(BuildPtrs P) {
+__global__ __launch_bounds__(128) void k_build_rows(BuildPtrs P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rows_smem[];
-  const int w = blockIdx.x, tid = threadIdx.x, lane = tid;
+  const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const RawWin r = P.raw[w];
   const int L = r.L, grouping = P.grouping;
   const int Lq = L > 0 ? L : 1;
-  if (!P.mid[w].ok) return;
+  const BuildMid mid = P.mid[w];
+  if (!mid.ok) return;
   BuildRow* R = reinterpret_cast<BuildRow*>(rows_smem);
+  uint4* R4 = reinterpret_cast<uint4*>(R);
   uint16_t* NX = reinterpret_cast<uint16_t*>(R + Lq);
   const unsigned* A = P.mid_keys + r.line_off;
   const BuildLine* LI = P.mid_li + r.line_off;
   uint16_t* tile_rows = P.mid_trows + r.line_off + 8 * w;
   uint16_t* tile_ptr = P.mid_tptr + r.line_off + 8 * w;
+  __shared__ int s_rows0, s_ntr, s_ntp, s_nbig;
 #define BUILD_STAMP(i) do { if (P.dbg && w == 0 && tid == 0) P.dbg[i] = (unsigned long long)wall_clock64(); } while (0)
   BUILD_STAMP(3);
-  for (int l = lane; l < L; l += 64) NX[l] = (uint16_t)kNoRow;
+  for (int l = tid; l < L; l += 128) NX[l] = (uint16_t)kNoRow;
   __syncthreads();
-    // (plain LDS pointers + compiler barriers: `volatile` would turn every access into a FLAT instruction with a full wait behind it - measured
-    // 1300 cycles per line)
-    uint4* R4 = reinterpret_cast<uint4*>(R);
-    int q_head = -1, q_tail = -1, q_size = 0;
-    unsigned q_and = ~0u;
-    int nrows = 0, ntr = 0, ntp = 1;
-    if (lane == 0) tile_ptr[0] = 0;
 #define RL(v, i) __builtin_amdgcn_readlane((int)(v), (i))
 #define WL(v, val, i) do { if (lane == (i)) (v) = (val); } while (0)      /* (no v_writelane builtin in this compiler: a compare + select) */
 #define LDS_FENCE() asm volatile("" ::: "memory")
-    // row record in registers: x = used | nl << 8 | items << 16, y = head | tail << 16, z = lprev | lnext << 16, w = mask
-    auto store_row = [&](int rr, unsigned x, unsigned y, unsigned z, unsigned wv) { if (lane == 0) { uint4 v; v.x = x; v.y = y; v.z = z; v.w = wv; R4[rr] = v; } };
-    auto unlink = [&](int room, int rr, int p, int n) {
-      if (lane == 0) { if (p != kNoRow) R[p].lnext = (uint16_t)n; if (n != kNoRow) R[n].lprev = (uint16_t)p; }
-      if (p == kNoRow) WL(q_head, n == kNoRow ? -1 : n, room);
-      if (n == kNoRow) WL(q_tail, p == kNoRow ? -1 : p, room);
-      WL(q_size, RL(q_size, room) - 1, room);
-    };
+  // (plain LDS pointers + compiler barriers: `volatile` turns every access into a FLAT instruction with a full wait behind it)
+  const int top = wave ? L - 1 : 0, sgn = wave ? -1 : 1;          // row j of this wave lives at R[top + sgn * j]
+#define PH(j) (top + sgn * (j))
+  int q_tail = -1;
+  unsigned q_and = ~0u;
+  int nrows = 0, ntr = 0, ntp = 1;
+  int i = wave ? mid.n_long + mid.n_cls0 : 0;
+  const int iend = wave ? L : mid.n_long + mid.n_cls0;
+  if (wave == 0) {
     // long lines: a row entry of their own that spans (k + 15) / 16 rows of one tile
-    int i = 0;
-    {
-      int used_rows = 4;
-      for (; i < L; ++i) {
-        const unsigned key = A[i];
-        if ((key >> 16) >= 64u) break;
-        const int l = (int)(key & 0xffffu);
-        const BuildLine li = LI[l];
-        const int len = li.len, nr = (len + 15) / 16;
-        if (used_rows + nr > 4) { if (ntr > 0) { if (lane == 0) tile_ptr[ntp] = (uint16_t)ntr; ++ntp; } used_rows = 0; }
-        const int rr = nrows++;
-        store_row(rr, (unsigned)len | 1u << 8 | (unsigned)li.items << 16, (unsigned)l | (unsigned)l << 16, (unsigned)kNoRow | (unsigned)kNoRow << 16, li.fm & kLineMask);
-        if (lane == 0) tile_rows[ntr] = (uint16_t)rr;
-        ++ntr;
-        used_rows += nr;
+    if (lane == 0) tile_ptr[0] = 0;
+    int used_rows = 4;
+    for (; i < mid.n_long; ++i) {
+      const unsigned key = A[i];
+      const int l = (int)(key & 0xffffu);
+      const BuildLine li = LI[l];
+      const int len = li.len, nr = (len + 15) / 16;
+      if (used_rows + nr > 4) { if (ntr > 0) { if (lane == 0) tile_ptr[ntp] = (uint16_t)ntr; ++ntp; } used_rows = 0; }
+      const int rr = nrows++;
+      if (lane == 0) {
+        uint4 v; v.x = (unsigned)len | 1u << 8 | (unsigned)li.items << 16; v.y = (unsigned)l | (unsigned)l << 16; v.z = (unsigned)kNoRow | (unsigned)kNoRow << 16; v.w = li.fm & kLineMask;
+        R4[rr] = v;
+        tile_rows[ntr] = (uint16_t)rr;
       }
-      if (ntr > 0) { if (lane == 0) tile_ptr[ntp] = (uint16_t)ntr; ++ntp; }
+      ++ntr;
+      used_rows += nr;
     }
+    if (ntr > 0) { if (lane == 0) tile_ptr[ntp] = (uint16_t)ntr; ++ntp; }
     i = __builtin_amdgcn_readfirstlane(i);
-    LDS_FENCE();
-    int cur_cls = -1, cur_bucket = -1, prev_first = nrows;
-    int row0[2] = { nrows, nrows }, row1[2] = { nrows, nrows };
-    // lane j: the record of sorted line base + j - fetched from memory one block of 64 lines ahead of the walk
-    auto fetch = [&](int base, unsigned& k, unsigned& f, unsigned& q) {
-      k = 0xffffffffu; f = 0; q = 0;
-      if (base + lane < L) {
-        k = A[base + lane];
-        const BuildLine li = LI[k & 0xffffu];
-        f = li.fm; q = (unsigned)li.len | (unsigned)li.items << 8;
-      }
-    };
-    unsigned nx_key, nx_fm, nx_li;
-    fetch(i, nx_key, nx_fm, nx_li);
-    for (int base = i; base < L; base += 64) {
-      const unsigned my_key = nx_key, my_fm = nx_fm, my_li = nx_li;
-      fetch(base + 64, nx_key, nx_fm, nx_li);
-      const int nhere = min(64, L - base);
-      for (int j = 0; j < nhere; ++j) {
-        LDS_FENCE();
-        const int jj = __builtin_amdgcn_readfirstlane(j);
-        const unsigned key = (unsigned)RL(my_key, jj);
-        const int l = (int)(key & 0xffffu);
-        const int cell = (int)(key >> 16) - 64, bucket = cell >> 4, cls = grouping ? (bucket >= kBuildBuckets ? 1 : 0) : bucket;
-        if (cls != cur_cls) {
-          if (cur_cls == 0) row1[0] = nrows;
-          if (cls == 1 && cur_cls < 0) { row0[0] = nrows; row1[0] = nrows; }
-          row0[cls] = nrows;
-          q_head = -1; q_tail = -1; q_size = 0; q_and = ~0u;       // open.clear(): the lists live through a class
-          prev_first = nrows;
-          cur_cls = cls;
-        }
-        if (bucket != cur_bucket) {
-          if (grouping) {
-            // only the rows the previous group left open stay in the lists (lba_pack.cpp:229-236)
-            for (int q = 0; q <= 16; ++q) {
-              int cur = RL(q_head, q);
-              while (cur >= 0) {
-                const uint4 v = R4[cur];
-                const int pv = (int)(v.z & 0xffffu), nx = (int)(v.z >> 16);
-                if (cur < prev_first) unlink(q, cur, pv, nx);
-                LDS_FENCE();
-                cur = nx == kNoRow ? -1 : nx;
-              }
+  }
+  const int nbig = nrows;
+  LDS_FENCE();
+  int cur_bucket = -1, prev_first = nrows;
+  // lane j: the record of sorted line base + j - fetched from memory one block of 64 lines ahead of the walk
+  auto fetch = [&](int base, unsigned& k, unsigned& f, unsigned& q) {
+    k = 0xffffffffu; f = 0; q = 0;
+    if (base + lane < iend) {
+      k = A[base + lane];
+      const BuildLine li = LI[k & 0xffffu];
+      f = li.fm; q = (unsigned)li.len | (unsigned)li.items << 8;
+    }
+  };
+  unsigned nx_key, nx_fm, nx_li;
+  fetch(i, nx_key, nx_fm, nx_li);
+  for (int base = i; base < iend; base += 64) {
+    const unsigned my_key = nx_key, my_fm = nx_fm, my_li = nx_li;
+    fetch(base + 64, nx_key, nx_fm, nx_li);
+    const int nhere = min(64, iend - base);
+    for (int j = 0; j < nhere; ++j) {
+      LDS_FENCE();
+      const int jj = __builtin_amdgcn_readfirstlane(j);
+      const unsigned key = (unsigned)RL(my_key, jj);
+      const int l = (int)(key & 0xffffu);
+      const int bucket = ((int)(key >> 16) - 64) >> 4;
+      if (bucket != cur_bucket) {
+        if (grouping) {
+          // only the rows the previous group left open stay in the lists (lba_pack.cpp:229-236); a list is walked from its tail
+          for (int q = 0; q <= 16; ++q) {
+            int cur = RL(q_tail, q);
+            int after = -1;                                    // the row that follows `cur` in the list after the removals so far
+            while (cur >= 0) {
+              const uint4 v = R4[PH(cur)];
+              const int pv = (int)(v.z & 0xffffu), pvi = pv == kNoRow ? -1 : pv;
+              if (cur < prev_first) {
+                // unlink: the neighbours close ranks
+                if (lane == 0) { if (pvi >= 0) R[PH(pvi)].lnext = (uint16_t)(after < 0 ? kNoRow : after); if (after >= 0) R[PH(after)].lprev = (uint16_t)pv; }
+                if (after < 0) WL(q_tail, pvi, q);
+              } else after = cur;
+              LDS_FENCE();
+              cur = pvi;
             }
-            prev_first = nrows;
           }
-          cur_bucket = bucket;
+          prev_first = nrows;
         }
-        const unsigned li = (unsigned)RL(my_li, jj), fmw = (unsigned)RL(my_fm, jj);
-        const int len = (int)(li & 0xffu), itm = (int)(li >> 8);
-        const unsigned fm = fmw & kLineMask;
-        int rr = -1, room = 0;
-        unsigned rx = 0, ry = 0, rz = 0, rw = 0;
-        // pass 0: the fullest open row that holds the line and shares no free camera with it (at most 32 candidates per list, newest first;
-        // a list whose and-mask meets the line's cameras cannot hold such a row and is not read)
-        unsigned long long m0 = __ballot(lane >= len && lane <= 16 && q_size > 0 && !(q_and & fm));
-        while (m0 && rr < 0) {
-          room = __ffsll((long long)m0) - 1;
-          m0 &= m0 - 1;
-          int cur = RL(q_tail, room);
-          for (int steps = 0; cur >= 0 && steps < 32; ++steps) {
-            const uint4 v = R4[cur];
-            if (!(v.w & fm)) { rr = cur; rx = v.x; ry = v.y; rz = v.z; rw = v.w; break; }
-            const int pv = (int)(v.z & 0xffffu);
-            cur = pv == kNoRow ? -1 : pv;
-          }
+        cur_bucket = bucket;
+      }
+      const unsigned li = (unsigned)RL(my_li, jj), fmw = (unsigned)RL(my_fm, jj);
+      const int len = (int)(li & 0xffu), itm = (int)(li >> 8);
+      const unsigned fm = fmw & kLineMask;
+      int rr = -1, room = 0;
+      unsigned rx = 0, ry = 0, rz = 0, rw = 0;
+      const bool fits = lane >= len && lane <= 16 && q_tail >= 0;
+      // pass 0: the fullest open row that holds the line and shares no free camera with it (at most 32 candidates per list, newest first;
+      // a list whose and-mask meets the line's cameras cannot hold such a row and is not read)
+      unsigned long long m0 = __ballot(fits && !(q_and & fm));
+      while (m0 && rr < 0) {
+        room = __ffsll((long long)m0) - 1;
+        m0 &= m0 - 1;
+        int cur = RL(q_tail, room);
+        for (int steps = 0; cur >= 0 && steps < 32; ++steps) {
+          const uint4 v = R4[PH(cur)];
+          if (!(v.w & fm)) { rr = cur; rx = v.x; ry = v.y; rz = v.z; rw = v.w; break; }
+          const int pv = (int)(v.z & 0xffffu);
+          cur = pv == kNoRow ? -1 : pv;
         }
-        if (rr < 0) {
-          // pass 1: the fullest open row that holds it
-          const unsigned long long m1 = __ballot(lane >= len && lane <= 16 && q_size > 0);
-          if (m1) {
-            room = __ffsll((long long)m1) - 1;
-            rr = RL(q_tail, room);
-            const uint4 v = R4[rr];
-            rx = v.x; ry = v.y; rz = v.z; rw = v.w;
-          }
+      }
+      if (rr < 0) {
+        // pass 1: the fullest open row that holds it
+        const unsigned long long m1 = __ballot(fits);
+        if (m1) {
+          room = __ffsll((long long)m1) - 1;
+          rr = RL(q_tail, room);
+          const uint4 v = R4[PH(rr)];
+          rx = v.x; ry = v.y; rz = v.z; rw = v.w;
         }
-        if (rr >= 0) {
-          rr = __builtin_amdgcn_readfirstlane(rr);
-          rx = (unsigned)__builtin_amdgcn_readfirstlane((int)rx); ry = (unsigned)__builtin_amdgcn_readfirstlane((int)ry);
-          rz = (unsigned)__builtin_amdgcn_readfirstlane((int)rz); rw = (unsigned)__builtin_amdgcn_readfirstlane((int)rw);
-          unlink(room, rr, (int)(rz & 0xffffu), (int)(rz >> 16));
-          // append (the row has a line already)
-          const int tail = (int)(ry >> 16);
-          if (lane == 0) NX[tail] = (uint16_t)l;
-          ry = (ry & 0xffffu) | (unsigned)l << 16;
-          rx = ((rx & 0xffu) + (unsigned)len) | (((rx >> 8) & 0xffu) + 1u) << 8 | ((rx >> 16) + (unsigned)itm) << 16;
-          rw |= fm;
-        } else {
-          rr = nrows++;
-          rx = (unsigned)len | 1u << 8 | (unsigned)itm << 16; ry = (unsigned)l | (unsigned)l << 16; rw = fm;
-        }
-        const int used = (int)(rx & 0xffu);
-        if (used < 16) {
-          // push: the row joins the list of its remaining room, at the tail
-          const int room2 = 16 - used;
-          const int t = RL(q_tail, room2), sz = RL(q_size, room2);
-          rz = (unsigned)(t < 0 ? kNoRow : t) | (unsigned)kNoRow << 16;
-          if (t >= 0) { if (lane == 0) R[t].lnext = (uint16_t)rr; } else WL(q_head, rr, room2);
-          WL(q_tail, rr, room2);
-          WL(q_and, sz == 0 ? rw : ((unsigned)RL(q_and, room2) & rw), room2);
-          WL(q_size, sz + 1, room2);
-        } else rz = (unsigned)kNoRow | (unsigned)kNoRow << 16;
-        store_row(rr, rx, ry, rz, rw);
+      }
+      // what lane 0 stores for this line: [neighbour p].lnext, [neighbour n].lprev, NX[tail], [list tail t].lnext, the row's record
+      int st_p = -1, st_n = -1, st_tail = -1, st_t = -1, st_pv = 0, st_nv = 0;
+      if (rr >= 0) {
+        rr = __builtin_amdgcn_readfirstlane(rr);
+        rx = (unsigned)__builtin_amdgcn_readfirstlane((int)rx); ry = (unsigned)__builtin_amdgcn_readfirstlane((int)ry);
+        rz = (unsigned)__builtin_amdgcn_readfirstlane((int)rz); rw = (unsigned)__builtin_amdgcn_readfirstlane((int)rw);
+        // unlink from its list
+        const int p = (int)(rz & 0xffffu), n = (int)(rz >> 16);
+        if (p != kNoRow) { st_p = p; st_pv = n; }
+        if (n != kNoRow) { st_n = n; st_nv = p; } else WL(q_tail, p == kNoRow ? -1 : p, room);
+        // append (the row has a line already)
+        st_tail = (int)(ry >> 16);
+        ry = (ry & 0xffffu) | (unsigned)l << 16;
+        rx = ((rx & 0xffu) + (unsigned)len) | (((rx >> 8) & 0xffu) + 1u) << 8 | ((rx >> 16) + (unsigned)itm) << 16;
+        rw |= fm;
+      } else {
+        rr = nrows++;
+        rx = (unsigned)len | 1u << 8 | (unsigned)itm << 16; ry = (unsigned)l | (unsigned)l << 16; rw = fm;
+      }
+      const int used = (int)(rx & 0xffu);
+      if (used < 16) {
+        // push: the row joins the list of its remaining room, at the tail
+        const int room2 = 16 - used;
+        const int t = RL(q_tail, room2);
+        rz = (unsigned)(t < 0 ? kNoRow : t) | (unsigned)kNoRow << 16;
+        st_t = t;
+        WL(q_and, t < 0 ? rw : ((unsigned)RL(q_and, room2) & rw), room2);
+        WL(q_tail, rr, room2);
+      } else rz = (unsigned)kNoRow | (unsigned)kNoRow << 16;
+      if (lane == 0) {
+        if (st_p >= 0) R[PH(st_p)].lnext = (uint16_t)st_pv;
+        if (st_n >= 0) R[PH(st_n)].lprev = (uint16_t)st_nv;
+        if (st_tail >= 0) NX[st_tail] = (uint16_t)l;
+        if (st_t >= 0) R[PH(st_t)].lnext = (uint16_t)rr;
+        uint4 v; v.x = rx; v.y = ry; v.z = rz; v.w = rw;
+        R4[PH(rr)] = v;
       }
     }
-    LDS_FENCE();
+  }
+  LDS_FENCE();
 #undef RL
 #undef WL
-    if (cur_cls == 0) { row1[0] = nrows; row0[1] = nrows; row1[1] = nrows; }
-    if (cur_cls == 1) row1[1] = nrows;
-    BUILD_STAMP(4);
-    // ---- to the next stage: the rows, the chains, the window's counts
-    LDS_FENCE();
+  if (lane == 0 && wave == 0) { s_rows0 = nrows; s_ntr = ntr; s_ntp = ntp; s_nbig = nbig; }
+  __syncthreads();
+  BUILD_STAMP(4);
+  // ---- to the next stage: the rows (class 1's behind class 0's, each in the order they were made), the chains, the window's counts
+  const int rows0 = s_rows0;
+  uint4* g_rows = P.mid_rows + r.line_off;
+  for (int q = lane; q < nrows; q += 64) g_rows[(wave ? rows0 : 0) + q] = R4[PH(q)];
+  uint16_t* g_next = P.mid_next + r.line_off;
+  for (int l = tid; l < L; l += 128) g_next[l] = NX[l];
+  if (lane == 0 && wave == 1) {
+    BuildMid& m = P.mid[w];
+    m.nrows = rows0 + nrows; m.ntr = s_ntr; m.ntp = s_ntp;
+    m.cls_row[0] = s_nbig; m.cls_row[1] = rows0; m.cls_row[2] = rows0; m.cls_row[3] = rows0 + nrows;
+  }
+#undef PH
 #undef LDS_FENCE
-    uint4* g_rows = P.mid_rows + r.line_off;
-    for (int q = lane; q < nrows; q += 64) g_rows[q] = reinterpret_cast<uint4*>(R)[q];
-    uint16_t* g_next = P.mid_next + r.line_off;
-    for (int l = lane; l < L; l += 64) g_next[l] = NX[l];
-    if (lane == 0) {
-      BuildMid& m = P.mid[w];
-      m.nrows = nrows; m.ntr = ntr; m.ntp = ntp; m.cls_row[0] = row0[0]; m.cls_row[1] = row1[0]; m.cls_row[2] = row0[1]; m.cls_row[3] = row1[1];
-    }
 #undef BUILD_STAMP
 }
 

@@ -1663,7 +1663,9 @@ __global__ __launch_bounds__(128) SLS_BACKSUB_OCC void k_backsub(BatchPtrs p, Po
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   SLS_K1_STAMP_INIT;
-  const Chunk ck = p.chunks[blockIdx.x];
+  // (experiment SLSLAM_DEBUG_ABLATE bit 15: the back-substitution walks the chunk array from its END - it then starts on the data the elimination
+  // sweep touched last, which the memory-side cache still holds)
+  const Chunk ck = p.chunks[(pol.debug_flags & 32768) ? gridDim.x - 1 - blockIdx.x : blockIdx.x];
   if (ck.win < 0) return;                              // an unused entry of a refillable batch's chunk array (lba_types.h)
   SLS_K1_WALL(28);
   const WinDesc wd = p.wins[ck.win];
