@@ -210,3 +210,90 @@ def test_stream_from_a_cxx_host(hip, tmp_path):
             off += x.size
             want_steps += s["num_successful_steps"] + s["num_unsuccessful_steps"]
     assert off == out.size and steps == want_steps
+
+
+def test_streamed_headline_path_matches_oracle_and_fresh_batches(hip, oracle):
+    """The path bench.py's `streamed` number runs, under the oracle: a depth-3 stream of five sets of 1024 windows of
+    2000 lines (synth.make_window(0 .. 1023), rotated so that every set is laid out differently) in page-locked arrays, DEFAULT options - so
+    the slots take the grouped matrix-core sweep (elimination 4) on the graded cut -3006, the refills are built on the DEVICE
+    (csrc/lba_device_build.h: copy-engine ingest, k_build_lines / _rows / _order / _layout / _tiles, k_permute_obs) and the results are written
+    in place.  Every window of every set equals, to the byte, the same window in a fresh batch built by the host packer; 16 windows of a
+    REFILLED set against oracle.lba_solve: identical accept / reject decisions at every iteration, summaries, and the deviation caps of
+    tests/test_gpu_lba.py::test_headline_path_matches_oracle."""
+    from test_gpu_lba import TIGHT, _assert_summary_parity, _assert_trace_parity
+    B = int(os.environ.get("SLSLAM_HEADLINE_WINDOWS", "1024"))
+    ws = [synth.make_window(i, num_lines=2000) for i in range(B)]
+    fresh = hip.LBABatch()
+    for w in ws:
+        fresh.add(w)
+    fresh.finalize()
+    assert fresh.elimination() == 4
+    fresh.solve(); fresh.download()
+    want = [fresh.parameters(i).copy() for i in range(B)]
+    want_sum = [fresh.summary(i) for i in range(B)]
+    cut = fresh.window_chunks(0)
+    fresh.close()
+    assert cut == -3006
+    nsets, depth = 5, 3
+    base = hip.WindowSet(ws, pinned=True)
+    rots = [(k * 37) % B for k in range(nsets)]
+    sets = [base.derive(list(range(r, B)) + list(range(r))) for r in rots]
+    st = hip.LBAStream(depth=depth, host_threads=1)
+    tickets, res = [], {}
+    views = {}
+    for k in range(nsets):
+        if k >= depth:
+            res[k - depth] = st.collect(tickets[k - depth])
+            views[k - depth] = None
+        tickets.append(st.submit(sets[k]))
+    for k in range(nsets - depth, nsets):
+        res[k] = st.collect(tickets[k])
+    ss, bs = st.stats(), st.build_stats()
+    assert ss["builds"] == depth and ss["refills"] == nsets - depth
+    assert bs["device_builds"] == nsets - depth and bs["zero_copy"] == nsets - depth and bs["fallback_windows"] == 0
+    # the batch that served the last (refilled) set: the headline's sweep and cut, traces for the oracle comparison
+    kk = nsets - 1
+    bv = st.batch_of(tickets[kk], sets[kk])
+    assert bv.elimination() == 4
+    # (the windows tests/test_gpu_lba.py::test_headline_path_matches_oracle holds against the oracle, every second one; position j of the set
+    # holds window (j + rotation) % B)
+    picks_i = sorted(set(int(round(x)) for x in np.linspace(0, B - 1, 32)))[::2]
+    picks = [(i - rots[kk]) % B for i in picks_i]
+    assert all(bv.window_chunks(j) == -3006 for j in picks)
+    traces = {j: bv.trace(j) for j in picks}
+    for k in range(nsets):
+        r = rots[k]
+        for j in range(B):
+            i = (j + r) % B                              # window i sits at position j of set k
+            assert np.array_equal(sets[k].parameters(j), want[i]), "set %d position %d (window %d)" % (k, j, i)
+            assert res[k][j] == want_sum[i]
+    CAP = dict(cost=1e-6, radius=5e-5, step_norm=3e-4, rho=1e-3, cam=3e-9, line=1.5e-3)
+    beyond, rejected = 0, 0
+    for j in picks:
+        i = (j + rots[kk]) % B
+        w = ws[i]
+        x0, s0, t0 = oracle.lba_solve(w, linear_solver=1)
+        x1, s1, t1 = sets[kk].parameters(j), res[kk][j], traces[j]
+        assert len(t0) == len(t1)
+        for a, c in zip(t0, t1):
+            assert a["iteration"] == c["iteration"] and a["step_is_successful"] == c["step_is_successful"] and a["step_is_valid"] == c["step_is_valid"]
+        _assert_trace_parity(t0, t1, n=2)
+        _assert_summary_parity(s0, s1)
+        rejected += s1["num_unsuccessful_steps"]
+        nc = 6 * int(w["num_cameras"])
+        d = dict(cost=0.0, radius=0.0, step_norm=0.0, rho=0.0)
+        for a, c in zip(t0, t1):
+            d["cost"] = max(d["cost"], abs(a["cost"] - c["cost"]) / abs(a["cost"]))
+            d["radius"] = max(d["radius"], abs(a["trust_region_radius"] - c["trust_region_radius"]) / a["trust_region_radius"])
+            d["step_norm"] = max(d["step_norm"], abs(a["step_norm"] - c["step_norm"]) / (a["step_norm"] + 1e-12))
+            d["rho"] = max(d["rho"], abs(a["relative_decrease"] - c["relative_decrease"]) / (abs(a["relative_decrease"]) + 1e-3))
+        d["cam"] = float(np.abs(x0[:nc] - x1[:nc]).max())
+        d["line"] = float(np.abs(x0[nc:] - x1[nc:]).max())
+        for q in CAP:
+            assert d[q] <= CAP[q], (i, q, d[q])
+        beyond += any(d[q] > TIGHT[q] for q in TIGHT)
+    assert beyond <= len(picks) // 4 and rejected > 0
+    st.close()
+    for s_ in sets:
+        s_.close()
+    base.close()
