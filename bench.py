@@ -853,7 +853,39 @@ def main():
                 for W, mt in ((5, 8.4), (10, 16.5), (20, 32.0), (40, 61.0))}
             if not args.no_cpu_baseline:
                 out["config5_pose_graph"] = pose_graph_block()
-        print(json.dumps(out))
+        if world == 1:
+            print(json.dumps(out))
+    if world > 1:
+        # ---- BASELINE config 4 as it reads - a STREAM of windows sharded over the GPUs: every rank streams its shard of every set through a
+        # stream object of its own (page-locked arrays, the build stage on the device, results in place), host threads = the quota's share
+        sb = None
+        if not args.no_streamed and ns == 1:
+            resident_params = {}
+            for bt in batches:
+                bt.close()
+            batches = []
+            quota = host_cpu_info().get("cgroup_cpu_quota") or os.cpu_count() or 1
+            ht = args.host_threads or max(1, min(2, int(quota) // world))
+            dist.barrier()
+            try:
+                sb = streamed_block(windows, local_rank, (iters_total / elapsed) / world, resident_params, batches_timed=args.stream_batches,
+                                    host_threads=ht, mode="pinned", depth=args.stream_depth, chunks_per_window=args.chunks, lba_elimination=args.elim,
+                                    lba_keep_jacobian=args.keep_jacobian)
+            except capi.SlslamError as e:
+                sb = {"error": str(e)}
+            allsb = [None] * world
+            dist.all_gather_object(allsb, sb)
+            if rank == 0:
+                good = [x for x in allsb if x and "error" not in x]
+                keep = ("value", "fraction_of_resident", "host_threads", "steady_ms_per_batch", "ms_per_batch", "device_builds", "zero_copy_batches",
+                        "windows_handed_to_the_host_path", "ms_per_batch_in_submit")
+                out["streamed"] = {"value": sum(x["value"] for x in good), "unit": "LM iterations/s",
+                                   "fraction_of_resident": sum(x["value"] for x in good) / out["value"] if good else None,
+                                   "host_threads_per_rank": ht, "ranks": len(good), "mode": "pinned",
+                                   "per_rank": [({k: x.get(k) for k in keep} if x and "error" not in x else x) for x in allsb],
+                                   "timed_region": good[0]["timed_region"] if good else None}
+        if rank == 0:
+            print(json.dumps(out))
     for bt in batches:
         bt.close()
     if world > 1:

@@ -46,6 +46,20 @@ int  slslam_dist_solve(slslam_dist* d, const slslam_lba_window* my_windows, int 
 /* Test hook: the next slslam_dist_solve on this rank solves its shard and then reports it as failed (exercises the path above). */
 int  slslam_dist_debug_fail_next_shard(slslam_dist* d);
 
+/* ---- the STREAMED form: a stream of sets of windows, every set sharded over the ranks (BASELINE config 4: "many independent 10-KF
+ * windows sharded across 8 MI355X").  Every rank drives a slslam_lba_stream over ITS shard of every set - `depth` refillable batches in
+ * flight, the LBAProblem::build stage on the device when the windows' arrays are page-locked (slslam_pinned_alloc), results written in
+ * place - and the ranks meet once per set: collect() is the one ncclAllReduce of the three sums of reference src/slam.cpp:949-952 over
+ * the whole set (sums[0] LM iterations, sums[1] initial cost, sums[2] final cost).  Replaces, per set and rank, the loop over
+ * LBAProblem::build + ceres::Solve (src/slam.cpp:924-944) of the shard.  submit() is local (no collective); collect() is collective:
+ * every rank calls it once per set, in the order of the submits, with the ticket its submit returned (-1 if its submit failed: the rank
+ * still enters the all-reduce, and every rank returns an error for that set). */
+typedef struct slslam_dist_stream slslam_dist_stream;
+int  slslam_dist_stream_create(slslam_dist* d, const slslam_solver_options* opt, int depth, slslam_dist_stream** out);
+void slslam_dist_stream_destroy(slslam_dist_stream* s);
+int  slslam_dist_stream_submit(slslam_dist_stream* s, const slslam_lba_window* my_windows, int n_mine, int* ticket);
+int  slslam_dist_stream_collect(slslam_dist_stream* s, int ticket, double sums[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -183,5 +184,75 @@ extern "C" int slslam_dist_solve(slslam_dist* d, const slslam_lba_window* w, int
 extern "C" int slslam_dist_debug_fail_next_shard(slslam_dist* d) {
   if (!d) return SLSLAM_ERR_INVALID_ARGUMENT;
   d->fail_next_shard = 1;
+  return SLSLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// The STREAMED form of the fan-out (BASELINE config 4 as it reads: a stream of windows sharded over the GPUs of a node): every rank owns a
+// stream object (slslam_lba_stream_*: refillable batches in flight, the build stage on the device when the caller's arrays are page-locked)
+// over its shard of every set; what the ranks exchange per set is the ONE all-reduce of the three sums the reference's caller accumulates
+// (src/slam.cpp:949-952) plus the count of ranks whose shard failed.
+struct slslam_dist_stream {
+  slslam_dist* d = nullptr;
+  slslam_lba_stream* st = nullptr;
+  int depth = 0;
+  std::vector<int> n_of_ticket;            // windows of the shard behind each ticket in flight (by slot)
+  std::vector<slslam_summary> summaries;
+};
+
+extern "C" int slslam_dist_stream_create(slslam_dist* d, const slslam_solver_options* opt, int depth, slslam_dist_stream** out) {
+  if (!d || !out) return SLSLAM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  slslam_dist_stream* s = new (std::nothrow) slslam_dist_stream();
+  if (!s) return SLSLAM_ERR_NO_MEMORY;
+  s->d = d; s->depth = depth;
+  const int rc = slslam_lba_stream_create(d->device, opt, depth, &s->st);
+  if (rc != SLSLAM_OK) { delete s; return rc; }
+  s->n_of_ticket.assign((size_t)depth, 0);
+  *out = s;
+  return SLSLAM_OK;
+}
+
+extern "C" void slslam_dist_stream_destroy(slslam_dist_stream* s) {
+  if (!s) return;
+  if (s->st) slslam_lba_stream_destroy(s->st);
+  delete s;
+}
+
+extern "C" int slslam_dist_stream_submit(slslam_dist_stream* s, const slslam_lba_window* my_windows, int n_mine, int* ticket) {
+  if (!s || !ticket) return SLSLAM_ERR_INVALID_ARGUMENT;
+  // no collective here: a rank whose submit fails reports it at collect time (ticket -1 is accepted there), so that the ranks stay in step
+  int t = -1;
+  const int rc = slslam_lba_stream_submit(s->st, my_windows, n_mine, &t);
+  *ticket = rc == SLSLAM_OK ? t : -1;
+  if (rc == SLSLAM_OK) s->n_of_ticket[(size_t)(t % s->depth)] = n_mine;
+  return rc;
+}
+
+extern "C" int slslam_dist_stream_collect(slslam_dist_stream* s, int ticket, double sums[3]) {
+  if (!s || !sums) return SLSLAM_ERR_INVALID_ARGUMENT;
+  slslam_dist* d = s->d;
+  DIST_HIP(hipSetDevice(d->device));
+  double local[4] = { 0.0, 0.0, 0.0, 0.0 };
+  int rc = ticket < 0 ? SLSLAM_ERR_STATE : SLSLAM_OK;      // (this rank's submit had failed: it still enters the all-reduce)
+  if (rc == SLSLAM_OK) {
+    const int n = s->n_of_ticket[(size_t)(ticket % s->depth)];
+    s->summaries.resize((size_t)std::max(1, n));
+    rc = slslam_lba_stream_collect(s->st, ticket, s->summaries.data());
+    for (int i = 0; i < n && rc == SLSLAM_OK; ++i) {
+      local[0] += s->summaries[(size_t)i].num_successful_steps + s->summaries[(size_t)i].num_unsuccessful_steps;
+      local[1] += s->summaries[(size_t)i].initial_cost; local[2] += s->summaries[(size_t)i].final_cost;
+    }
+  }
+  if (d->fail_next_shard) { d->fail_next_shard = 0; if (rc == SLSLAM_OK) rc = SLSLAM_ERR_HIP; }
+  if (rc != SLSLAM_OK) { local[0] = local[1] = local[2] = 0.0; local[3] = 1.0; }
+  hipError_t e = hipMemcpyAsync(d->d_sums, local, sizeof(local), hipMemcpyHostToDevice, d->stream);
+  if (e != hipSuccess && rc == SLSLAM_OK) rc = SLSLAM_ERR_HIP;
+  double total[4] = { 0.0, 0.0, 0.0, 0.0 };
+  DIST_NCCL(ncclAllReduce(d->d_sums, d->d_sums, 4, ncclDouble, ncclSum, d->comm, d->stream));
+  DIST_HIP(hipMemcpyAsync(total, d->d_sums, sizeof(total), hipMemcpyDeviceToHost, d->stream));
+  DIST_HIP(hipStreamSynchronize(d->stream));
+  sums[0] = total[0]; sums[1] = total[1]; sums[2] = total[2];
+  if (total[3] > 0.5) return rc != SLSLAM_OK ? rc : SLSLAM_ERR_STATE;      // some rank's shard failed: every rank says so
   return SLSLAM_OK;
 }

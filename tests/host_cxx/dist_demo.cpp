@@ -9,6 +9,7 @@
 // What is fanned out is the reference's per-window call LBAProblem::build + ceres::Solve (src/slam.cpp:924-944); the sums are the ones
 // its caller accumulates at :949-952.
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -78,10 +79,11 @@ int main(int argc, char** argv) {
   double sums[3] = { 0, 0, 0 };
   std::vector<double> gathered((size_t)slot * (size_t)world, 0.0);
   std::vector<long long> counts((size_t)world, 0);
-  if (argc > 7 && std::atoi(argv[7]) == 1 && !mine.empty()) {
-    std::vector<std::vector<double>> keep;
-    for (const slslam_lba_window& m : mine) keep.emplace_back(m.parameters, m.parameters + 6 * m.num_cameras + 4 * m.num_lines);
-    auto restore = [&] { for (size_t i = 0; i < mine.size(); ++i) std::memcpy(mine[i].parameters, keep[i].data(), keep[i].size() * sizeof(double)); };
+  std::vector<std::vector<double>> keep;
+  for (const slslam_lba_window& m : mine) keep.emplace_back(m.parameters, m.parameters + 6 * m.num_cameras + 4 * m.num_lines);
+  auto restore = [&] { for (size_t i = 0; i < mine.size(); ++i) std::memcpy(mine[i].parameters, keep[i].data(), keep[i].size() * sizeof(double)); };
+  const bool inject = argc > 7 && std::atoi(argv[7]) == 1 && !mine.empty();
+  if (inject) {
     slslam_dist_debug_fail_next_shard(d);
     const int r1 = slslam_dist_solve(d, mine.data(), (int)mine.size(), &opt, sums, gathered.data(), slot, counts.data());
     restore();
@@ -105,6 +107,55 @@ int main(int argc, char** argv) {
     for (long long c : counts) { const double v = (double)c; fwrite(&v, 8, 1, o); }
     fwrite(gathered.data(), 8, gathered.size(), o);
     std::fclose(o);
+  }
+  if (inject && rc == SLSLAM_OK) {
+    // the STREAMED form (slslam_dist_stream_*): the same shard three times through a depth-2 stream, the arrays in page-locked memory so that the
+    // second and third set are read by the GPU in place and built on the device; every set's all-reduced sums and solved parameters must be
+    // those of the batch call above
+    std::vector<std::vector<double>> solved;
+    for (const slslam_lba_window& m : mine) solved.emplace_back(m.parameters, m.parameters + 6 * m.num_cameras + 4 * m.num_lines);
+    size_t need = 4096;
+    for (const slslam_lba_window& m : mine) need += 80 * (size_t)m.num_observations + 8 * (6 * (size_t)m.num_cameras + 4 * (size_t)m.num_lines) + 5 * 64;
+    char* arena = nullptr;
+    int prc = slslam_pinned_alloc(3 * need, (void**)&arena);
+    if (prc != SLSLAM_OK) { std::fprintf(stderr, "rank %d: pinned alloc: %s\n", rank, slslam_status_string(prc)); return prc; }
+    size_t off = 0;
+    auto take = [&](const void* src, size_t bytes) { char* p = arena + off; std::memcpy(p, src, bytes); off += (bytes + 63) & ~(size_t)63; return (void*)p; };
+    std::vector<std::vector<slslam_lba_window>> sets(3);
+    for (int k = 0; k < 3; ++k)
+      for (size_t i = 0; i < mine.size(); ++i) {
+        const slslam_lba_window& m = mine[(i + (size_t)k) % mine.size()];          // another order in every set
+        const size_t M = (size_t)m.num_observations, np = 6 * (size_t)m.num_cameras + 4 * (size_t)m.num_lines;
+        slslam_lba_window c = m;
+        c.camera_index = (const int*)take(m.camera_index, 4 * M); c.line_index = (const int*)take(m.line_index, 4 * M);
+        c.fixed_index = (const int*)take(m.fixed_index, 8 * M); c.observations = (const double*)take(m.observations, 64 * M);
+        c.parameters = (double*)take(keep[(i + (size_t)k) % mine.size()].data(), 8 * np);
+        sets[(size_t)k].push_back(c);
+      }
+    slslam_dist_stream* ds = nullptr;
+    int src = slslam_dist_stream_create(d, &opt, 2, &ds);
+    int tk[3] = { -1, -1, -1 };
+    double ssum[3][3];
+    for (int k = 0; k < 3 && src == SLSLAM_OK; ++k) {
+      if (k >= 2) src = slslam_dist_stream_collect(ds, tk[k - 2], ssum[k - 2]);
+      if (src == SLSLAM_OK) src = slslam_dist_stream_submit(ds, sets[(size_t)k].data(), (int)sets[(size_t)k].size(), &tk[k]);
+    }
+    for (int k = 1; k < 3 && src == SLSLAM_OK; ++k) src = slslam_dist_stream_collect(ds, tk[k], ssum[k]);
+    if (src != SLSLAM_OK) { std::fprintf(stderr, "rank %d: dist stream: %s\n", rank, slslam_status_string(src)); return src; }
+    long long dev_builds = 0, zero_copy = 0, fallbacks = 0;
+    bool same = true;
+    for (int k = 0; k < 3; ++k) {
+      same = same && ssum[k][0] == sums[0] && std::fabs(ssum[k][1] - sums[1]) <= 1e-12 * sums[1] && std::fabs(ssum[k][2] - sums[2]) <= 1e-12 * sums[2];
+      for (size_t i = 0; i < mine.size(); ++i) {
+        const std::vector<double>& wnt = solved[(i + (size_t)k) % mine.size()];
+        same = same && std::memcmp(sets[(size_t)k][i].parameters, wnt.data(), wnt.size() * sizeof(double)) == 0;
+      }
+    }
+    slslam_dist_stream_destroy(ds);
+    (void)slslam_pinned_free(arena);
+    (void)dev_builds; (void)zero_copy; (void)fallbacks;
+    if (!same) { std::fprintf(stderr, "rank %d: streamed sets differ from the batch call\n", rank); return 4; }
+    std::printf("rank %d: streamed fan-out ok (3 sets through slslam_dist_stream, sums and parameters equal to the batch call)\n", rank);
   }
   slslam_dist_destroy(d);
   return rc;

@@ -114,7 +114,7 @@ def test_bench_two_ranks_shared_gpu(hip):
     windows, lines = 24, 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--windows", str(windows), "--lines", str(lines), "--no-cpu-baseline", "--no-overlap-run", "--no-extra-configs"]
+           "--windows", str(windows), "--lines", str(lines), "--no-cpu-baseline", "--no-overlap-run", "--no-extra-configs", "--stream-batches", "6"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -122,6 +122,13 @@ def test_bench_two_ranks_shared_gpu(hip):
     assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["collective_backend"] == "gloo"
     assert len(d["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in d["per_rank_ms_per_step"])
     assert d["config"]["total_windows"] == 2 * windows and d["scaling"] == "weak"
+    #  the STREAMED leg runs on every rank - its shard of every set through a stream object of its own, page-locked
+    # arrays, refills built on the device, host threads = the CPU quota's share - and the line carries the per-rank blocks
+    sb = d["streamed"]
+    assert sb["ranks"] == 2 and len(sb["per_rank"]) == 2 and sb["host_threads_per_rank"] <= 2
+    for x in sb["per_rank"]:
+        assert x["value"] > 0 and x["device_builds"] == 6 and x["zero_copy_batches"] == 6 and x["windows_handed_to_the_host_path"] == 0
+    assert abs(sb["value"] - sum(x["value"] for x in sb["per_rank"])) <= 1e-6 * sb["value"]
     chk = d["results_check"]
     ids = chk["window_ids"]
     assert min(ids) == 0 and max(ids) >= windows and len(ids) == 2 * chk["checked_per_rank"]      # both shards: [0, 24) and [24, 48)
@@ -159,6 +166,9 @@ def test_c_level_fan_out_through_rccl(tmp_path):
     #  a failing shard - injected, and a malformed window - still enters the all-reduce, every rank gets an error,
     # nobody enters the all-gather, and the communicator serves the real solve below
     assert "error paths ok" in p.stdout, p.stdout + p.stderr
+    # the streamed form (slslam_dist_stream_*): the shard three times through a depth-2 stream from page-locked arrays - refills built on the
+    # device - with the per-set all-reduce; sums and parameters equal to the batch call
+    assert "streamed fan-out ok" in p.stdout, p.stdout + p.stderr
     out = np.fromfile(tmp_path / "out.bin")
     sums, slot, count = out[:3], int(out[3]), int(out[4])
     gathered = out[5:5 + slot]

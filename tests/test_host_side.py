@@ -628,7 +628,8 @@ def test_dist_library_exports_every_declared_symbol():
     L = C.CDLL(os.path.join(ROOT, "slslam_amd", "_lib", "libslslam_dist.so"))
     names = _declared_functions("slslam_dist.h")
     assert names == ["slslam_dist_create", "slslam_dist_debug_fail_next_shard", "slslam_dist_destroy", "slslam_dist_rank", "slslam_dist_shard_range",
-                     "slslam_dist_solve", "slslam_dist_unique_id", "slslam_dist_world"]
+                     "slslam_dist_solve", "slslam_dist_stream_collect", "slslam_dist_stream_create", "slslam_dist_stream_destroy", "slslam_dist_stream_submit",
+                     "slslam_dist_unique_id", "slslam_dist_world"]
     for n in names:
         assert hasattr(L, n), "include/slslam_dist.h declares %s but libslslam_dist.so does not export it" % n
     L.slslam_dist_shard_range.argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
