@@ -312,6 +312,8 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
     callers' arrays - `depth` batches in flight (slslam_lba_stream_*).  mode:
       "pinned"   the caller's arrays live in page-locked memory (slslam_pinned_alloc): the GPU reads them in place, builds the batch on the
                  device (csrc/lba_device_build.h) and writes the solved parameters back in place - no host thread touches the data;
+      "packed"   as "pinned", and the caller's packer writes the three index arrays narrowed to one 32-bit word per observation
+                 (slslam_pack_indices / slslam_lba_stream_submit_packed): 68 instead of 80 bytes per observation over the link;
       "pageable" ordinary arrays: the host threads copy them into a pinned staging buffer (indices narrowed on the way), the device builds;
       "host"     the round-5 path (device_build = -1): packing on the host threads, pinned image, upload, download, copy-out.
     Every batch is a set of host arrays over the rank's windows, rotated so that every batch is laid out differently (the read-only input
@@ -319,7 +321,7 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
     capture, pinned allocations) are warm-up.  Never the headline `value`: it measures the host, the host link and the GPU together."""
     B = len(windows)
     nsets = depth + 1 + batches_timed
-    base = capi.WindowSet(windows, pinned=(mode == "pinned"))
+    base = capi.WindowSet(windows, pinned=(mode in ("pinned", "packed")), packed=(mode == "packed"))
     sets = []
     for k in range(nsets):
         r = (k * 37) % B
@@ -363,7 +365,7 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
             equal = equal and bool(np.array_equal(sets[k].parameters(j), resident_params[i]))
     m = sum(len(w["camera_index"]) for w in windows)
     npar = sum(8 * (6 * w["num_cameras"] + 4 * w["num_lines"]) for w in windows)
-    link_in = {"pinned": 80 * m + npar, "pageable": 68 * m + npar}.get(mode)
+    link_in = {"pinned": 80 * m + npar, "packed": 68 * m + npar, "pageable": 68 * m + npar}.get(mode)
     if link_in is None:
         link_in = 8 * 8 * m + 4 * 2 * m + npar + sum(40 * w["num_lines"] for w in windows)
     out = {"value": its / dt, "unit": "LM iterations/s", "fraction_of_resident": (its / dt) / resident_value if resident_value else None,
@@ -379,7 +381,8 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
            "ms_per_batch_copying_results_out": (s1["ms_collect_copy"] - s0["ms_collect_copy"]) / batches_timed,
            "host_link_in_MB_per_batch": link_in / 1e6, "host_link_out_MB_per_batch": npar / 1e6, "lm_iterations": its,
            "bitwise_equal_to_resident_batch": equal if checked else None, "windows_compared": checked,
-           "timed_region": {"pinned": "per batch: zero-copy ingest from the callers' page-locked arrays + build on the device + hipGraph solve + results written in place, %d batches in flight",
+           "timed_region": {"pinned": "per batch: copy-engine ingest of the callers' page-locked arrays + build on the device + hipGraph solve + results written in place, %d batches in flight",
+                            "packed": "as pinned, the indices narrowed by the caller (one 32-bit word per observation), %d batches in flight",
                             "pageable": "per batch: staging copy (host threads, indices narrowed) + ingest + build on the device + hipGraph solve + D2H + copy-out, %d batches in flight",
                             "host": "per batch: pack (host threads) + pinned H2D + hipGraph solve + D2H + copy-out into the callers' arrays, %d batches in flight"}[mode] % depth}
     st.close()
@@ -479,7 +482,7 @@ def pose_graph_block():
 def order_line(out):
     """The driver's record keeps the contract keys, `roofline`, `cpu_baseline` and the last ~2 KB of the line: the streamed figures (BASELINE
     config 4, the product's end-to-end rate) go LAST, compact, so that they are in it."""
-    tail = ["streamed_host_packer", "streamed_pageable", "streamed"]
+    tail = ["streamed_host_packer", "streamed_pageable", "streamed_packed_indices", "streamed"]
     keep = ("value", "unit", "fraction_of_resident", "host_threads", "host_threads_per_rank", "ranks", "mode", "steady_value", "steady_ms_per_batch", "ms_per_batch",
             "batches_timed", "windows_per_batch", "depth", "device_builds", "zero_copy_batches", "windows_handed_to_the_host_path", "ms_per_batch_in_submit",
             "host_link_in_MB_per_batch", "bitwise_equal_to_resident_batch", "per_rank", "error")
@@ -816,6 +819,9 @@ def main():
                 out["streamed"] = {"error": str(e)}
             if not args.no_extra_configs:
                 try:
+                    # the caller's packer narrows the indices (68 instead of 80 bytes per observation over the link)
+                    out["streamed_packed_indices"] = streamed_block(windows, local_rank, out["value"], resident_params, batches_timed=args.stream_batches,
+                                                                    host_threads=args.host_threads or 1, mode="packed", **sopt)
                     # ordinary (pageable) arrays: the staging copy on TWO host threads, the build on the device
                     out["streamed_pageable"] = streamed_block(windows, local_rank, out["value"], resident_params, batches_timed=max(6, args.stream_batches // 2),
                                                               host_threads=args.host_threads or 2, mode="pageable", **sopt)

@@ -309,6 +309,11 @@ int  slslam_lba_stream_create(int device, const slslam_solver_options* opt, int 
 void slslam_lba_stream_destroy(slslam_lba_stream* s);
 int  slslam_lba_stream_submit(slslam_lba_stream* s, const slslam_lba_window* windows, int n, int* ticket);
 int  slslam_lba_stream_collect(slslam_lba_stream* s, int ticket, slslam_summary* summaries);
+/* submit() for a caller whose packer writes the indices NARROWED: packed_index[i] (when not NULL) replaces window i's camera_index /
+ * line_index / fixed_index by one 32-bit word per observation (slslam_pack_indices: what the loop at reference src/slam.cpp:904-912 would
+ * store instead of four ints) - 68 instead of 80 bytes per observation over the host link, which is what a stream of windows is bound
+ * by.  The words are validated on the device (or by the staging copy); everything else as submit(). */
+int  slslam_lba_stream_submit_packed(slslam_lba_stream* s, const slslam_lba_window* windows, const unsigned int* const* packed_index, int n, int* ticket);
 /* Host-side accounting since create: wall-clock ms the caller spent in submit (pack + layout + enqueue), waiting in collect, copying
  * results out; submits served by a refill / by building a batch; windows submitted; trust-region steps (successful + unsuccessful, the
  * count of reference src/slam.cpp:949-950) of the windows collected; host threads in use.  Any pointer may be NULL. */

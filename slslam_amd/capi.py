@@ -83,7 +83,7 @@ EXPORTS = [
     "slslam_lba_batch_add", "slslam_lba_batch_finalize", "slslam_lba_batch_solve", "slslam_lba_batch_reset",
     "slslam_lba_batch_download", "slslam_lba_batch_download_async", "slslam_lba_batch_wait", "slslam_lba_batch_refill",
     "slslam_lba_stream_create", "slslam_lba_stream_destroy", "slslam_lba_stream_submit", "slslam_lba_stream_collect", "slslam_lba_stream_stats",
-    "slslam_lba_stream_build_stats", "slslam_lba_stream_batch", "slslam_pinned_alloc", "slslam_pinned_free", "slslam_pinned_register", "slslam_pinned_unregister",
+    "slslam_lba_stream_build_stats", "slslam_lba_stream_batch", "slslam_lba_stream_submit_packed", "slslam_pinned_alloc", "slslam_pinned_free", "slslam_pinned_register", "slslam_pinned_unregister",
     "slslam_pinned_contains", "slslam_pack_indices", "slslam_debug_device_pack", "slslam_debug_device_pack_timed",
     "slslam_lba_batch_get_parameters", "slslam_lba_batch_get_summary",
     "slslam_lba_batch_get_trace", "slslam_lba_batch_export_device", "slslam_lba_batch_counts", "slslam_lba_batch_window_chunks", "slslam_lba_batch_path", "slslam_lba_batch_elimination",
@@ -127,6 +127,7 @@ def lib():
     L.slslam_lba_stream_collect.argtypes = [vp, C.c_int, C.POINTER(Summary)]
     L.slslam_lba_stream_stats.argtypes = [vp, dp, dp, dp] + [C.POINTER(C.c_longlong)] * 4 + [ip]
     L.slslam_lba_stream_build_stats.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 3
+    L.slslam_lba_stream_submit_packed.argtypes = [vp, C.POINTER(LBAWindow), C.POINTER(C.POINTER(C.c_uint)), C.c_int, ip]
     L.slslam_lba_stream_batch.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.slslam_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.slslam_pinned_free.argtypes = [vp]
@@ -261,6 +262,7 @@ class _WindowArrays:
         self.params = np.array(w["parameters"] if params is None else params, dtype=np.float64).reshape(-1).copy()
         if arena is not None:
             self.cam, self.line, self.fixed, self.obs = (arena.take(x) for x in (self.cam, self.line, self.fixed, self.obs))
+        if params_arena is not None or arena is not None:
             self.params = (params_arena or arena).take(self.params)
         m = len(self.cam)
         if len(self.line) != m or len(self.fixed) != 2 * m or len(self.obs) != 8 * m:
@@ -408,16 +410,32 @@ class WindowSet:
     """A C array of slslam_lba_window over numpy buffers that stay alive with it (what a caller of the stream / refill entry points
     holds: the five arrays of every window, reference src/slam.cpp:899-921)."""
 
-    def __init__(self, windows, pinned=False):
-        """pinned: the arrays live in ONE page-locked block (slslam_pinned_alloc): the device build reads them in place (zero copy) and the
-        solved parameters are written back into them by the GPU."""
+    def __init__(self, windows, pinned=False, packed=False):
+        """pinned: the arrays live in page-locked blocks (slslam_pinned_alloc): the device build reads them in place and the solved
+        parameters are written back into them by the GPU.  packed: the three index arrays of every window are ALSO held narrowed to one
+        32-bit word per observation (slslam_pack_indices), and LBAStream.submit hands those over instead (slslam_lba_stream_submit_packed)."""
         self.arena = self.params_arena = None
+        self.packed = None
         if pinned:
             # the read-only arrays of all windows in one block, the parameter arrays in another (derive() gives a set parameter arrays of its
             # own over the same inputs): arrays that lie next to each other go up in a few large copies
             self.arena = PinnedArena(sum(80 * len(w["camera_index"]) + 4 * 64 for w in windows) + 4096)
             self.params_arena = PinnedArena(sum(8 * (6 * int(w["num_cameras"]) + 4 * int(w["num_lines"])) + 64 for w in windows) + 4096)
-        self.arrays = [_WindowArrays(w, arena=self.arena, params_arena=self.params_arena) for w in windows]
+        if pinned and packed:
+            self.arena.close()
+            self.arena = PinnedArena(sum(68 * len(w["camera_index"]) + 2 * 64 for w in windows) + 4096)
+        self.arrays = [_WindowArrays(w, arena=None if packed else self.arena, params_arena=self.params_arena) for w in windows]
+        if packed:
+            self.packed_arrays = []
+            for a in self.arrays:
+                pk = np.zeros(len(a.cam), dtype=np.uint32)
+                _check(lib().slslam_pack_indices(len(a.cam), _ip(a.cam), _ip(a.line), _ip(a.fixed), pk.ctypes.data_as(C.POINTER(C.c_uint))), "slslam_pack_indices")
+                if self.arena is not None:
+                    pk = self.arena.take(pk)
+                    a.obs = self.arena.take(a.obs)
+                    a.c = LBAWindow(a.c.num_cameras, a.c.num_lines, a.c.num_observations, _ip(a.cam), _ip(a.line), _ip(a.fixed), _dp(a.obs), _dp(a.params))
+                self.packed_arrays.append(pk)
+            self.packed = (C.POINTER(C.c_uint) * max(len(self.arrays), 1))(*[p_.ctypes.data_as(C.POINTER(C.c_uint)) for p_ in self.packed_arrays])
         self.c = (LBAWindow * max(len(self.arrays), 1))(*[a.c for a in self.arrays])
         self.sizes = [(int(w["num_cameras"]), int(w["num_lines"])) for w in windows]
 
@@ -434,6 +452,10 @@ class WindowSet:
         import copy
         out = WindowSet.__new__(WindowSet)
         out.arena = out.params_arena = None
+        out.packed = None
+        if self.packed is not None:
+            out.packed_arrays = [self.packed_arrays[j] for j in order]
+            out.packed = (C.POINTER(C.c_uint) * max(len(order), 1))(*[p_.ctypes.data_as(C.POINTER(C.c_uint)) for p_ in out.packed_arrays])
         if self.arena is not None:
             out.params_arena = PinnedArena(sum(a.params.nbytes + 64 for a in self.arrays) + 4096)
         out.arrays = []
@@ -515,7 +537,10 @@ class LBAStream:
 
     def submit(self, ws):
         t = C.c_int(-1)
-        _check(lib().slslam_lba_stream_submit(self._h, ws.c, len(ws), C.byref(t)), "slslam_lba_stream_submit")
+        if getattr(ws, "packed", None) is not None:
+            _check(lib().slslam_lba_stream_submit_packed(self._h, ws.c, ws.packed, len(ws), C.byref(t)), "slslam_lba_stream_submit_packed")
+        else:
+            _check(lib().slslam_lba_stream_submit(self._h, ws.c, len(ws), C.byref(t)), "slslam_lba_stream_submit")
         self._live[t.value] = ws
         return t.value
 

@@ -1566,7 +1566,9 @@ unsigned long long copy_checked(double* dst, const double* src, size_t n) {
 // and ONE solve stream to all its slots, so that batch k + 1 crosses the link while batch k is solved and neither shares its resource
 // (batches that ingest and solve at the same time on streams of their own fall into step: three ingests share the link, then three
 // solves share the chip - measured 37 ms per batch against 20).
-int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, hipStream_t s, hipStream_t s_in) {
+// packed (optional): packed[i] != nullptr replaces window i's three index arrays by the narrowed form (slslam_pack_indices: one 32-bit word per
+// observation) - 68 instead of 80 bytes per observation over the host link.
+int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, hipStream_t s, hipStream_t s_in, const unsigned int* const* packed = nullptr) {
   if (b->opt.device_build < 0 || b->d_rawwin.n < (size_t)std::max(1, B) || !b->d_ob_raw.p) return SLSLAM_ERR_UNSUPPORTED;
   if (std::getenv("SLSLAM_CHUNK_WEIGHTS")) return SLSLAM_ERR_UNSUPPORTED;          // (an experiment knob of the host-side cut)
   static const bool timing = std::getenv("SLSLAM_REFILL_TIMING") != nullptr;
@@ -1578,7 +1580,8 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
   for (int i = 0; i < B; ++i) {
     const slslam_lba_window& w = windows[i];
     if (w.num_cameras < 0 || w.num_lines < 0 || w.num_observations < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
-    if (w.num_observations > 0 && (!w.camera_index || !w.line_index || !w.fixed_index || !w.observations)) return SLSLAM_ERR_INVALID_ARGUMENT;
+    const bool pk = packed && packed[i];
+    if (w.num_observations > 0 && ((!pk && (!w.camera_index || !w.line_index || !w.fixed_index)) || !w.observations)) return SLSLAM_ERR_INVALID_ARGUMENT;
     if ((w.num_cameras > 0 || w.num_lines > 0) && !w.parameters) return SLSLAM_ERR_INVALID_ARGUMENT;
     if (w.num_cameras > kMaxCams || w.num_lines > 0xfffe || w.num_observations >= (1 << 24)) return SLSLAM_ERR_UNSUPPORTED;
     maxL = std::max(maxL, w.num_lines); maxM = std::max(maxM, w.num_observations); maxC = std::max(maxC, w.num_cameras);
@@ -1604,8 +1607,10 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
       const slslam_lba_window& w = windows[i];
       const size_t M = (size_t)w.num_observations, np = (size_t)6 * w.num_cameras + (size_t)4 * w.num_lines;
       if (np && !PinnedRegistry::contains(rs, w.parameters, 8 * np)) { params_pinned = false; all_pinned = false; }
-      if (M && all_pinned && !(PinnedRegistry::contains(rs, w.camera_index, 4 * M) && PinnedRegistry::contains(rs, w.line_index, 4 * M) &&
-                               PinnedRegistry::contains(rs, w.fixed_index, 8 * M) && PinnedRegistry::contains(rs, w.observations, 64 * M)))
+      const bool pk = packed && packed[i];
+      if (M && all_pinned && !((pk ? PinnedRegistry::contains(rs, packed[i], 4 * M)
+                                   : (PinnedRegistry::contains(rs, w.camera_index, 4 * M) && PinnedRegistry::contains(rs, w.line_index, 4 * M) && PinnedRegistry::contains(rs, w.fixed_index, 8 * M))) &&
+                               PinnedRegistry::contains(rs, w.observations, 64 * M)))
         all_pinned = false;
     }
   }
@@ -1624,7 +1629,9 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
     for (int i = 0; i < B; ++i) {
       const slslam_lba_window& w = windows[i];
       RawWin& r = b->host_src[(size_t)i];
-      r.cam = w.camera_index; r.line = w.line_index; r.fixed = w.fixed_index; r.packed = nullptr; r.obs = w.observations; r.params_in = w.parameters; r.params = w.parameters;
+      const bool pk = packed && packed[i];
+      r.cam = pk ? nullptr : w.camera_index; r.line = pk ? nullptr : w.line_index; r.fixed = pk ? nullptr : w.fixed_index; r.packed = pk ? packed[i] : nullptr;
+      r.obs = w.observations; r.params_in = w.parameters; r.params = w.parameters;
       rw[i] = r;
     }
     // Arrays that lie next to each other in host memory (a caller that carves its windows out of an arena) go up in a few large copies of
@@ -1639,10 +1646,13 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
     for (int i = 0; i < B && !no_dma; ++i) {
       const slslam_lba_window& w = windows[i];
       const size_t M = (size_t)w.num_observations, np = (size_t)6 * w.num_cameras + (size_t)4 * w.num_lines;
-      if (M) { rg.push_back({ (uintptr_t)w.camera_index, (uintptr_t)w.camera_index + 4 * M }); rg.push_back({ (uintptr_t)w.line_index, (uintptr_t)w.line_index + 4 * M });
-               rg.push_back({ (uintptr_t)w.fixed_index, (uintptr_t)w.fixed_index + 8 * M }); rg.push_back({ (uintptr_t)w.observations, (uintptr_t)w.observations + 64 * M }); }
+      const bool pk = packed && packed[i];
+      if (M && pk) rg.push_back({ (uintptr_t)packed[i], (uintptr_t)packed[i] + 4 * M });
+      if (M && !pk) { rg.push_back({ (uintptr_t)w.camera_index, (uintptr_t)w.camera_index + 4 * M }); rg.push_back({ (uintptr_t)w.line_index, (uintptr_t)w.line_index + 4 * M });
+                      rg.push_back({ (uintptr_t)w.fixed_index, (uintptr_t)w.fixed_index + 8 * M }); }
+      if (M) rg.push_back({ (uintptr_t)w.observations, (uintptr_t)w.observations + 64 * M });
       if (np) rg.push_back({ (uintptr_t)w.parameters, (uintptr_t)w.parameters + 8 * np });
-      payload += 80 * M + 8 * np;
+      payload += (pk ? 68 : 80) * M + 8 * np;
     }
     std::sort(rg.begin(), rg.end(), [](const Rg& x, const Rg& y) { return x.lo < y.lo; });
     for (const Rg& g : rg) {
@@ -1677,6 +1687,9 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
       bad |= copy_checked(pr, w.parameters, np);
       const int C = w.num_cameras, L = w.num_lines;
       unsigned oob = 0;
+      if (packed && packed[i]) {
+        for (size_t q = 0; q < M; ++q) { const uint32_t v = packed[i][q]; oob |= (unsigned)((int)(v & 0xffffu) >= L) | (unsigned)((int)((v >> 16) & 0xffu) >= C) | (v >> 26); ix[q] = v; }
+      } else
       for (size_t q = 0; q < M; ++q) {
         const int c = w.camera_index[q], l = w.line_index[q];
         oob |= (unsigned)(c < 0) | (unsigned)(c >= C) | (unsigned)(l < 0) | (unsigned)(l >= L);
@@ -2363,9 +2376,38 @@ extern "C" void slslam_lba_stream_destroy(slslam_lba_stream* st) {
   delete st;
 }
 
+namespace {
+int stream_submit_impl(slslam_lba_stream* st, const slslam_lba_window* windows, const unsigned int* const* packed, int n, int* ticket);
+}
 extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_window* windows, int n, int* ticket) {
+  return stream_submit_impl(st, windows, nullptr, n, ticket);
+}
+extern "C" int slslam_lba_stream_submit_packed(slslam_lba_stream* st, const slslam_lba_window* windows, const unsigned int* const* packed_index, int n, int* ticket) {
+  return stream_submit_impl(st, windows, packed_index, n, ticket);
+}
+namespace {
+int stream_submit_impl(slslam_lba_stream* st, const slslam_lba_window* windows, const unsigned int* const* packed, int n, int* ticket) {
   if (!st || !windows || n <= 0) return SLSLAM_ERR_INVALID_ARGUMENT;
   const auto t0 = std::chrono::steady_clock::now();
+  // windows whose indices came narrowed and that end up on the host packer (the slot's first batch, a refill the device build does not take)
+  // get their three index arrays back first
+  std::vector<slslam_lba_window> expanded;
+  std::vector<std::vector<int>> exp_idx;
+  auto expand = [&]() -> const slslam_lba_window* {
+    if (!packed) return windows;
+    if (!expanded.empty()) return expanded.data();
+    expanded.assign(windows, windows + n);
+    exp_idx.resize((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      if (!packed[i]) continue;
+      const size_t M = (size_t)std::max(0, windows[i].num_observations);
+      std::vector<int>& v = exp_idx[(size_t)i];
+      v.resize(4 * M);
+      for (size_t q = 0; q < M; ++q) { const unsigned int x = packed[i][q]; v[q] = (int)((x >> 16) & 0xffu); v[M + q] = (int)(x & 0xffffu); v[2 * M + 2 * q] = (int)((x >> 24) & 1u); v[2 * M + 2 * q + 1] = (int)((x >> 25) & 1u); }
+      expanded[(size_t)i].camera_index = v.data(); expanded[(size_t)i].line_index = v.data() + M; expanded[(size_t)i].fixed_index = v.data() + 2 * M;
+    }
+    return expanded.data();
+  };
   auto& sl = st->slots[(size_t)(st->next_ticket % st->depth)];
   if (sl.in_flight) return SLSLAM_ERR_STATE;             // its results have not been collected
   HIP_TRY(hipSetDevice(st->device));
@@ -2377,7 +2419,7 @@ extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_
     if (b->finalized && b->refillable && !b->part[0] && !b->big_mode && !b->fused_motion_only && !b->opt.reuse_elimination && (int)b->wins.size() == n) {
       static const bool serial_build = std::getenv("SLSLAM_STREAM_SERIAL_BUILD") != nullptr;      // (measurement switch: build and solve on one stream)
       hipStream_t bs = serial_build ? st->solve_stream : st->build_stream;
-      rc = refill_device(b, windows, n, bs, st->ingest_stream);
+      rc = refill_device(b, windows, n, bs, st->ingest_stream, packed);
       if (rc == SLSLAM_OK) {
         run = st->solve_stream;
         if (bs != run) { HIP_TRY(hipEventRecord(st->ev_built, bs)); HIP_TRY(hipStreamWaitEvent(run, st->ev_built, 0)); }
@@ -2386,7 +2428,7 @@ extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_
     if (rc == SLSLAM_ERR_UNSUPPORTED) {
       // the host packer (or refused: a new batch below): its uploads overlap the other slots' solves on a stream of the slot's own
       if (!sl.stream) HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-      rc = slslam_lba_batch_refill(b, windows, n, (void*)sl.stream);
+      rc = slslam_lba_batch_refill(b, expand(), n, (void*)sl.stream);
       if (rc == SLSLAM_OK) run = sl.stream;
     }
   }
@@ -2399,7 +2441,8 @@ extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_
     b->ext_pool = st->pool.get();
     b->wins.resize((size_t)n);
     std::vector<int> ps((size_t)n, SLSLAM_OK);
-    if (!st->pool->run(n, [&](int i) { ps[(size_t)i] = pack_window(&windows[i], &b->wins[(size_t)i]); })) rc = SLSLAM_ERR_NO_MEMORY;
+    const slslam_lba_window* ew = expand();
+    if (!st->pool->run(n, [&](int i) { ps[(size_t)i] = pack_window(&ew[i], &b->wins[(size_t)i]); })) rc = SLSLAM_ERR_NO_MEMORY;
     for (int r : ps) if (r != SLSLAM_OK) rc = r;
     if (rc == SLSLAM_OK) rc = slslam_lba_batch_finalize(b, &st->opt);
     if (rc != SLSLAM_OK) { b->ext_pool = nullptr; slslam_lba_batch_destroy(b); return rc; }
@@ -2422,6 +2465,7 @@ extern "C" int slslam_lba_stream_submit(slslam_lba_stream* st, const slslam_lba_
   st->ms_submit += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return SLSLAM_OK;
 }
+}  // namespace
 
 extern "C" int slslam_lba_stream_collect(slslam_lba_stream* st, int ticket, slslam_summary* summaries) {
   if (!st || ticket < 0) return SLSLAM_ERR_INVALID_ARGUMENT;
@@ -2457,7 +2501,7 @@ extern "C" int slslam_lba_stream_collect(slslam_lba_stream* st, int ticket, slsl
   for (int i : flagged) {
     const RawWin& r = bt->host_src[(size_t)i];
     std::vector<int> cam, line, fixed;
-    slslam_lba_window w;
+    slslam_lba_window w{};
     w.num_cameras = r.C; w.num_lines = r.L; w.num_observations = r.M; w.observations = r.obs; w.parameters = sl.out_params[(size_t)i];
     if (r.packed) {
       cam.resize((size_t)r.M); line.resize((size_t)r.M); fixed.resize(2 * (size_t)r.M);

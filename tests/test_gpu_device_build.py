@@ -234,3 +234,42 @@ def test_stream_hands_flagged_windows_to_the_host_path(hip, oracle):
         for ws in wsets:
             ws.close()
         wb.close()
+
+
+def test_stream_with_narrowed_indices(hip):
+    """slslam_lba_stream_submit_packed: the caller hands the three index arrays of every window narrowed to one 32-bit word per observation
+    (slslam_pack_indices) - from page-locked memory (read in place) and from ordinary memory (staging copy).  Same bytes as fresh batches;
+    the slot's first batches (host packer) get the arrays expanded again; a word that names a camera the window does not have is refused."""
+    per = 5
+    sets = [[synth.make_window(8000 + 10 * k + i, num_lines=200 + 20 * i) for i in range(per)] for k in range(4)]
+    for pinned in (True, False):
+        st = hip.LBAStream(depth=2, host_threads=2)
+        wsets = [hip.WindowSet(s, pinned=pinned, packed=True) for s in sets]
+        tickets, res = [], {}
+        for k in range(4):
+            if k >= 2:
+                res[k - 2] = st.collect(tickets[k - 2])
+            tickets.append(st.submit(wsets[k]))
+        for k in (2, 3):
+            res[k] = st.collect(tickets[k])
+        bs = st.build_stats()
+        assert bs["device_builds"] == 2 and bs["fallback_windows"] == 0
+        for k in range(4):
+            fresh, _ = _solve_fresh(hip, sets[k])
+            for j in range(per):
+                assert np.array_equal(wsets[k].parameters(j), fresh[j][0]), (pinned, k, j)
+                assert res[k][j] == fresh[j][1]
+        bad = hip.WindowSet(sets[1], pinned=pinned, packed=True)
+        bad.packed_arrays[2][7] = np.uint32(int(bad.packed_arrays[2][7]) | (200 << 16))         # camera 200+
+        if pinned:
+            t = st.submit(bad)
+            with pytest.raises(hip.SlslamError) as e:
+                st.collect(t)
+            assert e.value.status == 1
+        else:
+            with pytest.raises(hip.SlslamError) as e:
+                st.submit(bad)
+            assert e.value.status == 1
+        st.close()
+        for ws in wsets + [bad]:
+            ws.close()

@@ -26,7 +26,7 @@ def main():
     B = args.windows
     windows = [synth.make_window(i, num_lines=args.lines) for i in range(B)]
     nsets = args.depth + 1 + args.batches
-    base = capi.WindowSet(windows, pinned=(args.mode == "pinned"))
+    base = capi.WindowSet(windows, pinned=(args.mode in ("pinned", "packed")), packed=(args.mode == "packed"))
     sets = [base.derive(list(range((k * 37) % B, B)) + list(range((k * 37) % B))) for k in range(nsets)]
     st = capi.LBAStream(depth=args.depth, host_threads=args.host_threads, **({"device_build": -1} if args.mode == "host" else {}))
     tick = []
