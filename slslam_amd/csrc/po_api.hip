@@ -256,7 +256,19 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   if (!structured) {
     for (int k = 0; k < N; ++k) if (used[k] && k != gauge) { slot[k] = n; n += 6; }
   } else {
-    order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, gauge, slot, chains, &n_chain, &n, &level_counts);
+    // The symbolic analysis depends on the TOPOLOGY alone, and the reference's graph only changes when a loop closure adds an edge
+    // (src/slam.cpp:1248-1280): the calling thread keeps the analysis of its last graph and reuses it when the edge lists are the same.
+    struct Symbolic { int N = -1, E = -1, n_chain = 0, n = 0; std::vector<int> p1, p2, slot, level_counts; std::vector<PoChain> chains; };
+    static thread_local Symbolic* sym = nullptr;
+    if (!sym) sym = new Symbolic();          // (never destroyed: no teardown order to get wrong at thread exit)
+    const bool hit = sym->N == N && sym->E == E && std::memcmp(sym->p1.data(), g->pose_index_1, sizeof(int) * (size_t)E) == 0 &&
+                     std::memcmp(sym->p2.data(), g->pose_index_2, sizeof(int) * (size_t)E) == 0 && !std::getenv("SLSLAM_PO_NO_SYMBOLIC_CACHE");
+    if (!hit) {
+      order_chains_first(N, E, g->pose_index_1, g->pose_index_2, used, gauge, slot, chains, &n_chain, &n, &level_counts);
+      sym->N = N; sym->E = E; sym->n_chain = n_chain; sym->n = n;
+      sym->p1.assign(g->pose_index_1, g->pose_index_1 + E); sym->p2.assign(g->pose_index_2, g->pose_index_2 + E);
+      sym->slot = slot; sym->level_counts = level_counts; sym->chains = chains;
+    } else { slot = sym->slot; chains = sym->chains; level_counts = sym->level_counts; n_chain = sym->n_chain; n = sym->n; }
   }
   for (int e = 0; e < E; ++e) if (slot[g->pose_index_1[e]] >= 0 || slot[g->pose_index_2[e]] >= 0) ++kept;
   const int ld = ((n + 7) / 8) * 8 + 8;
@@ -305,19 +317,26 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   const int nblk = (n + kNB - 1) / kNB;
   const dim3 g_edges((unsigned)((E + 4) / 5));
 
-  // one device allocation carved into the work arrays (17 hipMalloc / hipFree pairs cost more than a small solve)
+  // one device allocation carved into the work arrays (17 hipMalloc / hipFree pairs cost more than a small solve); what the host fills comes
+  // FIRST and contiguous - state | trace | poses (what comes back, in one copy) | indices, slots, constraints, scale, chains, the small zeroed
+  // words - so that it goes up in ONE copy from a pinned image the calling thread keeps (a dozen synchronous hipMemcpy / hipMemset calls were a
+  // quarter of a 260-pose solve's host clock)
+  size_t up_bytes = 0, down_bytes = 0;
+  char* stage = nullptr;
   {
     const size_t nn = ones.size(), nb2 = (size_t)kNB * kNB * (size_t)(nblk > 0 ? nblk : 1);
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_st = take(sizeof(LMState)), o_trace = take(sizeof(IterRec) * kMaxTrace), o_x = take(sizeof(double) * 12 * (N > 0 ? N : 1));
+    down_bytes = off;
     const size_t o_p1 = take(sizeof(int) * E), o_p2 = take(sizeof(int) * E), o_slot = take(sizeof(int) * (N > 0 ? N : 1)),
-                 o_cons = take(sizeof(double) * 6 * E), o_x = take(sizeof(double) * 12 * (N > 0 ? N : 1)), o_scale = take(sizeof(double) * nn),
-                 o_H = take(hbytes), o_g = take(sizeof(double) * nn), o_d2 = take(sizeof(double) * nn), o_y = take(sizeof(double) * nn),
+                 o_cons = take(sizeof(double) * 6 * E), o_scale = take(sizeof(double) * nn), o_chains = take(sizeof(PoChain) * (chains.size() + 1)),
+                 o_scal = take(sizeof(double) * 8), o_flags = take(sizeof(int) * 2), o_tri = take(sizeof(unsigned) * (size_t)(nblk + 1));
+    up_bytes = off;
+    const size_t o_H = take(hbytes), o_g = take(sizeof(double) * nn), o_d2 = take(sizeof(double) * nn), o_y = take(sizeof(double) * nn),
                  o_linv = take(sizeof(double) * nb2), o_Hf = take(f32 ? sizeof(float) * (size_t)(n > 0 ? n : 1) * ld : 0),
                  o_Lf = take(f32 ? 0 : hbytes), o_Lff = take(f32 ? sizeof(float) * (size_t)(n > 0 ? n : 1) * ld : 0),
-                 o_tri = take(sizeof(unsigned) * (size_t)(nblk + 1)),
-                 o_linvf = take(f32 ? sizeof(float) * nb2 : 0), o_scal = take(sizeof(double) * 8), o_flags = take(sizeof(int) * 2),
-                 o_st = take(sizeof(LMState)), o_trace = take(sizeof(IterRec) * kMaxTrace), o_chains = take(sizeof(PoChain) * (chains.size() + 1));
+                 o_linvf = take(f32 ? sizeof(float) * nb2 : 0);
     arena_bytes = off;
     (void)hipGetDevice(&arena_device);
     PO_TRY(DeviceBlockCache::acquire(off, arena_device, &arena));   // the block of the previous one-shot solve, if large enough
@@ -329,22 +348,29 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     d_tri_flags = (unsigned*)(arena + o_tri);
     p.scal = (double*)(arena + o_scal); p.flags = (int*)(arena + o_flags); p.st = (LMState*)(arena + o_st);
     p.trace = (IterRec*)(arena + o_trace); d_chains = (PoChain*)(arena + o_chains);
+    // the pinned image (kept per calling thread, grown on demand)
+    struct HostStage { char* p = nullptr; size_t bytes = 0; };
+    static thread_local HostStage* hs = nullptr;
+    if (!hs) hs = new HostStage();
+    if (hs->bytes < up_bytes) {
+      if (hs->p) (void)hipHostFree(hs->p);
+      hs->p = nullptr; hs->bytes = 0;
+      PO_TRY(hipHostMalloc((void**)&hs->p, up_bytes + up_bytes / 4 + 4096, hipHostMallocDefault));
+      hs->bytes = up_bytes + up_bytes / 4 + 4096;
+    }
+    stage = hs->p;
+    std::memset(stage, 0, up_bytes);
+    std::memset(&hst, 0, sizeof(hst));
+    hst.radius = pol.initial_radius; hst.decrease_factor = 2.0; hst.status = kRunning;
+    std::memcpy(stage + o_st, &hst, sizeof(hst));
+    std::memcpy(stage + o_x, g->parameters, sizeof(double) * 6 * N);
+    std::memcpy(stage + o_x + sizeof(double) * 6 * N, g->parameters, sizeof(double) * 6 * N);
+    std::memcpy(stage + o_p1, g->pose_index_1, sizeof(int) * E); std::memcpy(stage + o_p2, g->pose_index_2, sizeof(int) * E);
+    std::memcpy(stage + o_slot, slot.data(), sizeof(int) * N); std::memcpy(stage + o_cons, g->constraints, sizeof(double) * 6 * E);
+    std::memcpy(stage + o_scale, ones.data(), sizeof(double) * nn);
+    if (!chains.empty()) std::memcpy(stage + o_chains, chains.data(), sizeof(PoChain) * chains.size());
+    PO_TRY(hipMemcpyAsync(arena, stage, up_bytes, hipMemcpyHostToDevice, 0));
   }
-  PO_TRY(hipMemcpy(d_p1, g->pose_index_1, sizeof(int) * E, hipMemcpyHostToDevice));
-  PO_TRY(hipMemcpy(d_p2, g->pose_index_2, sizeof(int) * E, hipMemcpyHostToDevice));
-  PO_TRY(hipMemcpy(d_slot, slot.data(), sizeof(int) * N, hipMemcpyHostToDevice));
-  PO_TRY(hipMemcpy(d_cons, g->constraints, sizeof(double) * 6 * E, hipMemcpyHostToDevice));
-  std::memcpy(x2.data(), g->parameters, sizeof(double) * 6 * N);
-  std::memcpy(x2.data() + (size_t)6 * N, g->parameters, sizeof(double) * 6 * N);
-  PO_TRY(hipMemcpy(p.x, x2.data(), sizeof(double) * 12 * N, hipMemcpyHostToDevice));
-  PO_TRY(hipMemcpy(p.scale, ones.data(), sizeof(double) * ones.size(), hipMemcpyHostToDevice));
-  std::memset(&hst, 0, sizeof(hst));
-  hst.radius = pol.initial_radius; hst.decrease_factor = 2.0; hst.status = kRunning;
-  PO_TRY(hipMemcpy(p.st, &hst, sizeof(hst), hipMemcpyHostToDevice));
-  PO_TRY(hipMemset(p.trace, 0, sizeof(IterRec) * kMaxTrace));
-  PO_TRY(hipMemset(p.scal, 0, sizeof(double) * 8));
-  PO_TRY(hipMemset(p.flags, 0, sizeof(int) * 2));
-  PO_TRY(hipMemset(d_tri_flags, 0, sizeof(unsigned) * (size_t)(nblk + 1)));
   (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, arena_device);
   // k_po_trisolve_wide spin-waits across workgroups: all of its nblk workgroups have to be resident together.  Ask the runtime how
   // many fit (a CU mask or a compute partition shows up here); when it cannot tell, the one-workgroup substitution runs instead.
@@ -359,9 +385,6 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   p.N = N; p.E = E; p.n = n; p.ld = ld;
   pj = p;                                  // the junction block as a matrix of its own (same leading dimension)
   pj.n = nj; pj.H = p.H + (size_t)n_chain * ld + n_chain; pj.y = p.y + n_chain;
-  if (!chains.empty()) {
-    PO_TRY(hipMemcpy(d_chains, chains.data(), sizeof(PoChain) * chains.size(), hipMemcpyHostToDevice));
-  }
 
   if (po_step_lds_attributes() != hipSuccess) { PO_TRY(hipErrorInvalidValue); }
   stamp(); stamp();                       // [1] is re-recorded at the end
@@ -444,9 +467,11 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     for (hipEvent_t e : tev) (void)hipEventDestroy(e);
     tev.clear();
   }
-  PO_TRY(hipMemcpy(&hst, p.st, sizeof(hst), hipMemcpyDeviceToHost));
-  PO_TRY(hipMemcpy(htrace.data(), p.trace, sizeof(IterRec) * kMaxTrace, hipMemcpyDeviceToHost));
-  PO_TRY(hipMemcpy(x2.data(), p.x, sizeof(double) * 12 * N, hipMemcpyDeviceToHost));
+  // state | trace | poses come back in ONE copy (they are the first bytes of the block)
+  PO_TRY(hipMemcpy(stage, arena, down_bytes, hipMemcpyDeviceToHost));
+  std::memcpy(&hst, stage + ((char*)p.st - arena), sizeof(hst));
+  std::memcpy(htrace.data(), stage + ((char*)p.trace - arena), sizeof(IterRec) * kMaxTrace);
+  std::memcpy(x2.data(), stage + ((char*)p.x - arena), sizeof(double) * 12 * N);
   {
     int term = hst.status == kRunning ? SLSLAM_NO_CONVERGENCE : hst.status;
     if (n == 0) term = SLSLAM_FUNCTION_TOLERANCE;     // no non-constant parameter blocks
