@@ -319,7 +319,8 @@ int  slslam_lba_stream_submit_packed(slslam_lba_stream* s, const slslam_lba_wind
  * count of reference src/slam.cpp:949-950) of the windows collected; host threads in use.  Any pointer may be NULL. */
 int  slslam_lba_stream_stats(const slslam_lba_stream* s, double* ms_submit, double* ms_collect_wait, double* ms_collect_copy,
                              long long* refills, long long* builds, long long* windows, long long* lm_iterations, int* host_threads);
-/* Of the refills: how many were built on the device, how many of those read the callers' page-locked arrays in place (zero copy); windows the
+/* Of the refills: how many were built on the device, how many of those read the callers' page-locked observations and parameters in place (no
+ * staging copy; the index arrays are narrowed by the host threads on the way); windows the
  * device build handed back to the host path at collect time (a camera that sees a line twice, a line with more than 64 observations, more
  * than 20 free cameras, no room in the slot's arrays).  Any pointer may be NULL. */
 int  slslam_lba_stream_build_stats(const slslam_lba_stream* s, long long* device_builds, long long* zero_copy, long long* fallback_windows);

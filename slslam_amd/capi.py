@@ -254,14 +254,15 @@ class PinnedArena:
 class _WindowArrays:
     """Keeps the numpy buffers a slslam_lba_window points to alive."""
 
-    def __init__(self, w, params=None, arena=None, params_arena=None):
+    def __init__(self, w, params=None, arena=None, params_arena=None, obs_arena=None):
         self.cam = np.ascontiguousarray(w["camera_index"], dtype=np.int32)
         self.line = np.ascontiguousarray(w["line_index"], dtype=np.int32)
         self.fixed = np.ascontiguousarray(w["fixed_index"], dtype=np.int32).reshape(-1)
         self.obs = np.ascontiguousarray(w["observations"], dtype=np.float64).reshape(-1)
         self.params = np.array(w["parameters"] if params is None else params, dtype=np.float64).reshape(-1).copy()
         if arena is not None:
-            self.cam, self.line, self.fixed, self.obs = (arena.take(x) for x in (self.cam, self.line, self.fixed, self.obs))
+            self.cam, self.line, self.fixed = (arena.take(x) for x in (self.cam, self.line, self.fixed))
+            self.obs = (obs_arena or arena).take(self.obs)
         if params_arena is not None or arena is not None:
             self.params = (params_arena or arena).take(self.params)
         m = len(self.cam)
@@ -414,17 +415,19 @@ class WindowSet:
         """pinned: the arrays live in page-locked blocks (slslam_pinned_alloc): the device build reads them in place and the solved
         parameters are written back into them by the GPU.  packed: the three index arrays of every window are ALSO held narrowed to one
         32-bit word per observation (slslam_pack_indices), and LBAStream.submit hands those over instead (slslam_lba_stream_submit_packed)."""
-        self.arena = self.params_arena = None
+        self.arena = self.params_arena = self.obs_arena = None
         self.packed = None
         if pinned:
-            # the read-only arrays of all windows in one block, the parameter arrays in another (derive() gives a set parameter arrays of its
-            # own over the same inputs): arrays that lie next to each other go up in a few large copies
-            self.arena = PinnedArena(sum(80 * len(w["camera_index"]) + 4 * 64 for w in windows) + 4096)
+            # three blocks - the index arrays of all windows, their observation arrays, their parameter arrays (derive() gives a set parameter
+            # arrays of its own over the same inputs): arrays that lie next to each other go up in a few large copies of the copy engine, and the
+            # index arrays - which the host threads narrow on the way - do not sit between the observation arrays
+            self.arena = PinnedArena(sum(16 * len(w["camera_index"]) + 3 * 64 for w in windows) + 4096)
+            self.obs_arena = PinnedArena(sum(64 * len(w["camera_index"]) + 64 for w in windows) + 4096)
             self.params_arena = PinnedArena(sum(8 * (6 * int(w["num_cameras"]) + 4 * int(w["num_lines"])) + 64 for w in windows) + 4096)
         if pinned and packed:
             self.arena.close()
-            self.arena = PinnedArena(sum(68 * len(w["camera_index"]) + 2 * 64 for w in windows) + 4096)
-        self.arrays = [_WindowArrays(w, arena=None if packed else self.arena, params_arena=self.params_arena) for w in windows]
+            self.arena = PinnedArena(sum(4 * len(w["camera_index"]) + 64 for w in windows) + 4096)
+        self.arrays = [_WindowArrays(w, arena=None if packed else self.arena, params_arena=self.params_arena, obs_arena=self.obs_arena) for w in windows]
         if packed:
             self.packed_arrays = []
             for a in self.arrays:
@@ -432,7 +435,7 @@ class WindowSet:
                 _check(lib().slslam_pack_indices(len(a.cam), _ip(a.cam), _ip(a.line), _ip(a.fixed), pk.ctypes.data_as(C.POINTER(C.c_uint))), "slslam_pack_indices")
                 if self.arena is not None:
                     pk = self.arena.take(pk)
-                    a.obs = self.arena.take(a.obs)
+                    a.obs = self.obs_arena.take(a.obs)
                     a.c = LBAWindow(a.c.num_cameras, a.c.num_lines, a.c.num_observations, _ip(a.cam), _ip(a.line), _ip(a.fixed), _dp(a.obs), _dp(a.params))
                 self.packed_arrays.append(pk)
             self.packed = (C.POINTER(C.c_uint) * max(len(self.arrays), 1))(*[p_.ctypes.data_as(C.POINTER(C.c_uint)) for p_ in self.packed_arrays])
@@ -451,7 +454,7 @@ class WindowSet:
         of observations once more.  Page-locked like this set."""
         import copy
         out = WindowSet.__new__(WindowSet)
-        out.arena = out.params_arena = None
+        out.arena = out.params_arena = out.obs_arena = None
         out.packed = None
         if self.packed is not None:
             out.packed_arrays = [self.packed_arrays[j] for j in order]
@@ -471,7 +474,7 @@ class WindowSet:
 
     def close(self):
         self.arrays = [] if (self.arena is not None or self.params_arena is not None) else self.arrays
-        for name in ("arena", "params_arena"):
+        for name in ("arena", "params_arena", "obs_arena"):
             if getattr(self, name, None) is not None:
                 getattr(self, name).close()
                 setattr(self, name, None)

@@ -295,6 +295,7 @@ struct slslam_lba_batch {
   size_t d_stage_bytes = 0;
   std::vector<RawWin> host_src;              // per window: host-readable pointers to what the device was given (the callers' page-locked arrays, or the staging copy)
   int ingest_mode = 0;                       // of the last device-built refill: 0 zero-copy kernel reads of the callers' page-locked arrays, 1 copy engine
+  bool ingest_pinned = false;                // ... its observations and parameters were read where the caller holds them (page-locked), no staging copy
   bool device_built = false;                 // the batch's present windows were built on the device
   bool inplace_export = false;               // ... and their `parameters` arrays are pinned: results can be written straight into them
   bool results_inplace = false;              // the last download wrote them there
@@ -1639,20 +1640,58 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
     // outstanding in the L2 channels, and every latency-bound kernel beside it waits behind them (the window build 2.7 -> 11.6 ms, k_build_tiles
     // 0.36 -> 6.4 ms measured).  Scattered arrays: zero-copy kernel reads.
     static const bool no_dma = std::getenv("SLSLAM_INGEST_ZERO_COPY") != nullptr;         // (measurement switch)
+    // The three int32 index arrays are 16 of the 80 bytes an observation sends over the link, which is what a stream of page-locked windows is
+    // bound by (1.085 GB per 1024 x 2000-line batch at 57 GB/s = 19 ms against 15 ms of solve).  The host threads narrow them to one word per
+    // observation into a pinned block on the way (4 B; ~0.25 GB of reads per batch: a few milliseconds on two threads, beside the GPU's work) -
+    // the observations and the parameters still go up from where they are.  Bad indices are reported now, as the host packer does.
+    static const bool no_narrow = std::getenv("SLSLAM_NO_HOST_NARROW") != nullptr;          // (measurement switch)
+    const bool narrow = !no_dma && !no_narrow && nobs > 0;
+    if (narrow) {
+      const size_t need = 4 * (size_t)nobs + 64;
+      if (need > b->raw_stage_bytes) {
+        if (b->h_raw_stage) { (void)hipHostFree(b->h_raw_stage); b->h_raw_stage = nullptr; b->raw_stage_bytes = 0; }
+        const size_t want = need + need / 8 + 4096;
+        HIP_TRY(hipHostMalloc((void**)&b->h_raw_stage, want, hipHostMallocDefault));
+        b->raw_stage_bytes = want;
+      }
+      std::vector<int> st((size_t)B, SLSLAM_OK);
+      HostPool* pool = batch_pool(b, (int)std::min<long long>(B, b->opt.host_threads > 0 ? b->opt.host_threads : (B >= 64 ? 8 : 1)));
+      auto narrow_one = [&](int i) {
+        if (packed && packed[i]) return;
+        const slslam_lba_window& w = windows[i];
+        const size_t M = (size_t)w.num_observations;
+        uint32_t* ix = reinterpret_cast<uint32_t*>(b->h_raw_stage) + obs_off[(size_t)i];
+        const int C = w.num_cameras, L = w.num_lines;
+        const int* cam = w.camera_index; const int* line = w.line_index; const int* fx = w.fixed_index;
+        unsigned oob = 0;
+        for (size_t q = 0; q < M; ++q) {
+          const int c = cam[q], l = line[q];
+          oob |= (unsigned)(c < 0) | (unsigned)(c >= C) | (unsigned)(l < 0) | (unsigned)(l >= L);
+          ix[q] = ((uint32_t)l & 0xffffu) | ((uint32_t)c & 0xffu) << 16 | (fx[2 * q] ? 1u << 24 : 0u) | (fx[2 * q + 1] ? 1u << 25 : 0u);
+        }
+        if (oob) st[(size_t)i] = SLSLAM_ERR_INVALID_ARGUMENT;
+        RawWin& r = b->host_src[(size_t)i];
+        r.cam = nullptr; r.line = nullptr; r.fixed = nullptr; r.packed = ix;
+        rw[i] = r;
+      };
+      if (!run_all(pool, B, narrow_one)) return SLSLAM_ERR_NO_MEMORY;
+      for (int v : st) if (v != SLSLAM_OK) return v;
+    }
     struct Rg { uintptr_t lo, hi; };
     std::vector<Rg> rg;
     rg.reserve((size_t)5 * B);
     size_t payload = 0;
+    if (narrow) { rg.push_back({ (uintptr_t)b->h_raw_stage, (uintptr_t)b->h_raw_stage + 4 * (size_t)nobs }); payload += 4 * (size_t)nobs; }
     for (int i = 0; i < B && !no_dma; ++i) {
       const slslam_lba_window& w = windows[i];
       const size_t M = (size_t)w.num_observations, np = (size_t)6 * w.num_cameras + (size_t)4 * w.num_lines;
       const bool pk = packed && packed[i];
       if (M && pk) rg.push_back({ (uintptr_t)packed[i], (uintptr_t)packed[i] + 4 * M });
-      if (M && !pk) { rg.push_back({ (uintptr_t)w.camera_index, (uintptr_t)w.camera_index + 4 * M }); rg.push_back({ (uintptr_t)w.line_index, (uintptr_t)w.line_index + 4 * M });
-                      rg.push_back({ (uintptr_t)w.fixed_index, (uintptr_t)w.fixed_index + 8 * M }); }
+      if (M && !pk && !narrow) { rg.push_back({ (uintptr_t)w.camera_index, (uintptr_t)w.camera_index + 4 * M }); rg.push_back({ (uintptr_t)w.line_index, (uintptr_t)w.line_index + 4 * M });
+                                 rg.push_back({ (uintptr_t)w.fixed_index, (uintptr_t)w.fixed_index + 8 * M }); }
       if (M) rg.push_back({ (uintptr_t)w.observations, (uintptr_t)w.observations + 64 * M });
       if (np) rg.push_back({ (uintptr_t)w.parameters, (uintptr_t)w.parameters + 8 * np });
-      payload += (pk ? 68 : 80) * M + 8 * np;
+      payload += (pk ? 68 : narrow ? 64 : 80) * M + 8 * np;
     }
     std::sort(rg.begin(), rg.end(), [](const Rg& x, const Rg& y) { return x.lo < y.lo; });
     for (const Rg& g : rg) {
@@ -1729,6 +1768,7 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
     }
   }
   b->ingest_mode = runs.empty() ? 0 : 1;
+  b->ingest_pinned = all_pinned;
   for (int i = 0; i < B; ++i) {
     RawWin& r = rw[i];
     r.param_off = par_off[(size_t)i]; r.C = windows[i].num_cameras; r.L = windows[i].num_lines; r.M = windows[i].num_observations;
@@ -2432,7 +2472,7 @@ int stream_submit_impl(slslam_lba_stream* st, const slslam_lba_window* windows, 
       if (rc == SLSLAM_OK) run = sl.stream;
     }
   }
-  if (rc == SLSLAM_OK) { ++st->n_refills; if (sl.batch->device_built) { ++st->n_device_builds; if (!sl.batch->host_src.empty() && !sl.batch->host_src[0].packed) ++st->n_zero_copy; } }
+  if (rc == SLSLAM_OK) { ++st->n_refills; if (sl.batch->device_built) { ++st->n_device_builds; if (sl.batch->ingest_pinned) ++st->n_zero_copy; } }
   else if (rc == SLSLAM_ERR_UNSUPPORTED) {
     // the first batch of the slot, another number of windows, or windows that do not fit the room the slot's arrays have: a new batch
     if (sl.batch) { if (sl.stream) HIP_TRY(hipStreamSynchronize(sl.stream)); HIP_TRY(hipStreamSynchronize(st->solve_stream)); HIP_TRY(hipStreamSynchronize(st->build_stream)); HIP_TRY(hipStreamSynchronize(st->result_stream)); sl.batch->ext_pool = nullptr; slslam_lba_batch_destroy(sl.batch); sl.batch = nullptr; }

@@ -178,8 +178,9 @@ def test_device_built_refill_equals_fresh_batch(hip, oracle, elim, pinned):
 def test_stream_hands_flagged_windows_to_the_host_path(hip, oracle):
     """A stream whose sets hold windows the device build flags - a camera that sees a line twice (the reference's map never does, the ABI does
     not forbid it) - among ordinary ones: the flagged windows are solved through the host path at collect time, the others by the batch;
-    every window equals what slslam_lba_solve / a fresh batch returns; stats count the device builds and the fallbacks.  With bad input
-    (an index out of range) collect reports SLSLAM_ERR_INVALID_ARGUMENT and the other windows of the set are solved all the same."""
+    every window equals what slslam_lba_solve / a fresh batch returns; stats count the device builds and the fallbacks.  Bad input: an
+    index out of range is refused at submit time (the host threads narrow the indices); a NaN the device alone sees is reported by collect
+    (SLSLAM_ERR_INVALID_ARGUMENT) and the other windows of the set are solved all the same."""
     per = 6
     base = [[synth.make_window(7000 + 10 * k + i, num_lines=220 + 15 * i) for i in range(per)] for k in range(5)]
     dup = dict(base[3][2])
@@ -212,10 +213,19 @@ def test_stream_hands_flagged_windows_to_the_host_path(hip, oracle):
                 assert np.array_equal(wsets[k].parameters(j), fresh[fi][0]), (pinned, k, j)
                 assert res[k][j] == fresh[fi][1]
                 fi += 1
-        # bad input in a refill: reported by collect, the rest of the set solved
+        # bad input in a refill.  An index out of range is found by whoever narrows the indices - the host threads, at submit time, as the
+        # host packer would; a NaN among page-locked observations only the device sees: flagged there, reported by collect, the rest of the set solved
         bad = [dict(w) for w in base[1]]
         cam = np.asarray(bad[4]["camera_index"]).copy(); cam[3] = 99
         bad[4]["camera_index"] = cam
+        wb = hip.WindowSet(bad, pinned=pinned)
+        with pytest.raises(hip.SlslamError) as e:
+            st.submit(wb)
+        assert e.value.status == 1
+        wb.close()
+        bad = [dict(w) for w in base[1]]
+        ob = np.asarray(bad[4]["observations"], dtype=np.float64).reshape(-1).copy(); ob[17] = np.nan
+        bad[4]["observations"] = ob
         wb = hip.WindowSet(bad, pinned=pinned)
         if pinned:
             t = st.submit(wb)
@@ -228,7 +238,7 @@ def test_stream_hands_flagged_windows_to_the_host_path(hip, oracle):
             assert np.array_equal(wb.parameters(4), np.asarray(bad[4]["parameters"]))        # untouched
         else:
             with pytest.raises(hip.SlslamError) as e:
-                st.submit(wb)                               # the staging copy validates on the host, as the host packer does
+                st.submit(wb)                               # the staging copy tests the values on the host, as the host packer does
             assert e.value.status == 1
         st.close()
         for ws in wsets:

@@ -950,3 +950,38 @@ def test_pack_observation_destinations(host_math):
             oo, oc, nk = np.zeros(M, np.int32), np.zeros(M, np.int32), C.c_int(0)
             assert host_math.hm_pack_dest(Cn, L, M, _ip(cam), _ip(line), _ip(fixed), _dp(bad), _dp(prm), grouping, mode, _dp(planes), _dp(raw), _ip(oo), _ip(oc),
                                           C.byref(nk), _dp(own)) == 1
+
+
+def test_round6_entry_points_without_a_device():
+    """The round-6 surface (include/slslam_hip.h): slslam_pack_indices is host arithmetic and works anywhere - the narrowed word is
+    line | camera << 16 | camera constant << 24 | line constant << 25, indices beyond 255 cameras / 65534 lines are refused; page-locked
+    memory, the device build's test hook and streams need a HIP device (SLSLAM_ERR_NO_DEVICE), never a CPU stand-in."""
+    import ctypes as C
+    from slslam_amd import capi
+    L = capi.lib()
+    w = synth.make_window(3, num_lines=40)
+    cam = np.ascontiguousarray(w["camera_index"], dtype=np.int32); line = np.ascontiguousarray(w["line_index"], dtype=np.int32)
+    fixed = np.ascontiguousarray(w["fixed_index"], dtype=np.int32)
+    fixed[2 * 5 + 1] = 1
+    pk = np.zeros(len(cam), dtype=np.uint32)
+    assert L.slslam_pack_indices(len(cam), _ip(cam), _ip(line), _ip(fixed), pk.ctypes.data_as(C.POINTER(C.c_uint))) == 0
+    assert np.array_equal(pk & 0xffff, line) and np.array_equal((pk >> 16) & 0xff, cam)
+    assert np.array_equal((pk >> 24) & 1, fixed[0::2] != 0) and np.array_equal((pk >> 25) & 1, fixed[1::2] != 0) and not np.any(pk >> 26)
+    bad = cam.copy(); bad[0] = 256
+    assert L.slslam_pack_indices(len(cam), _ip(bad), _ip(line), _ip(fixed), pk.ctypes.data_as(C.POINTER(C.c_uint))) == 4
+    bad = line.copy(); bad[0] = 65535
+    assert L.slslam_pack_indices(len(cam), _ip(cam), _ip(bad), _ip(fixed), pk.ctypes.data_as(C.POINTER(C.c_uint))) == 4
+    assert L.slslam_pack_indices(3, None, _ip(line), _ip(fixed), pk.ctypes.data_as(C.POINTER(C.c_uint))) == 1
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = C.c_void_p()
+    assert L.slslam_pinned_alloc(4096, C.byref(p)) == 2 and not p.value
+    buf = np.zeros(4096, dtype=np.uint8)
+    assert L.slslam_pinned_register(buf.ctypes.data_as(C.c_void_p), 4096) == 2
+    assert L.slslam_pinned_contains(buf.ctypes.data_as(C.c_void_p), 16) == 0
+    with pytest.raises(capi.SlslamError) as e:
+        capi.debug_device_pack(w)
+    assert e.value.status == 2
+    with pytest.raises(capi.SlslamError) as e:
+        capi.LBAStream()
+    assert e.value.status == 2
