@@ -310,8 +310,9 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
     window (src/slam.cpp:899-921) and its solved parameters go back into the caller's array (:957-972).  Inside the timed region, per
     batch of len(windows) windows: the LBAProblem::build stage, the same captured solve the resident headline replays, the results into the
     callers' arrays - `depth` batches in flight (slslam_lba_stream_*).  mode:
-      "pinned"   the caller's arrays live in page-locked memory (slslam_pinned_alloc): the GPU reads them in place, builds the batch on the
-                 device (csrc/lba_device_build.h) and writes the solved parameters back in place - no host thread touches the data;
+      "pinned"   the caller's arrays live in page-locked memory (slslam_pinned_alloc): the copy engine takes the observations and parameters
+                 from where they are, the host threads only narrow the three index arrays on the way (16 -> 4 B per observation), the batch
+                 is built on the device (csrc/lba_device_build.h) and the solved parameters are written back in place;
       "packed"   as "pinned", and the caller's packer writes the three index arrays narrowed to one 32-bit word per observation
                  (slslam_pack_indices / slslam_lba_stream_submit_packed): 68 instead of 80 bytes per observation over the link;
       "pageable" ordinary arrays: the host threads copy them into a pinned staging buffer (indices narrowed on the way), the device builds;
@@ -365,7 +366,8 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
             equal = equal and bool(np.array_equal(sets[k].parameters(j), resident_params[i]))
     m = sum(len(w["camera_index"]) for w in windows)
     npar = sum(8 * (6 * w["num_cameras"] + 4 * w["num_lines"]) for w in windows)
-    link_in = {"pinned": 80 * m + npar, "packed": 68 * m + npar, "pageable": 68 * m + npar}.get(mode)
+    # (page-locked arrays: the host threads narrow the three index arrays to one word per observation on the way - 64 + 4 B per observation cross the link)
+    link_in = {"pinned": 68 * m + npar, "packed": 68 * m + npar, "pageable": 68 * m + npar}.get(mode)
     if link_in is None:
         link_in = 8 * 8 * m + 4 * 2 * m + npar + sum(40 * w["num_lines"] for w in windows)
     out = {"value": its / dt, "unit": "LM iterations/s", "fraction_of_resident": (its / dt) / resident_value if resident_value else None,
@@ -381,7 +383,7 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
            "ms_per_batch_copying_results_out": (s1["ms_collect_copy"] - s0["ms_collect_copy"]) / batches_timed,
            "host_link_in_MB_per_batch": link_in / 1e6, "host_link_out_MB_per_batch": npar / 1e6, "lm_iterations": its,
            "bitwise_equal_to_resident_batch": equal if checked else None, "windows_compared": checked,
-           "timed_region": {"pinned": "per batch: copy-engine ingest of the callers' page-locked arrays + build on the device + hipGraph solve + results written in place, %d batches in flight",
+           "timed_region": {"pinned": "per batch: index arrays narrowed by the host threads + copy-engine ingest of the callers' page-locked observations and parameters + build on the device + hipGraph solve + results written in place, %d batches in flight",
                             "packed": "as pinned, the indices narrowed by the caller (one 32-bit word per observation), %d batches in flight",
                             "pageable": "per batch: staging copy (host threads, indices narrowed) + ingest + build on the device + hipGraph solve + D2H + copy-out, %d batches in flight",
                             "host": "per batch: pack (host threads) + pinned H2D + hipGraph solve + D2H + copy-out into the callers' arrays, %d batches in flight"}[mode] % depth}
