@@ -1038,10 +1038,22 @@ __global__ __launch_bounds__(256) void k_slab_reduce(BatchPtrs p) {
 // RESIDENT = 4: four workgroups per CU - the LDS limit - need <= 128 registers: the whole 1024-window batch is resident in one
 // round.  RESIDENT = 1: a batch of at most one window per CU (the reference's call protocol: one window) has the CU to itself and
 // the tile factorisation on its critical path gets the registers it wants (no scratch).
+// the lane index, remade on every call (asm volatile: never merged into one long-lived value)
+__device__ __forceinline__ int sls_fresh_lane() {
+  int x;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+  return x;
+}
+
 template <int RESIDENT>
 __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Policy pol) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the thread's indices are remade where they are used - the lane from v_mbcnt behind an asm the compiler does not merge, the wave kept in a scalar
+  // register: as one value that lives from the first line to the last the thread index was spilled under the 128-register cap of the
+  // four-workgroups-per-CU form and reloaded from scratch 53 times along the solve)
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#define lane sls_fresh_lane()
+#define tid (wave * 64 + sls_fresh_lane())
   const int w = blockIdx.x;
   const WinDesc wd = p.wins[w];
   LMState* st = p.state + w;
@@ -1573,6 +1585,8 @@ __global__ __launch_bounds__(256, RESIDENT) void k_reduced_solve(BatchPtrs p, Po
   }
   SLS_SOLVE_STAMP(8);
 }
+#undef lane
+#undef tid
 
 // ------------------------------------------------------------------------------------------
 // Kernel 3, variant A (default): back-substitution  y_l = A^-1 (g_l - sum_i H_cl,i^T y_c) = K^T K (g_l - w),
