@@ -297,3 +297,56 @@ def test_streamed_headline_path_matches_oracle_and_fresh_batches(hip, oracle):
     for s_ in sets:
         s_.close()
     base.close()
+
+
+def test_stream_with_an_oversize_window_among_ordinary_ones(hip, oracle):
+    """ A submit that mixes a window beyond the tiled sweeps (24 free cameras: the global-memory path) with ordinary ones is
+    solved as a MIXED batch - two parts side by side, the top-level batch holds no LM states of its own: collect must take the step counts and
+    summaries through the routing getters.  Two such sets through a depth-2 stream (the second submit to a slot finds a mixed batch: rebuilt),
+    every window against a fresh batch of its set, the oversize one also against the oracle."""
+    sets = []
+    for k in range(3):
+        s = [synth.make_window(9100 + 10 * k + i, num_lines=180 + 20 * i) for i in range(4)]
+        s.insert(2, synth.make_window(9150 + k, num_lines=50, num_kf=30, num_free=24, mean_track=10.0))
+        sets.append(s)
+    st = hip.LBAStream(depth=2, host_threads=2)
+    wsets = [hip.WindowSet(s) for s in sets]
+    tickets, res = [], {}
+    for k in range(3):
+        if k >= 2:
+            res[k - 2] = st.collect(tickets[k - 2])
+        tickets.append(st.submit(wsets[k]))
+    for k in (1, 2):
+        res[k] = st.collect(tickets[k])
+    its = st.stats()["lm_iterations"]
+    want_its = 0
+    for k in range(3):
+        fresh, _, _ = _solve_fresh(hip, sets[k])
+        for j in range(5):
+            assert np.array_equal(wsets[k].parameters(j), fresh[j][0]), (k, j)
+            assert res[k][j] == fresh[j][1]
+            want_its += fresh[j][1]["num_successful_steps"] + fresh[j][1]["num_unsuccessful_steps"]
+    assert its == want_its
+    xo, so, _ = oracle.lba_solve(sets[1][2], linear_solver=1)
+    assert so["num_successful_steps"] == res[1][2]["num_successful_steps"] and np.abs(xo - wsets[1].parameters(2)).max() < 1e-5
+    st.close()
+
+
+def test_refused_refill_keeps_the_results_of_the_download_under_way(hip):
+    """ slslam_lba_batch_refill after download_async: a refill that is REFUSED (windows that cannot fit) leaves the batch as it
+    was, the results of the download included - wait() and the getters still deliver them."""
+    ws = [synth.make_window(9300 + i, num_lines=200 + 10 * i) for i in range(4)]
+    b = hip.LBABatch()
+    for w in ws:
+        b.add(w)
+    b.finalize(refill_headroom_percent=20)
+    b.solve(); b.download()
+    want = [b.parameters(i).copy() for i in range(4)]
+    b.reset(); b.solve(); b.download_async()
+    with pytest.raises(hip.SlslamError) as e:
+        b.refill([synth.make_window(9400 + i, num_lines=900) for i in range(4)])
+    assert e.value.status == 4
+    b.wait()
+    for i in range(4):
+        assert np.array_equal(b.parameters(i), want[i])
+    b.close()
