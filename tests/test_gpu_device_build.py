@@ -283,3 +283,51 @@ def test_stream_with_narrowed_indices(hip):
         st.close()
         for ws in wsets + [bad]:
             ws.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_device_built_refill_edge_shapes(hip, oracle, pinned):
+    """Refills whose windows are degenerate: a window without observations, one whose blocks are all constant, unused camera / line slots with a
+    scrambled order, a motion-only shaped window among general ones, fewer cameras than the slot was made for - and a set whose EVERY window is
+    flagged (all emitted empty: nothing is launched, every result comes from the host path).  Same bytes as fresh batches."""
+    base = [synth.make_window(9500 + i, num_lines=150 + 10 * i) for i in range(5)]
+    w = synth.make_window(9510, num_lines=60)
+    rng = np.random.default_rng(11)
+    perm = rng.permutation(len(w["camera_index"]))
+    ragged = dict(w, num_cameras=22, num_lines=63, camera_index=w["camera_index"][perm], line_index=w["line_index"][perm],
+                  fixed_index=w["fixed_index"].reshape(-1, 2)[perm].reshape(-1), observations=w["observations"].reshape(-1, 8)[perm].reshape(-1),
+                  parameters=np.concatenate([w["parameters"][:120], rng.normal(size=12), w["parameters"][120:], rng.uniform(0.2, 1, 12)]))
+    empty = dict(num_cameras=2, num_lines=3, camera_index=np.zeros(0, np.int32), line_index=np.zeros(0, np.int32), fixed_index=np.zeros(0, np.int32),
+                 observations=np.zeros(0), parameters=np.arange(24.0))
+    wc = synth.make_window(9511, num_lines=40)
+    all_const = dict(wc, fixed_index=np.ones_like(wc["fixed_index"]))
+    few = synth.make_window(9512, num_lines=80, num_kf=8, num_free=3)
+    other = [ragged, empty, all_const, few, synth.make_window(9513, num_lines=170)]
+    # (the slot's first batch sets the room: 22 cameras in a window, 10 free, twice the lines)
+    first = [dict(ragged), synth.make_window(9520, num_lines=300), synth.make_window(9521, num_lines=320), synth.make_window(9522, num_lines=280),
+             synth.make_window(9523, num_lines=310)]
+    st = hip.LBAStream(depth=1, host_threads=2, refill_headroom_percent=50)
+    for k, s in enumerate((first, base, other, base)):
+        ws = hip.WindowSet(s, pinned=pinned)
+        res = st.collect(st.submit(ws))
+        fresh, _ = _solve_fresh(hip, s)
+        for j in range(5):
+            assert np.array_equal(ws.parameters(j), fresh[j][0]), (k, j)
+            assert res[j] == fresh[j][1], (k, j)
+        ws.close()
+    assert st.build_stats()["device_builds"] == 3 and st.build_stats()["fallback_windows"] == 0
+    # every window flagged: cameras that see a line twice in all five
+    dups = []
+    for wd_ in base:
+        cam = np.asarray(wd_["camera_index"]).copy()
+        same = np.flatnonzero(np.asarray(wd_["line_index"]) == wd_["line_index"][0])
+        cam[same[1]] = cam[same[0]]
+        dups.append(dict(wd_, camera_index=cam))
+    ws = hip.WindowSet(dups, pinned=pinned)
+    res = st.collect(st.submit(ws))
+    assert st.build_stats()["fallback_windows"] == 5
+    for j in range(5):
+        x, s_, _ = hip.lba_solve(dups[j])
+        assert np.array_equal(ws.parameters(j), x) and res[j] == s_
+    ws.close()
+    st.close()
