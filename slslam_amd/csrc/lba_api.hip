@@ -1572,6 +1572,9 @@ unsigned long long copy_checked(double* dst, const double* src, size_t n) {
 int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, hipStream_t s, hipStream_t s_in, const unsigned int* const* packed = nullptr) {
   if (b->opt.device_build < 0 || b->d_rawwin.n < (size_t)std::max(1, B) || !b->d_ob_raw.p) return SLSLAM_ERR_UNSUPPORTED;
   if (std::getenv("SLSLAM_CHUNK_WEIGHTS")) return SLSLAM_ERR_UNSUPPORTED;          // (an experiment knob of the host-side cut)
+  // (k_build_layout dispatches graded chunks in at most kLayoutMaxRank classes: a batch cut for more rounds of the wave slots - several
+  // thousand 2000-line windows - keeps the host packer)
+  if ((b->opt.chunks_per_window < 0 ? (-b->opt.chunks_per_window) / 1000 : (b->opt.reproducible ? 3 : b->auto_rounds)) > (int)kLayoutMaxRank) return SLSLAM_ERR_UNSUPPORTED;
   static const bool timing = std::getenv("SLSLAM_REFILL_TIMING") != nullptr;
   const auto tt0 = std::chrono::steady_clock::now();
   // ---- what the host knows without reading an array: the windows' sizes, hence their places in the batch
