@@ -2384,7 +2384,7 @@ extern "C" int slslam_lba_stream_create(int device, const slslam_solver_options*
   int pr_lo = 0, pr_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
   if (hipStreamCreateWithPriority(&st->ingest_stream, hipStreamNonBlocking, pr_hi) != hipSuccess || hipStreamCreateWithFlags(&st->solve_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&st->build_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithPriority(&st->build_stream, hipStreamNonBlocking, std::getenv("SLSLAM_BUILD_STREAM_PRIORITY") ? std::atoi(std::getenv("SLSLAM_BUILD_STREAM_PRIORITY")) : 0) != hipSuccess ||
       hipStreamCreateWithFlags(&st->result_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&st->ev_solved, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&st->ev_built, hipEventDisableTiming) != hipSuccess) {
     if (st->ingest_stream) (void)hipStreamDestroy(st->ingest_stream);
