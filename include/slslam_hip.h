@@ -126,7 +126,7 @@ typedef struct slslam_solver_options {
                                            bookkeeping stay fp64, as does the first sweep of a solve.  Which parts may be float was
                                            measured (a float line Jacobian changes accept / reject decisions: its depth column carries
                                            d = cos t / sin t, reference src/lba_problem.h:63).  Grouped sweep only (lba_elimination 0 or
-                                           4, at most 10 free cameras); opt-in; results within the tolerance stated in DESIGN.md 7e and
+                                           4, at most 10 free cameras); opt-in; results within the tolerance stated in DESIGN.md 4 ("Mixed precision") and
                                            tests/test_gpu_lba.py::test_mixed_precision_solves of the fp64 path and of the oracle.
                                            MEASURED: buys nothing (0.997 x the fp64 step) - fp32 line Jacobians change LM accept / reject
                                            decisions, and what is left to fp32 is a few per cent of the sweep.  Kept as a tested option  */
