@@ -705,13 +705,21 @@ HostPool* batch_pool(slslam_lba_batch* b, int threads) {
 // A refill's observations arrive in the caller's order (one linear copy per window on the host, one upload): thread <-> sorted observation o of
 // window blockIdx.y takes observation ob_orig[o] of that window's raw block and lays its four (x, y) pairs into the planes the sweeps stream.
 // What pack_window's gather does on the host for a fresh batch - the same bytes - at the device's memory rate instead of a host core's.
-__global__ __launch_bounds__(256) void k_permute_obs(BatchPtrs p, const double* raw, const int* ob_orig, double* ob_planes) {
+__global__ __launch_bounds__(256) void k_permute_obs(BatchPtrs p, const double* raw, const int* ob_orig, double* ob_planes, const RawWin* src_of = nullptr) {
   const WinDesc wd = p.wins[blockIdx.y];
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= wd.M) return;
   const long long g = (long long)wd.obs_off + o;
-  const double2* src = reinterpret_cast<const double2*>(raw + ((long long)wd.obs_off + ob_orig[g]) * 8);
-  const double2 a = src[0], b = src[1], c = src[2], d = src[3];
+  // (src_of: the window's observations lie where the copy engine put them - a device-built refill of page-locked or staged arrays)
+  const double* base = src_of ? src_of[blockIdx.y].obs : raw + (long long)wd.obs_off * 8;
+  const double* sp = base + (long long)ob_orig[g] * 8;
+  double2 a, b, c, d;
+  if ((reinterpret_cast<uintptr_t>(sp) & 15u) == 0) {
+    const double2* src = reinterpret_cast<const double2*>(sp);
+    a = src[0]; b = src[1]; c = src[2]; d = src[3];
+  } else {
+    a = make_double2(sp[0], sp[1]); b = make_double2(sp[2], sp[3]); c = make_double2(sp[4], sp[5]); d = make_double2(sp[6], sp[7]);
+  }
   double2* out = reinterpret_cast<double2*>(ob_planes);
   out[g] = a; out[p.ob_stride + g] = b; out[2 * p.ob_stride + g] = c; out[3 * p.ob_stride + g] = d;
 }
@@ -1422,18 +1430,24 @@ namespace {
 // Results of a device-built refill whose `parameters` arrays are page-locked go straight where the caller wants them (reference
 // src/slam.cpp:957-972 reads them there): thread <-> parameter block, the window's destination from the RawWin table.  A window that ended in
 // NUMERICAL_FAILURE is left untouched, as Ceres leaves the user's parameters.
-__global__ __launch_bounds__(256) void k_export_inplace(BatchPtrs p, const RawWin* raw, const int* line_pos) {
-  // thread <-> one double of window blockIdx.y's parameter vector, in the CALLER'S order: consecutive lanes write consecutive addresses
-  // (the destination is host memory across the link: 8-byte stores scattered by the sorted line order ran at a sixth of its rate)
-  const int w = blockIdx.y;
-  const WinDesc wd = p.wins[w];
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= 6 * wd.C + 4 * wd.L || p.state[w].status == SLSLAM_NUMERICAL_FAILURE) return;
-  const int cur = p.state[w].cur;
-  double v;
-  if (q < 6 * wd.C) { const int c = q / 6; v = p.cam_x[((long long)(wd.cam_off + c) * 2 + cur) * kCamRec + (q - 6 * c)]; }
-  else { const int ql = q - 6 * wd.C, l = ql >> 2; v = p.line_x[line_rec(p, (long long)wd.line_off + line_pos[wd.line_off + l], cur) + (ql & 3)]; }
-  raw[w].params[q] = v;
+__global__ __launch_bounds__(256) void k_export_inplace(BatchPtrs p, const RawWin* raw, const int* line_pos, int nwin) {
+  // thread <-> one double of a window's parameter vector, in the CALLER'S order: consecutive lanes write consecutive addresses
+  // (the destination is host memory across the link: 8-byte stores scattered by the sorted line order ran at a sixth of its rate).
+  // FEW workgroups walk the windows: the stores are posted and the link sets the pace (~1.3 ms per 67 MB) whatever the grid is, but a
+  // wave that has stores on their way keeps its slot - a grid of thousands of short workgroups held slots all over the chip for that time,
+  // and the solves of the stream's other batches (two 256-register waves per SIMD, no room beside them) waited for every one of them.
+  for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+    const WinDesc wd = p.wins[w];
+    if (p.state[w].status == SLSLAM_NUMERICAL_FAILURE) continue;
+    const int cur = p.state[w].cur, np = 6 * wd.C + 4 * wd.L;
+    double* dst = raw[w].params;
+    for (int q = threadIdx.x; q < np; q += 256) {
+      double v;
+      if (q < 6 * wd.C) { const int c = q / 6; v = p.cam_x[((long long)(wd.cam_off + c) * 2 + cur) * kCamRec + (q - 6 * c)]; }
+      else { const int ql = q - 6 * wd.C, l = ql >> 2; v = p.line_x[line_rec(p, (long long)wd.line_off + line_pos[wd.line_off + l], cur) + (ql & 3)]; }
+      dst[q] = v;
+    }
+  }
 }
 
 int download_async_impl(slslam_lba_batch* b, void* stream, bool allow_inplace) {
@@ -1450,11 +1464,10 @@ int download_async_impl(slslam_lba_batch* b, void* stream, bool allow_inplace) {
   const bool inplace = allow_inplace && b->device_built && b->inplace_export;
   b->results_inplace = inplace;
   if (inplace) {
-    long long maxp = 0;
-    for (const PackedWindow& P : b->wins) maxp = std::max(maxp, 6LL * P.C + 4LL * P.L);
-    if (maxp > 0 && !b->wins.empty())
-      hipLaunchKernelGGL(k_export_inplace, dim3((unsigned)((maxp + 255) / 256), (unsigned)b->wins.size()), dim3(256), 0, s, b->ptrs, (const RawWin*)b->d_rawwin.p,
-                         (const int*)b->d_line_pos.p);
+    static const int export_wgs = std::getenv("SLSLAM_EXPORT_WORKGROUPS") ? std::max(1, std::atoi(std::getenv("SLSLAM_EXPORT_WORKGROUPS"))) : 64;
+    if (b->total_params > 0 && !b->wins.empty())
+      hipLaunchKernelGGL(k_export_inplace, dim3((unsigned)std::min<size_t>(b->wins.size(), (size_t)export_wgs)), dim3(256), 0, s, b->ptrs, (const RawWin*)b->d_rawwin.p,
+                         (const int*)b->d_line_pos.p, (int)b->wins.size());
     HIP_TRY(hipGetLastError());
   } else {
     int rc = slslam_lba_batch_export_device(b, b->d_params_out.p, stream);
@@ -1648,7 +1661,9 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
     // observation into a pinned block on the way (4 B; ~0.25 GB of reads per batch: a few milliseconds on two threads, beside the GPU's work) -
     // the observations and the parameters still go up from where they are.  Bad indices are reported now, as the host packer does.
     static const bool no_narrow = std::getenv("SLSLAM_NO_HOST_NARROW") != nullptr;          // (measurement switch)
-    const bool narrow = !no_dma && !no_narrow && nobs > 0;
+    bool any_unpacked = false;
+    for (int i = 0; i < B && !any_unpacked; ++i) any_unpacked = windows[i].num_observations > 0 && !(packed && packed[i]);
+    const bool narrow = !no_dma && !no_narrow && nobs > 0 && any_unpacked;       // (a batch whose caller narrowed every window sends no block of ours)
     if (narrow) {
       const size_t need = 4 * (size_t)nobs + 64;
       if (need > b->raw_stage_bytes) {
@@ -1701,7 +1716,7 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
       if (!runs.empty() && g.lo <= runs.back().hi + 4096) runs.back().hi = std::max(runs.back().hi, g.hi);
       else runs.push_back(Run{ g.lo, g.hi, 0 });
     }
-    for (Run& r : runs) { r.dev_off = dev_need; dev_need += ((r.hi - r.lo) + 255) & ~(size_t)255; }
+    for (Run& r : runs) { r.dev_off = dev_need + (r.lo & 255); dev_need += ((r.lo & 255) + (r.hi - r.lo) + 255) & ~(size_t)255; }     // (device address = host address modulo 256)
     if (runs.size() > (size_t)std::max(8, B / 16) || dev_need > payload + payload / 8 + (1u << 20)) { runs.clear(); dev_need = 0; }     // scattered: zero copy
   } else {
     // staging: per window [observations 64 M | narrowed indices 4 M | parameters], 64-byte aligned pieces
@@ -1811,6 +1826,7 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
   std::memset(&P, 0, sizeof(P));
   P.raw = b->d_rawwin.p; P.bw = b->d_buildwin.p; P.nwin = B; P.grouping = b->elim_grouped ? 1 : 0;
   P.ob_raw = b->d_ob_raw.p; P.raw_idx = b->d_raw_idx.p; P.line_raw = b->d_line_raw.p; P.lflags = b->d_lflags.p; P.fmask = b->d_fmask.p; P.line_pos = b->d_line_pos.p;
+  P.obs_in_place = runs.empty() ? 0 : 1;       // the copy engine's block is read where it is (k_permute_obs): no second copy of the observations
   P.mid_keys = b->d_mid_keys.p; P.mid_li = b->d_mid_li.p; P.mid_rows = b->d_mid_rows.p; P.mid_next = b->d_mid_next.p; P.mid_trows = b->d_mid_trows.p; P.mid_tptr = b->d_mid_tptr.p; P.mid = b->d_mid.p;
   P.wins = b->d_wins.p; P.tiles = b->d_tiles.p; P.chunks = b->d_chunks.p; P.items = b->d_items.p; P.lane_map = b->d_lane_map.p; P.line_desc = b->d_line_desc.p;
   P.cam_x0 = b->d_cam_x0.p; P.cam_cf = b->d_cam_cf.p; P.cam_win = b->d_cam_win.p;
@@ -1867,7 +1883,8 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
   if (b->slab_sum_image) HIP_TRY(hipMemsetAsync(b->d_slab_sum.p, 0, b->d_slab_sum.n * sizeof(double), s));
   HIP_TRY(hipMemsetAsync(b->d_active.p, 0, sizeof(unsigned int), s));
   if (nobs > 0 && maxM > 0)
-    hipLaunchKernelGGL(k_permute_obs, dim3((unsigned)((maxM + 255) / 256), (unsigned)B), dim3(256), 0, s, b->ptrs, (const double*)b->d_ob_raw.p, (const int*)b->d_ob_orig.p, b->d_ob.p);
+    hipLaunchKernelGGL(k_permute_obs, dim3((unsigned)((maxM + 255) / 256), (unsigned)B), dim3(256), 0, s, b->ptrs, (const double*)b->d_ob_raw.p, (const int*)b->d_ob_orig.p, b->d_ob.p,
+                       (const RawWin*)(runs.empty() ? nullptr : b->d_rawwin.p));
   rc = device_init_after_upload(b, s);
   if (timing) {
     const auto tt3 = std::chrono::steady_clock::now();
@@ -2383,8 +2400,20 @@ extern "C" int slslam_lba_stream_create(int device, const slslam_solver_options*
   // The ingest stream gets the highest priority: its few workgroups must find wave slots while a solve's thousands are queued.
   int pr_lo = 0, pr_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+  // (experiment: SLSLAM_BUILD_CUS = n confines the build stream to n compute units spread over the chip)
+  auto make_build_stream = [&](hipStream_t* out) -> hipError_t {
+    const int ncu = std::getenv("SLSLAM_BUILD_CUS") ? std::atoi(std::getenv("SLSLAM_BUILD_CUS")) : 0;
+    hipDeviceProp_t prop;
+    if (ncu > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && ncu < prop.multiProcessorCount) {
+      const int total = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
+      for (int k = 0; k < ncu; ++k) { const int cu = (int)((long long)k * total / ncu); mask[(size_t)cu / 32] |= 1u << (cu % 32); }
+      return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+    }
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, std::getenv("SLSLAM_BUILD_STREAM_PRIORITY") ? std::atoi(std::getenv("SLSLAM_BUILD_STREAM_PRIORITY")) : 0);
+  };
   if (hipStreamCreateWithPriority(&st->ingest_stream, hipStreamNonBlocking, pr_hi) != hipSuccess || hipStreamCreateWithFlags(&st->solve_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithPriority(&st->build_stream, hipStreamNonBlocking, std::getenv("SLSLAM_BUILD_STREAM_PRIORITY") ? std::atoi(std::getenv("SLSLAM_BUILD_STREAM_PRIORITY")) : 0) != hipSuccess ||
+      make_build_stream(&st->build_stream) != hipSuccess ||
       hipStreamCreateWithFlags(&st->result_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&st->ev_solved, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&st->ev_built, hipEventDisableTiming) != hipSuccess) {
     if (st->ingest_stream) (void)hipStreamDestroy(st->ingest_stream);

@@ -76,6 +76,7 @@ struct BuildPtrs {
   int grouping;
   // ingest destinations
   double* ob_raw;             // [8 nobs] observations in the caller's order
+  int obs_in_place;           // the observations stay where RawWin.obs has them (device memory): the ingest only tests them
   uint32_t* raw_idx;          // [nobs] narrowed indices
   double* line_raw;           // [4 nline] line parameters in the caller's order
   // per-line scratch (sorted order)
@@ -131,15 +132,16 @@ __global__ __launch_bounds__(256) void k_ingest(BuildPtrs P) {
       if ((reinterpret_cast<uintptr_t>(r.obs) & 15u) == 0) {
         const double2* src = reinterpret_cast<const double2*>(r.obs);
         double2* d2 = reinterpret_cast<double2*>(dst);
+        const bool copy = !P.obs_in_place;
         for (long long i = tid; i < n2; i += 1024) {
           double2 v[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) if (i + 256 * u < n2) v[u] = src[i + 256 * u];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) if (i + 256 * u < n2) { d2[i + 256 * u] = v[u]; bad |= bad_exponent(v[u].x) | bad_exponent(v[u].y); }
+          for (int u = 0; u < 4; ++u) if (i + 256 * u < n2) { if (copy) d2[i + 256 * u] = v[u]; bad |= bad_exponent(v[u].x) | bad_exponent(v[u].y); }
         }
       } else {
-        for (long long i = tid; i < 2 * n2; i += 256) { const double v = r.obs[i]; dst[i] = v; bad |= bad_exponent(v); }
+        for (long long i = tid; i < 2 * n2; i += 256) { const double v = r.obs[i]; if (!P.obs_in_place) dst[i] = v; bad |= bad_exponent(v); }
       }
     }
     // indices, narrowed: line | camera << 16 | camera constant << 24 | line constant << 25

@@ -27,7 +27,7 @@ export GPU_MAX_HW_QUEUES=8
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_iso -o t -- python tools/stream_probe.py --batches 6 --depth 1 --mode pinned --host-threads 1 > gpurun_out/${TAG}_iso.log 2>&1
 python tools/rocpd_summary.py gpurun_out/${TAG}_iso/t_results.db > gpurun_out/${TAG}_stream_kernels_alone.txt 2>&1
 rm -rf gpurun_out/${TAG}_iso
-timeout 900 rocprofv3 --kernel-trace -d gpurun_out/${TAG}_tl -o t -- python tools/stream_probe.py --batches 8 --mode pinned --host-threads 1 > gpurun_out/${TAG}_tl.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --memory-copy-trace -d gpurun_out/${TAG}_tl -o t -- python tools/stream_probe.py --batches 8 --mode pinned --host-threads 1 > gpurun_out/${TAG}_tl.log 2>&1
 python tools/rocpd_timeline.py gpurun_out/${TAG}_tl/t_results.db | tail -90 > gpurun_out/${TAG}_stream_timeline.txt 2>&1
 rm -rf gpurun_out/${TAG}_tl
 unset GPU_MAX_HW_QUEUES
@@ -39,6 +39,7 @@ for MODE in pinned packed pageable host; do
 done
 python tools/build_phases.py > gpurun_out/${TAG}_build_phases.txt 2>&1
 python tools/first_solve_after_refill.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_first_solve_after_refill.txt
+python tools/solve_phases.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_reduced_solve_phases.txt
 python tools/po_bench.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_po_bench.txt
 tools/micro/_build/zcb > gpurun_out/${TAG}_zero_copy_bench.txt 2>&1
 tail -3 gpurun_out/${TAG}_gputests.log; head -12 gpurun_out/${TAG}_kernel_trace.txt; grep -A2 "k_eliminate_grouped\|k_backsub" gpurun_out/${TAG}_pmc.txt | head -20; tail -c 1500 gpurun_out/${TAG}_bench.json

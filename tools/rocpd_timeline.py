@@ -26,6 +26,18 @@ for st, en, q, name in rows:
         runs.append([a, b, q, 'SOLVE'])
     else:
         runs.append([a, b, q, n])
+# copies of the copy engines (rocprofv3 --memory-copy-trace), when the database has them: size and rate of every copy above 1 MB
+mc = [t for t in tabs if 'memory_copy' in t and 'rocpd_memory_copy' in t] or [t for t in tabs if 'memory_copy' in t]
+if mc:
+    cols = [r[1] for r in cur.execute(f"pragma table_info({mc[0]})")]
+    if all(c in cols for c in ('start', 'end', 'size')):
+        for st, en, size in cur.execute(f"select start, end, size from {mc[0]} order by start"):
+            a, b = (st - t0) / 1e6, (en - t0) / 1e6
+            if size >= (1 << 20) and b > a:
+                runs.append([a, b, -1, "COPY %.1f MB at %.1f GB/s" % (size / 1e6, size / 1e9 / ((b - a) / 1e3))])
+        runs.sort(key=lambda r: r[0])
+    else:
+        print("# memory copy table %s has columns %s" % (mc[0], cols))
 for a, b, q, n in runs:
     if b - a > 0.25 and a >= lo and a <= hi:
         print("%9.2f %9.2f  %7.2f ms  q%d  %s" % (a, b, b - a, q, n))

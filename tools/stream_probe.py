@@ -49,7 +49,8 @@ def main():
     dt = time.perf_counter() - t00
     for r in rows:
         print("batch %2d  collect %.2f ms  submit %.2f ms" % r)
-    print(json.dumps({"ms_per_batch": 1e3 * dt / args.batches, "stats": st.stats(), "build_stats": st.build_stats()}))
+    periods = sorted(r[1] + r[2] for r in rows[args.depth:args.batches])
+    print(json.dumps({"ms_per_batch": 1e3 * dt / args.batches, "steady_ms_per_batch": periods[len(periods) // 2] if periods else None, "stats": st.stats(), "build_stats": st.build_stats()}))
     st.close()
 
 
