@@ -350,3 +350,48 @@ def test_refused_refill_keeps_the_results_of_the_download_under_way(hip):
     for i in range(4):
         assert np.array_equal(b.parameters(i), want[i])
     b.close()
+
+
+def test_a_window_that_fails_numerically_keeps_its_parameters(hip, oracle):
+    """Ceres leaves the user's parameters untouched when a solve ends in NUMERICAL_FAILURE (include/slslam_hip.h).  A window whose initial
+    cost overflows (one observation at 1e200: finite, so it passes the input tests of every path) ends so at once; its parameter array must
+    come back as it went in - through the one-shot call, a fresh batch, a stream of page-locked sets (the in-place export skips the window)
+    and a stream of ordinary arrays (the export hands back the initial values) - while its neighbours are solved as if it were not there."""
+    sets = []
+    for k in range(3):
+        s = [synth.make_window(9400 + 10 * k + i, num_lines=200 + 20 * i) for i in range(4)]
+        s[1]["observations"] = s[1]["observations"].copy()
+        s[1]["observations"].reshape(-1)[8 * 5 + 2] = 1e200
+        sets.append(s)
+    x, summ, _ = hip.lba_solve(sets[0][1])
+    assert summ["termination"] == "NUMERICAL_FAILURE" and np.array_equal(x, sets[0][1]["parameters"])
+    _, so, _ = oracle.lba_solve(sets[0][1], linear_solver=1)
+    assert so["termination_type"] == summ["termination_type"]
+    fresh = [_solve_fresh(hip, s)[0] for s in sets]
+    for k in range(3):
+        assert fresh[k][1][1]["termination"] == "NUMERICAL_FAILURE" and np.array_equal(fresh[k][1][0], sets[k][1]["parameters"])
+        alone = _solve_fresh(hip, [sets[k][0], sets[k][2], sets[k][3]])[0]
+        for j, i in enumerate((0, 2, 3)):
+            assert fresh[k][i][1]["termination"] != "NUMERICAL_FAILURE"
+            assert fresh[k][i][1]["num_successful_steps"] == alone[j][1]["num_successful_steps"]
+            assert abs(fresh[k][i][1]["final_cost"] - alone[j][1]["final_cost"]) <= 1e-9 * alone[j][1]["final_cost"]
+    for pinned in (True, False):
+        st = hip.LBAStream(depth=2, host_threads=2)
+        wsets = [hip.WindowSet(s, pinned=pinned) for s in sets]
+        tickets, res = [], {}
+        for k in range(3):
+            if k >= 2:
+                res[k - 2] = st.collect(tickets[k - 2])
+            tickets.append(st.submit(wsets[k]))
+        for k in (1, 2):
+            res[k] = st.collect(tickets[k])
+        assert st.build_stats()["device_builds"] >= 1
+        for k in range(3):
+            assert res[k][1]["termination"] == "NUMERICAL_FAILURE"
+            assert np.array_equal(wsets[k].parameters(1), sets[k][1]["parameters"]), (pinned, k)
+            for i in (0, 2, 3):
+                assert np.array_equal(wsets[k].parameters(i), fresh[k][i][0]), (pinned, k, i)
+                assert res[k][i] == fresh[k][i][1]
+        st.close()
+        for ws in wsets:
+            ws.close()
