@@ -1606,8 +1606,11 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
     obs_off[(size_t)i + 1] = obs_off[(size_t)i] + w.num_observations;
     par_off[(size_t)i + 1] = par_off[(size_t)i] + 6LL * w.num_cameras + 4LL * w.num_lines;
   }
-  const size_t lds_build = build_lds_bytes(maxL), lds_tiles = build_tiles_lds_bytes(maxL, maxL);
+  size_t lds_tiles = build_tiles_lds_bytes(maxL, maxL);
+  const size_t lds_build = build_lds_bytes(maxL), lds_tiles_staged = build_tiles_lds_bytes(maxL, maxL, maxM, b->elim_grouped ? 1 : 0);
   if (lds_build > 158 * 1024 || lds_tiles > 158 * 1024) return SLSLAM_ERR_UNSUPPORTED;
+  const int tiles_stage_m = lds_tiles_staged <= 158 * 1024 ? maxM : -1;      // (k_build_tiles: the tile loop's inputs in LDS when they fit)
+  if (tiles_stage_m >= 0) lds_tiles = lds_tiles_staged;
   const long long ncam = cam_off[(size_t)B], nline = line_off[(size_t)B], nobs = obs_off[(size_t)B], nparams = par_off[(size_t)B];
   const long long ob_stride = (long long)(b->d_ob.n / 8);
   if ((size_t)ncam > b->d_cam_cf.n || (size_t)nline > b->d_line_win.n || nobs > ob_stride || (size_t)nparams > b->d_params_out.n ||
@@ -1873,7 +1876,7 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
     hipLaunchKernelGGL(k_build_rows, dim3((unsigned)B), dim3(128), build_rows_lds_bytes(maxL), s, P);
     hipLaunchKernelGGL(k_build_order, dim3((unsigned)B), dim3(256), lds_build, s, P);
     hipLaunchKernelGGL(k_build_layout, dim3(1), dim3(256), 0, s, P, a);
-    hipLaunchKernelGGL(k_build_tiles, dim3((unsigned)B), dim3(256), lds_tiles, s, P, (const int*)b->d_cam_cf.p);
+    hipLaunchKernelGGL(k_build_tiles, dim3((unsigned)B), dim3(256), lds_tiles, s, P, (const int*)b->d_cam_cf.p, tiles_stage_m);
   }
   HIP_TRY(hipGetLastError());
   // what a fresh batch finds zeroed
@@ -2267,8 +2270,12 @@ extern "C" int slslam_debug_device_pack_timed(const slslam_lba_window* w, int gr
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SLSLAM_ERR_NO_DEVICE;
   const int C = w->num_cameras, L = w->num_lines, M = w->num_observations;
   if (C < 0 || L < 0 || M < 0 || C > kMaxCams || L > 0xfffe || M >= (1 << 24)) return SLSLAM_ERR_UNSUPPORTED;
-  const size_t lds_build = build_lds_bytes(L), lds_tiles = build_tiles_lds_bytes(L, L);
+  size_t lds_tiles = build_tiles_lds_bytes(L, L);
+  const size_t lds_build = build_lds_bytes(L), lds_tiles_staged = build_tiles_lds_bytes(L, L, M, grouping ? 1 : 0);
   if (lds_build > 158 * 1024 || lds_tiles > 158 * 1024) return SLSLAM_ERR_UNSUPPORTED;
+  const bool no_stage = std::getenv("SLSLAM_BUILD_TILES_UNSTAGED") != nullptr;      // (tests: the form for windows whose observations do not fit the LDS)
+  const int tiles_stage_m = (lds_tiles_staged <= 158 * 1024 && !no_stage) ? M : -1;
+  if (tiles_stage_m >= 0) lds_tiles = lds_tiles_staged;
   const size_t Lq = (size_t)std::max(1, L), Mq = (size_t)std::max(1, M), Cq = (size_t)std::max(1, C), np = (size_t)6 * C + (size_t)4 * L;
   const size_t cap_tiles = Lq + 8, cap_items = (size_t)std::max(1, max_items);
   DeviceArena ar;
@@ -2318,7 +2325,7 @@ extern "C" int slslam_debug_device_pack_timed(const slslam_lba_window* w, int gr
     hipLaunchKernelGGL(k_build_rows, dim3(1), dim3(128), build_rows_lds_bytes(L), 0, P);
     hipLaunchKernelGGL(k_build_order, dim3(1), dim3(256), lds_build, 0, P);
     hipLaunchKernelGGL(k_build_layout, dim3(1), dim3(256), 0, 0, P, a);
-    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), lds_tiles, 0, P, (const int*)d_cam_cf.p);
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), lds_tiles, 0, P, (const int*)d_cam_cf.p, tiles_stage_m);
     e = hipDeviceSynchronize();
   }
   BuildWin bw;

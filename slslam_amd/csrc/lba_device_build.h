@@ -684,15 +684,24 @@ __global__ __launch_bounds__(256) void k_build_order(BuildPtrs P) {
   // (lba_pack.cpp:308-333): keys camera key << 24 | index dropped into the line's range, then sorted per line
   unsigned* okey = reinterpret_cast<unsigned*>(P.ob_orig + r.obs_off);
   int kept = 0;
-  for (int i = tid; i < M; i += 256) {
-    const uint32_t v = ridx[i];
-    const int l = (int)(v & 0xffffu), c = (int)((v >> 16) & 0xffu);
-    const int s = line_pos[l];
-    const unsigned slot = atomicAdd(&fill[s], 1u);
-    const int cf = s_cam_cf[c];
-    const unsigned ck = cf >= 0 ? (unsigned)cf : (unsigned)(Cf + c);
-    okey[lptr[s] + slot] = ck << 24 | (unsigned)i;
-    if (!(((constset >> c) & 1ull) && (LI[l].fm & kLineConst))) ++kept;
+  // (four index words in flight per thread: the loop is a chain of one global load, two LDS reads, an LDS atomic and a store per observation)
+  for (int i0 = tid; i0 < M; i0 += 1024) {
+    uint32_t vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vv[u] = i0 + 256 * u < M ? ridx[i0 + 256 * u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 256 * u;
+      if (i >= M) break;
+      const uint32_t v = vv[u];
+      const int l = (int)(v & 0xffffu), c = (int)((v >> 16) & 0xffu);
+      const int s = line_pos[l];
+      const unsigned slot = atomicAdd(&fill[s], 1u);
+      const int cf = s_cam_cf[c];
+      const unsigned ck = cf >= 0 ? (unsigned)cf : (unsigned)(Cf + c);
+      okey[lptr[s] + slot] = ck << 24 | (unsigned)i;
+      if (!(((constset >> c) & 1ull) && (LI[l].fm & kLineConst))) ++kept;
+    }
   }
   if (kept) atomicAdd(&s_nkept, kept);
   __syncthreads();
@@ -880,16 +889,28 @@ __global__ __launch_bounds__(256) void k_build_layout(BuildPtrs P, LayoutArgs a)
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Tiles of one window, thread <-> tile: what lba_pack.cpp:410-505 does per tile - lane map, skew flags, line descriptors, pair items.
-__global__ __launch_bounds__(256) void k_build_tiles(BuildPtrs P, const int* cam_cf) {
+// stage_m >= the window's observation count: the per-line and per-observation inputs of the tile loop are first brought into LDS in bulk
+// (coalesced, every thread with several loads in flight) - the loop itself is a chain of dependent reads (line pointer -> camera of the
+// observation -> free index of the camera -> seen counter), each a global round trip when read in place: 0.36 ms per batch, all of it latency.
+__global__ __launch_bounds__(256) void k_build_tiles(BuildPtrs P, const int* cam_cf, int stage_m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tiles_smem[];
   const int w = blockIdx.x, tid = threadIdx.x;
   const WinDesc wd = P.wins[w];
   const int L = wd.L, nt = wd.ntiles, grouping = P.grouping;
   if (nt <= 0 || L <= 0) return;
+#define TILE_STAMP(i) do { if (P.dbg && w == 0 && tid == 0) P.dbg[i] = (unsigned long long)wall_clock64(); } while (0)
+  TILE_STAMP(10);
   unsigned* F = reinterpret_cast<unsigned*>(tiles_smem);                 // [L] tile-start flags -> tile of each line; then [nt + 1] items per tile
   unsigned* part = F + (L > nt + 1 ? L : nt + 1);                        // [257]
   unsigned* tbeg = part + 260;                                           // [nt + 1] first sorted line of each tile
   unsigned char* seen_all = reinterpret_cast<unsigned char*>(tbeg + nt + 2);     // [256][4 * kMaxFreeCams]
+  const bool staged = stage_m >= wd.M;
+  unsigned* lp = reinterpret_cast<unsigned*>(seen_all);                          // staged (no seen block: the parities live in registers): [L + 1] line pointers relative to the window
+  unsigned* fm = lp + L + 1;                                                     // [L] free-camera masks
+  unsigned* dl = grouping ? F : fm + L;                                          // [L] line descriptors (sorted per tile here, written out in bulk); grouped packing: no pair items, F is free
+  unsigned char* fl = reinterpret_cast<unsigned char*>(fm + L + (grouping ? 0 : L));     // [L] row-entry / tile-start flags (bits 0-1) | constant (bit 2)
+  signed char* cfb = reinterpret_cast<signed char*>(fl + ((L + 15) & ~15));      // [M] free index of every observation's camera, or -1
+  __shared__ signed char s_ccf[64];
   const uint8_t* lfl = P.lflags + wd.line_off;
   for (int s = tid; s < L; s += 256) F[s] = (lfl[s] & 2) ? 1u : 0u;
   __syncthreads();
@@ -912,7 +933,138 @@ __global__ __launch_bounds__(256) void k_build_tiles(BuildPtrs P, const int* cam
   __syncthreads();
   block_scan_excl(F, nt + 1, part);
   const int item_base = P.item_base[w];
+  TILE_STAMP(11);
   unsigned char* seen = seen_all + tid * (4 * kMaxFreeCams);
+  if (staged) {
+    if (tid < 64) s_ccf[tid] = tid < wd.C ? (signed char)ccf[tid] : (signed char)-1;
+    for (int s = tid; s < L; s += 256) {
+      lp[s] = (unsigned)(line_ptr[s] - wd.obs_off);
+      fm[s] = fmask[s];
+      fl[s] = (unsigned char)((lfl[s] & 3) | ((line_flags[s] & 1) << 2));
+    }
+    if (tid == 0) lp[L] = (unsigned)wd.M;
+    __syncthreads();
+    const int* oc = P.ob_cam + wd.obs_off;
+    for (int i0 = tid; i0 < wd.M; i0 += 1024) {
+      int c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = i0 + 256 * u < wd.M ? oc[i0 + 256 * u] : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (i0 + 256 * u < wd.M) cfb[i0 + 256 * u] = s_ccf[c[u] & 63];
+    }
+    __syncthreads();
+    TILE_STAMP(12);
+    for (int t = tid; t < nt; t += 256) {
+      const long long gt = (long long)wd.tile_off + t;
+      uint16_t* map = P.lane_map + 64 * gt;
+      unsigned sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0;                         // parity of the (row, free camera) counters: one word per row
+      const unsigned it0 = grouping ? 0u : F[t], it1 = grouping ? 0u : F[t + 1];
+      uint8_t* item_w = P.items + 2 * ((long long)item_base + it0);
+      const int s0 = (int)tbeg[t], s1 = (int)tbeg[t + 1];
+      // ONE pass over the tile's 64 lanes, the same trip count for every thread of a wave (a loop over lines with an inner loop over a
+      // line's lanes costs a wave the longest line times the most lines of its 64 tiles: 68 us for this loop against 13 in this form).
+      // Every lane position begins at most one line (a line takes at least one lane).
+      int lane = 0, nl = 0, min_lanes = 64, max_run = 1, multi = 0;
+      int s = s0, next_start = 0, end = 0, o0 = 0, k = 0;
+      for (int q8 = 0; q8 < 64; q8 += 8) {
+      unsigned pk[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+      for (int u8 = 0; u8 < 8; ++u8) {
+        const int q = q8 + u8;
+        if (s < s1 && q == next_start) {
+          // line s begins at lane q
+          const unsigned f = fl[s];
+          lane = q;
+          o0 = (int)lp[s]; k = (int)lp[s + 1] - o0;
+          const int run = k > 1 ? k : 1;
+          end = lane + run;
+          min_lanes = min(min_lanes, run);
+          max_run = max(max_run, min(run, 16));
+          if (run > 16) multi = 1;
+          const bool is_const = (f & 4) != 0;
+          const unsigned fms = fm[s];
+          if (!is_const && !grouping) {
+            const int kf = __popc(fms);                                  // free-camera observations come first, one per camera
+            for (int i2 = 0; i2 < kf; ++i2)
+              for (int j2 = i2 + 1; j2 < kf; ++j2) { *item_w++ = (uint8_t)(lane + i2); *item_w++ = (uint8_t)(lane + j2); }
+          }
+          const uint32_t m = is_const ? 0u : (fms & 0x3ffu);
+          uint32_t desc;
+          if (!grouping) {
+            bool blk[4] = { false, false, false, false };
+            for (int cf = 0; cf < 10; ++cf)
+              if ((m >> cf) & 1u) { blk[(6 * cf) / 16] = true; blk[(6 * cf + 5) / 16] = true; }
+            uint32_t touched = 0;
+            for (int I = 0, tt = 0; I < 4; ++I)
+              for (int J = 0; J <= I; ++J, ++tt) if (blk[I] && blk[J]) touched |= 1u << tt;
+            desc = m | ((uint32_t)lane << 10) | (touched << 16);
+          } else {
+            uint32_t a = 0, nblk = 0, wdt = 0, holes = 0;
+            if (m) {
+              a = (uint32_t)(__ffs((int)m) - 1);
+              wdt = (uint32_t)(31 - __clz((int)m)) - a + 1u;
+              nblk = (6u * wdt + 15u) / 16u;
+              holes = (uint32_t)__popc(m) != wdt ? 1u : 0u;
+            }
+            desc = gp_desc(m, (uint32_t)lane, a, nblk, holes, wdt);
+          }
+          dl[s] = desc;
+          ++s; ++nl;
+          next_start = s < s1 ? ((fl[s] & 1) ? (end + 15) & ~15 : end) : 64;      // every row entry starts a row
+        }
+        unsigned v = 0x00FFu;                                            // (a lane no line uses)
+        if (q < end) {
+          // lane map with the skew flag (bit 15): every second lane of a 16-lane row that holds an observation of the same free camera
+          const int j2 = q - lane;
+          v = (unsigned)((nl - 1) | (j2 << 8));
+          if (j2 < k) {
+            const int cf = cfb[o0 + j2];
+            if (cf >= 0) {
+              const int row = q >> 4;
+              const unsigned bit = 1u << cf, cur = row == 0 ? sb0 : row == 1 ? sb1 : row == 2 ? sb2 : sb3;
+              if (cur & bit) v |= 0x8000u;
+              if (row == 0) sb0 ^= bit; else if (row == 1) sb1 ^= bit; else if (row == 2) sb2 ^= bit; else sb3 ^= bit;
+            }
+          }
+        }
+        pk[u8 >> 1] |= (v & 0xffffu) << (16 * (u8 & 1));
+      }
+      // (eight lanes per store: 2-byte stores scattered over a wave's 64 tiles were the whole cost of this loop)
+      reinterpret_cast<uint4*>(map)[q8 >> 3] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      }
+      const int rounds_log2 = min_lanes >= 4 ? 0 : min_lanes >= 2 ? 1 : 2;
+      Tile tl;
+      tl.line_begin = wd.line_off + s0; tl.nlines = (int16_t)nl;
+      tl.flags = (int16_t)(multi | (rounds_log2 << 1) | (max_run << 3));
+      tl.item_off = item_base + (int)it0; tl.nitems = (int)(it1 - it0);
+      P.tiles[gt] = tl;
+    }
+    __syncthreads();
+    if (grouping) {
+      // the grouped sweep walks a tile's descriptors group after group, inside a group by the number of blocks, lines without elimination
+      // work last (a STABLE sort, lba_pack.cpp:484-496): wave <-> tile, lane <-> line; rank = keys below + equal keys before.  (One thread
+      // per tile with an insertion sort cost a wave its slowest tile: 64 short lines, ~1000 dependent LDS steps - most of this kernel.)
+      const int wv = tid >> 6, ln = tid & 63;
+      for (int t = wv; t < nt; t += 4) {
+        const int s0 = (int)tbeg[t], n = (int)tbeg[t + 1] - s0;
+        const unsigned v = ln < n ? dl[s0 + ln] : 0u;
+        const int key = ln < n ? (gp_mask(v) ? (int)(gp_group(v) * 8u + gp_blocks(v)) : 1 << 20) : 0x7fffffff;
+        const int nxt = __shfl_down(key, 1);
+        if (__ballot(ln + 1 < n && key > nxt) == 0ull) continue;         // in order already
+        int rank = 0;
+        for (int u = 0; u < n; ++u) {
+          const int ku = __builtin_amdgcn_readlane(key, u);
+          rank += (ku < key || (ku == key && u < ln)) ? 1 : 0;
+        }
+        if (ln < n) dl[s0 + rank] = v;
+      }
+      __syncthreads();
+    }
+    TILE_STAMP(13);
+    for (int s = tid; s < L; s += 256) P.line_desc[wd.line_off + s] = dl[s];
+    TILE_STAMP(14);
+    return;
+  }
   for (int t = tid; t < nt; t += 256) {
     const long long gt = (long long)wd.tile_off + t;
     uint16_t* map = P.lane_map + 64 * gt;
@@ -990,9 +1142,12 @@ __global__ __launch_bounds__(256) void k_build_tiles(BuildPtrs P, const int* cam
     P.tiles[gt] = tl;
   }
 }
-__host__ __device__ inline size_t build_tiles_lds_bytes(int L, int ntiles_max) {
+#undef TILE_STAMP
+__host__ __device__ inline size_t build_tiles_lds_bytes(int L, int ntiles_max, int stage_m = -1, int grouping = 0) {
   const size_t a = (size_t)(L > ntiles_max + 1 ? L : ntiles_max + 1);
-  return 4 * a + 4 * 260 + 4 * ((size_t)ntiles_max + 2) + 256 * 4 * kMaxFreeCams + 64;
+  const size_t n = 4 * a + 4 * 260 + 4 * ((size_t)ntiles_max + 2) + 64;
+  if (stage_m >= 0) return n + 4 * ((size_t)L + 1) + (grouping ? 4 : 8) * (size_t)L + (((size_t)L + 15) & ~(size_t)15) + (((size_t)stage_m + 15) & ~(size_t)15) + 64;
+  return n + 256 * 4 * kMaxFreeCams;
 }
 
 }  // namespace slslam

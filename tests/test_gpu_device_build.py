@@ -68,6 +68,20 @@ def test_device_build_reproduces_the_packer_digest(hip, host_math):
     assert seen == len(gold) == 12
 
 
+def test_build_tiles_without_lds_staging(hip, host_math, monkeypatch):
+    """k_build_tiles keeps the tile loop's inputs in LDS when a window's observations fit; the form that reads them in place (windows
+    beyond that) is the same bytes: part of the digest family and a scrambled window through SLSLAM_BUILD_TILES_UNSTAGED."""
+    monkeypatch.setenv("SLSLAM_BUILD_TILES_UNSTAGED", "1")
+    mod = _digest_module()
+    gold = json.load(open(os.path.join(HERE, "golden", "packer_digest.json")))
+    for name, w in list(mod.family().items())[:3]:
+        for g in (0, 1):
+            D = _compare(hip, host_math, w, g, name)
+            assert mod.digest(D) == gold["%s/grouping%d" % (name, g)]["crc32"], (name, g)
+    for g in (0, 1):
+        _compare(hip, host_math, _scrambled(58, num_lines=300), g, "scrambled58")
+
+
 def test_device_build_equals_host_packer_on_varied_windows(hip, host_math):
     """Shapes the digest family does not hold: few and many lines, every track length (long lines take whole rows, short ones need several
     sin / cos rounds), lines nobody observes, constant cameras among the free ones, scrambled caller order, one camera, no observation."""

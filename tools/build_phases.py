@@ -24,3 +24,7 @@ for lines in (2000, 500):
         print("%d lines, grouping %d: %.1f us from the first stamp to the last (three kernels, launch gaps included), %d tiles" % (lines, g, tot / 100.0, D["ntiles"]))
         for n, c in zip(NAMES[:9], d):
             print("   %-44s %9.1f us  %5.1f %%" % (n, c / 100.0, 100.0 * c / max(1, tot)))
+        tt = clk[10:15].astype(np.int64)
+        if tt[4] > tt[0] > 0:
+            print("   k_build_tiles: prologue (tile starts, scans) %.1f us, inputs into LDS %.1f us, tile loop %.1f us, descriptors out %.1f us"
+                  % tuple((b - a) / 100.0 for a, b in zip(tt[:-1], tt[1:])))
