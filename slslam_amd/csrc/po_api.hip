@@ -221,6 +221,8 @@ hipError_t po_step_lds_attributes() {
 }
 }  // namespace
 
+namespace { thread_local int po_iter_hint = -1; }     // LM iterations the calling thread's previous pose-graph solve took
+
 extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_options* opt_in,
                                slslam_summary* summary, slslam_iteration* trace, int trace_cap, int* trace_len) {
   if (!g) return SLSLAM_ERR_INVALID_ARGUMENT;
@@ -311,6 +313,8 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   int num_cus = 0;
   int wide_resident = 0;             // workgroups of k_po_trisolve_wide the device keeps resident together (0: not known - the one-workgroup substitution runs)
   LMState hst;
+  int next_check = 8;
+  bool have_results = false;
   std::vector<IterRec> htrace(kMaxTrace);
   std::vector<double> x2((size_t)12 * N), ones((size_t)(n > 0 ? n : 1), 1.0);
   const size_t hbytes = (size_t)(n > 0 ? n : 1) * ld * sizeof(double);
@@ -400,11 +404,18 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   hipLaunchKernelGGL(k_po_linearise, g_edges, dim3(64), 0, 0, p, 0);
   hipLaunchKernelGGL(k_po_prepare, dim3(1), dim3(256), 0, 0, p, pol, 1);
   // ---- LM iterations, enqueued without host synchronisation; finished solves early-out on device
+  // An iteration enqueued behind a finished solve early-outs on the device, but its ~14 launches still cost ~45 us: the host asks the device
+  // whether it is done after one iteration more than this thread's PREVIOUS solve took steps (the terminating test runs at the head of the next one; consecutive pose graphs of a session are alike;
+  // 8 when there is no history), then every 4.  The answer replaces the wait at the end, it is not an extra one.
+  next_check = po_iter_hint >= 0 ? std::min(po_iter_hint + 1, 8) : 8;
   for (int it = 0; it < pol.max_num_iterations && n > 0; ++it) {
-    if (it > 0 && (it % 8) == 0) {      // long solves: stop enqueueing once the device reports termination
-      PO_TRY(hipMemcpyAsync(&hst, p.st, sizeof(hst), hipMemcpyDeviceToHost, 0));
+    if (it == next_check) {             // stop enqueueing once the device reports termination
+      // (state | trace | poses in one copy: when the solve has finished, this IS the download)
+      PO_TRY(hipMemcpyAsync(stage, arena, down_bytes, hipMemcpyDeviceToHost, 0));
       PO_TRY(hipStreamSynchronize(0));
-      if (hst.status != kRunning) break;
+      std::memcpy(&hst, stage + ((char*)p.st - arena), sizeof(hst));
+      if (hst.status != kRunning) { have_results = true; break; }
+      next_check += 4;
     }
     if (zero_small) hipLaunchKernelGGL(k_po_zero_structured, g_zero, dim3(256), 0, 0, p, n_l1);
     else {
@@ -456,7 +467,7 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
   }
   PO_TRY(hipGetLastError());
   if (timing && tev.size() >= 2) (void)hipEventRecord(tev[1], 0);
-  PO_TRY(hipDeviceSynchronize());
+  if (!have_results || timing) PO_TRY(hipDeviceSynchronize());
   if (timing) {
     PoTiming& T = g_po_timing;
     T.total_ms = 0; T.factor_ms = 0; T.factor_max_ms = 0; T.factor_calls = 0; T.unknowns = n; T.junction_unknowns = nj;
@@ -468,13 +479,14 @@ extern "C" int slslam_po_solve(const slslam_po_graph* g, const slslam_solver_opt
     tev.clear();
   }
   // state | trace | poses come back in ONE copy (they are the first bytes of the block)
-  PO_TRY(hipMemcpy(stage, arena, down_bytes, hipMemcpyDeviceToHost));
+  if (!have_results) PO_TRY(hipMemcpy(stage, arena, down_bytes, hipMemcpyDeviceToHost));
   std::memcpy(&hst, stage + ((char*)p.st - arena), sizeof(hst));
   std::memcpy(htrace.data(), stage + ((char*)p.trace - arena), sizeof(IterRec) * kMaxTrace);
   std::memcpy(x2.data(), stage + ((char*)p.x - arena), sizeof(double) * 12 * N);
   {
     int term = hst.status == kRunning ? SLSLAM_NO_CONVERGENCE : hst.status;
     if (n == 0) term = SLSLAM_FUNCTION_TOLERANCE;     // no non-constant parameter blocks
+    po_iter_hint = hst.n_success + hst.n_unsuccess;
     if (term != SLSLAM_NUMERICAL_FAILURE)
       std::memcpy(g->parameters, x2.data() + (size_t)hst.cur * 6 * N, sizeof(double) * 6 * N);
     if (summary) {
