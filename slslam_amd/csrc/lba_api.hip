@@ -1582,6 +1582,16 @@ unsigned long long copy_checked(double* dst, const double* src, size_t n) {
 // solves share the chip - measured 37 ms per batch against 20).
 // packed (optional): packed[i] != nullptr replaces window i's three index arrays by the narrowed form (slslam_pack_indices: one 32-bit word per
 // observation) - 68 instead of 80 bytes per observation over the host link.
+// the device block the copy engine fills (refill_device); the previous refill's kernels have read the old one: ev_stage_free / the results were waited for
+int ensure_stage_block(slslam_lba_batch* b, size_t bytes) {
+  if (bytes <= b->d_stage_bytes) return SLSLAM_OK;
+  if (b->d_stage_in) { (void)hipFree(b->d_stage_in); b->d_stage_in = nullptr; b->d_stage_bytes = 0; }
+  const size_t want = bytes + bytes / 8 + 4096;
+  HIP_TRY(hipMalloc((void**)&b->d_stage_in, want));
+  b->d_stage_bytes = want;
+  return SLSLAM_OK;
+}
+
 int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, hipStream_t s, hipStream_t s_in, const unsigned int* const* packed = nullptr) {
   if (b->opt.device_build < 0 || b->d_rawwin.n < (size_t)std::max(1, B) || !b->d_ob_raw.p) return SLSLAM_ERR_UNSUPPORTED;
   if (std::getenv("SLSLAM_CHUNK_WEIGHTS")) return SLSLAM_ERR_UNSUPPORTED;          // (an experiment knob of the host-side cut)
@@ -1645,6 +1655,8 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
   struct Run { uintptr_t lo, hi; size_t dev_off; };
   std::vector<Run> runs;
   size_t dev_need = 0;
+  int idx_run = -1;                   // the run that holds the indices the host threads narrow (copied after the others)
+  bool early_dma = false;             // the other runs are on their way already
   if (all_pinned) {
     for (int i = 0; i < B; ++i) {
       const slslam_lba_window& w = windows[i];
@@ -1675,6 +1687,45 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
         HIP_TRY(hipHostMalloc((void**)&b->h_raw_stage, want, hipHostMallocDefault));
         b->raw_stage_bytes = want;
       }
+    }
+    // the ranges the copy engine is to move: the callers' arrays and - a run of its own, never merged with a neighbour - the narrowed block
+    struct Rg { uintptr_t lo, hi; bool idx; };
+    std::vector<Rg> rg;
+    rg.reserve((size_t)5 * B + 1);
+    size_t payload = 0;
+    if (narrow) { rg.push_back({ (uintptr_t)b->h_raw_stage, (uintptr_t)b->h_raw_stage + 4 * (size_t)nobs, true }); payload += 4 * (size_t)nobs; }
+    for (int i = 0; i < B && !no_dma; ++i) {
+      const slslam_lba_window& w = windows[i];
+      const size_t M = (size_t)w.num_observations, np = (size_t)6 * w.num_cameras + (size_t)4 * w.num_lines;
+      const bool pk = packed && packed[i];
+      if (M && pk) rg.push_back({ (uintptr_t)packed[i], (uintptr_t)packed[i] + 4 * M, false });
+      if (M && !pk && !narrow) { rg.push_back({ (uintptr_t)w.camera_index, (uintptr_t)w.camera_index + 4 * M, false }); rg.push_back({ (uintptr_t)w.line_index, (uintptr_t)w.line_index + 4 * M, false });
+                                 rg.push_back({ (uintptr_t)w.fixed_index, (uintptr_t)w.fixed_index + 8 * M, false }); }
+      if (M) rg.push_back({ (uintptr_t)w.observations, (uintptr_t)w.observations + 64 * M, false });
+      if (np) rg.push_back({ (uintptr_t)w.parameters, (uintptr_t)w.parameters + 8 * np, false });
+      payload += (pk ? 68 : narrow ? 64 : 80) * M + 8 * np;
+    }
+    std::sort(rg.begin(), rg.end(), [](const Rg& x, const Rg& y) { return x.lo < y.lo; });
+    bool barrier = true;                                  // the next range starts a run whatever lies before it
+    for (const Rg& g : rg) {
+      if (g.idx) { idx_run = (int)runs.size(); runs.push_back(Run{ g.lo, g.hi, 0 }); barrier = true; continue; }
+      if (!barrier && g.lo <= runs.back().hi + 4096) runs.back().hi = std::max(runs.back().hi, g.hi);
+      else runs.push_back(Run{ g.lo, g.hi, 0 });
+      barrier = false;
+    }
+    for (Run& r : runs) { r.dev_off = dev_need + (r.lo & 255); dev_need += ((r.lo & 255) + (r.hi - r.lo) + 255) & ~(size_t)255; }     // (device address = host address modulo 256)
+    if (runs.size() > (size_t)std::max(8, B / 16) || dev_need > payload + payload / 8 + (1u << 20)) { runs.clear(); dev_need = 0; idx_run = -1; }     // scattered: zero copy
+    // The callers' arrays start up the link NOW, the host threads narrow the indices meanwhile: a submit's chain is
+    // max(narrowing, 0.87 GB of copies) + build, not their sum - with three batches in flight the sum (13 + 17 + 4 ms on a slow host thread)
+    // left 2 ms of slack against two solve periods, and a stream at the mercy of the host's jitter (0.70 of resident measured on such a box).
+    if (!runs.empty()) {
+      rc = ensure_stage_block(b, dev_need);
+      if (rc != SLSLAM_OK) return rc;
+      for (size_t k = 0; k < runs.size(); ++k)
+        if ((int)k != idx_run) HIP_TRY(hipMemcpyAsync(b->d_stage_in + runs[k].dev_off, (const void*)runs[k].lo, runs[k].hi - runs[k].lo, hipMemcpyHostToDevice, s_in));
+      early_dma = true;
+    }
+    if (narrow) {
       std::vector<int> st((size_t)B, SLSLAM_OK);
       HostPool* pool = batch_pool(b, (int)std::min<long long>(B, b->opt.host_threads > 0 ? b->opt.host_threads : (B >= 64 ? 8 : 1)));
       auto narrow_one = [&](int i) {
@@ -1695,32 +1746,13 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
         r.cam = nullptr; r.line = nullptr; r.fixed = nullptr; r.packed = ix;
         rw[i] = r;
       };
-      if (!run_all(pool, B, narrow_one)) return SLSLAM_ERR_NO_MEMORY;
-      for (int v : st) if (v != SLSLAM_OK) return v;
+      int bad = run_all(pool, B, narrow_one) ? SLSLAM_OK : SLSLAM_ERR_NO_MEMORY;
+      for (int v : st) if (bad == SLSLAM_OK && v != SLSLAM_OK) bad = v;
+      if (bad != SLSLAM_OK) {
+        if (early_dma) (void)hipStreamSynchronize(s_in);            // the copies under way read the callers' arrays: not beyond this call
+        return bad;
+      }
     }
-    struct Rg { uintptr_t lo, hi; };
-    std::vector<Rg> rg;
-    rg.reserve((size_t)5 * B);
-    size_t payload = 0;
-    if (narrow) { rg.push_back({ (uintptr_t)b->h_raw_stage, (uintptr_t)b->h_raw_stage + 4 * (size_t)nobs }); payload += 4 * (size_t)nobs; }
-    for (int i = 0; i < B && !no_dma; ++i) {
-      const slslam_lba_window& w = windows[i];
-      const size_t M = (size_t)w.num_observations, np = (size_t)6 * w.num_cameras + (size_t)4 * w.num_lines;
-      const bool pk = packed && packed[i];
-      if (M && pk) rg.push_back({ (uintptr_t)packed[i], (uintptr_t)packed[i] + 4 * M });
-      if (M && !pk && !narrow) { rg.push_back({ (uintptr_t)w.camera_index, (uintptr_t)w.camera_index + 4 * M }); rg.push_back({ (uintptr_t)w.line_index, (uintptr_t)w.line_index + 4 * M });
-                                 rg.push_back({ (uintptr_t)w.fixed_index, (uintptr_t)w.fixed_index + 8 * M }); }
-      if (M) rg.push_back({ (uintptr_t)w.observations, (uintptr_t)w.observations + 64 * M });
-      if (np) rg.push_back({ (uintptr_t)w.parameters, (uintptr_t)w.parameters + 8 * np });
-      payload += (pk ? 68 : narrow ? 64 : 80) * M + 8 * np;
-    }
-    std::sort(rg.begin(), rg.end(), [](const Rg& x, const Rg& y) { return x.lo < y.lo; });
-    for (const Rg& g : rg) {
-      if (!runs.empty() && g.lo <= runs.back().hi + 4096) runs.back().hi = std::max(runs.back().hi, g.hi);
-      else runs.push_back(Run{ g.lo, g.hi, 0 });
-    }
-    for (Run& r : runs) { r.dev_off = dev_need + (r.lo & 255); dev_need += ((r.lo & 255) + (r.hi - r.lo) + 255) & ~(size_t)255; }     // (device address = host address modulo 256)
-    if (runs.size() > (size_t)std::max(8, B / 16) || dev_need > payload + payload / 8 + (1u << 20)) { runs.clear(); dev_need = 0; }     // scattered: zero copy
   } else {
     // staging: per window [observations 64 M | narrowed indices 4 M | parameters], 64-byte aligned pieces
     std::vector<size_t> st_off((size_t)B + 1, 0);
@@ -1767,13 +1799,8 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
     if (st_off[(size_t)B] > 0) { runs.push_back(Run{ (uintptr_t)b->h_raw_stage, (uintptr_t)b->h_raw_stage + st_off[(size_t)B], 0 }); dev_need = (st_off[(size_t)B] + 255) & ~(size_t)255; }
   }
   if (!runs.empty()) {
-    if (dev_need > b->d_stage_bytes) {
-      // (the previous refill's ingest has read the old block: ev_stage_free was waited for above)
-      if (b->d_stage_in) { (void)hipFree(b->d_stage_in); b->d_stage_in = nullptr; b->d_stage_bytes = 0; }
-      const size_t want = dev_need + dev_need / 8 + 4096;
-      HIP_TRY(hipMalloc((void**)&b->d_stage_in, want));
-      b->d_stage_bytes = want;
-    }
+    rc = ensure_stage_block(b, dev_need);
+    if (rc != SLSLAM_OK) return rc;
     // the device reads every array at its place in the block
     auto to_dev = [&](const void* p) -> const void* {
       if (!p) return nullptr;
@@ -1857,7 +1884,8 @@ int refill_device(slslam_lba_batch* b, const slslam_lba_window* windows, int B, 
   HIP_TRY(hipMemcpyAsync(b->d_rawwin.p, rw, sizeof(RawWin) * (size_t)B, hipMemcpyHostToDevice, s_in));
   HIP_TRY(hipMemsetAsync(b->d_buildwin.p, 0, sizeof(BuildWin) * (size_t)B, s_in));
   static const int ingest_wgs = std::getenv("SLSLAM_INGEST_WORKGROUPS") ? std::max(1, std::atoi(std::getenv("SLSLAM_INGEST_WORKGROUPS"))) : 32;
-  for (const Run& r : runs) HIP_TRY(hipMemcpyAsync(b->d_stage_in + r.dev_off, (const void*)r.lo, r.hi - r.lo, hipMemcpyHostToDevice, s_in));
+  for (size_t k = 0; k < runs.size(); ++k)
+    if (!early_dma || (int)k == idx_run) HIP_TRY(hipMemcpyAsync(b->d_stage_in + runs[k].dev_off, (const void*)runs[k].lo, runs[k].hi - runs[k].lo, hipMemcpyHostToDevice, s_in));
   // zero copy: the ingest kernel IS the transfer (32 workgroups keep the link full: tools/micro/zero_copy_bench.hip; more only queue in the L2)
   if (B > 0 && runs.empty()) hipLaunchKernelGGL(k_ingest, dim3((unsigned)std::min(B, ingest_wgs)), dim3(256), 0, s_in, P);
   if (!b->ev_stage_free) HIP_TRY(hipEventCreateWithFlags(&b->ev_stage_free, hipEventDisableTiming));
