@@ -318,10 +318,11 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
       "pageable" ordinary arrays: the host threads copy them into a pinned staging buffer (indices narrowed on the way), the device builds;
       "host"     the round-5 path (device_build = -1): packing on the host threads, pinned image, upload, download, copy-out.
     Every batch is a set of host arrays over the rank's windows, rotated so that every batch is laid out differently (the read-only input
-    arrays are shared between the sets, every set has parameter arrays of its own); the first depth + 1 submits (batch builds, graph
-    capture, pinned allocations) are warm-up.  Never the headline `value`: it measures the host, the host link and the GPU together."""
+    arrays are shared between the sets, every set has parameter arrays of its own); the first 2 x depth submits (batch builds, graph
+    capture, every slot's first refill with its staging allocations) are warm-up.  Never the headline `value`: it measures the host, the host link and the GPU together."""
     B = len(windows)
-    nsets = depth + 1 + batches_timed
+    warm = 2 * depth                 # every slot is built once and REFILLED once before the clock starts (a slot's first refill allocates its staging blocks)
+    nsets = warm + batches_timed
     base = capi.WindowSet(windows, pinned=(mode in ("pinned", "packed")), packed=(mode == "packed"))
     sets = []
     for k in range(nsets):
@@ -331,11 +332,11 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
         opt = dict(opt, device_build=-1)
     st = capi.LBAStream(device=device, depth=depth, host_threads=host_threads, **opt)
     tick = []
-    for k in range(depth + 1):                      # warm-up: builds the slots' batches, then one refill
+    for k in range(warm):                           # warm-up: builds the slots' batches, then one refill of each
         if k >= depth:
             st.collect(tick[k - depth], want_summaries=False)
         tick.append(st.submit(sets[k]))
-    for k in range(1, depth + 1):
+    for k in range(warm - depth, warm):
         st.collect(tick[k], want_summaries=False)
     s0, b0 = st.stats(), st.build_stats()
     torch.cuda.synchronize()
@@ -345,7 +346,7 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
         marks.append(time.perf_counter())           # a batch PERIOD: collect of the batch `depth` back + submit of this one
         if k >= depth:
             st.collect(tick[k - depth], want_summaries=False)
-        tick.append(st.submit(sets[depth + 1 + k]))
+        tick.append(st.submit(sets[warm + k]))
     marks.append(time.perf_counter())
     for k in range(max(0, batches_timed - depth), batches_timed):
         st.collect(tick[k], want_summaries=False)
@@ -357,7 +358,7 @@ def streamed_block(windows, device, resident_value, resident_params, batches_tim
     nwin = s1["windows"] - s0["windows"]
     # the streamed results are the resident batch's results, byte for byte (same windows, same sweep, same cut)
     equal, checked = True, 0
-    k = depth + 1 + batches_timed - 1
+    k = warm + batches_timed - 1
     r = (k * 37) % B
     for j in (0, 1, B // 2, B - 1):
         i = (j + r) % B                              # window i of the rank sits at position j of set k

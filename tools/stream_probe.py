@@ -25,16 +25,17 @@ def main():
     args = ap.parse_args()
     B = args.windows
     windows = [synth.make_window(i, num_lines=args.lines) for i in range(B)]
-    nsets = args.depth + 1 + args.batches
+    warm = 2 * args.depth
+    nsets = warm + args.batches
     base = capi.WindowSet(windows, pinned=(args.mode in ("pinned", "packed")), packed=(args.mode == "packed"))
     sets = [base.derive(list(range((k * 37) % B, B)) + list(range((k * 37) % B))) for k in range(nsets)]
     st = capi.LBAStream(depth=args.depth, host_threads=args.host_threads, **({"device_build": -1} if args.mode == "host" else {}))
     tick = []
-    for k in range(args.depth + 1):
+    for k in range(warm):                # every slot built once and refilled once (a slot's first refill allocates its staging blocks)
         if k >= args.depth:
             st.collect(tick[k - args.depth], want_summaries=False)
         tick.append(st.submit(sets[k]))
-    for k in range(1, args.depth + 1):
+    for k in range(warm - args.depth, warm):
         st.collect(tick[k], want_summaries=False)
     rows, tick = [], []
     t00 = time.perf_counter()
@@ -42,7 +43,7 @@ def main():
         tw = 0.0
         if k >= args.depth:
             a = time.perf_counter(); st.collect(tick[k - args.depth], want_summaries=False); tw = time.perf_counter() - a
-        a = time.perf_counter(); tick.append(st.submit(sets[args.depth + 1 + k])); ts = time.perf_counter() - a
+        a = time.perf_counter(); tick.append(st.submit(sets[warm + k])); ts = time.perf_counter() - a
         rows.append((k, 1e3 * tw, 1e3 * ts))
     for k in range(max(0, args.batches - args.depth), args.batches):
         a = time.perf_counter(); st.collect(tick[k], want_summaries=False); rows.append((k, 1e3 * (time.perf_counter() - a), 0.0))
