@@ -2588,9 +2588,50 @@ extern "C" int slslam_lba_stream_collect(slslam_lba_stream* st, int ticket, slsl
   // that solved it: the top-level batch of such a slot holds no LM states of its own)
   std::vector<int> steps((size_t)sl.n, 0);
   slslam_lba_batch* bt = sl.batch;
-  const bool dev = bt->device_built && !bt->part[0];
+  bool dev = bt->device_built && !bt->part[0];
   std::vector<int> flagged;
   if (dev) for (int i = 0; i < sl.n; ++i) if (bt->build_status[(size_t)i] != SLSLAM_OK) flagged.push_back(i);
+  // A refill that did not fit the room the slot's arrays have (only the device knows the tiles a set needs: k_build_layout flags the refill as
+  // a whole) is what submit answers with a new batch when the HOST can see it: the same here, late - the set is packed by the host threads into
+  // a batch of its own size (plus the stream's headroom), solved as ONE batch, and that batch takes the slot, so that the sets that follow fit.
+  // (Solving 1024 flagged windows one by one would take a second, and the next set of that shape would be flagged again.)
+  bool whole_nofit = dev && sl.n > 0 && (int)flagged.size() == sl.n && bt->h_buildwin && (int)bt->src_windows.size() == sl.n;
+  for (int i = 0; whole_nofit && i < sl.n; ++i) if (!(bt->h_buildwin[i].status & kBuildNoFit)) whole_nofit = false;
+  if (whole_nofit) {
+    const int n = sl.n;
+    std::vector<slslam_lba_window> ws(bt->src_windows);
+    std::vector<std::vector<int>> idx((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      const RawWin& r = bt->host_src[(size_t)i];
+      ws[(size_t)i].parameters = sl.out_params[(size_t)i];
+      if (ws[(size_t)i].num_observations > 0 && (!ws[(size_t)i].camera_index || !ws[(size_t)i].line_index || !ws[(size_t)i].fixed_index)) {
+        if (!r.packed) return SLSLAM_ERR_STATE;
+        const size_t M = (size_t)r.M;
+        std::vector<int>& v = idx[(size_t)i];
+        v.resize(4 * M);
+        for (size_t q = 0; q < M; ++q) { const uint32_t x = r.packed[q]; v[q] = (int)((x >> 16) & 0xffu); v[M + q] = (int)(x & 0xffffu); v[2 * M + 2 * q] = (int)((x >> 24) & 1u); v[2 * M + 2 * q + 1] = (int)((x >> 25) & 1u); }
+        ws[(size_t)i].camera_index = v.data(); ws[(size_t)i].line_index = v.data() + M; ws[(size_t)i].fixed_index = v.data() + 2 * M;
+      }
+    }
+    slslam_lba_batch* nb = nullptr;
+    if ((rc = slslam_lba_batch_create(st->device, &nb)) != SLSLAM_OK) return rc;
+    nb->ext_pool = st->pool.get();
+    nb->wins.resize((size_t)n);
+    std::vector<int> ps((size_t)n, SLSLAM_OK);
+    if (!st->pool->run(n, [&](int i) { ps[(size_t)i] = pack_window(&ws[(size_t)i], &nb->wins[(size_t)i]); })) rc = SLSLAM_ERR_NO_MEMORY;
+    for (int r : ps) if (r != SLSLAM_OK) rc = r;
+    if (rc == SLSLAM_OK) rc = slslam_lba_batch_finalize(nb, &st->opt);
+    if (rc == SLSLAM_OK) rc = slslam_lba_batch_solve(nb, (void*)st->solve_stream);
+    if (rc == SLSLAM_OK) rc = download_async_impl(nb, (void*)st->solve_stream, /*allow_inplace=*/false);
+    if (rc == SLSLAM_OK) rc = slslam_lba_batch_wait(nb);
+    if (rc != SLSLAM_OK) { nb->ext_pool = nullptr; slslam_lba_batch_destroy(nb); return rc; }
+    if (sl.stream) HIP_TRY(hipStreamSynchronize(sl.stream));
+    HIP_TRY(hipStreamSynchronize(st->solve_stream)); HIP_TRY(hipStreamSynchronize(st->build_stream)); HIP_TRY(hipStreamSynchronize(st->result_stream));
+    bt->ext_pool = nullptr; slslam_lba_batch_destroy(bt);
+    sl.batch = bt = nb;
+    ++st->n_builds; st->n_fallback_windows += n;
+    dev = false; flagged.clear();
+  }
   auto one = [&](int i) {
     if (dev && bt->build_status[(size_t)i] != SLSLAM_OK) return;                 // below
     int r = SLSLAM_OK;

@@ -260,6 +260,33 @@ def test_stream_hands_flagged_windows_to_the_host_path(hip, oracle):
         wb.close()
 
 
+@pytest.mark.parametrize("mode", ["pageable", "pinned", "packed"])
+def test_stream_rebuilds_a_slot_whose_refill_did_not_fit(hip, mode):
+    """Only the device knows how many tiles a set needs.  A set with fewer lines and observations than the slot was built for, but long
+    tracks (a line of twenty observations takes two rows of 16 lanes, four short ones share one), passes the host's size tests and is flagged by k_build_layout as a whole:
+    collect packs it on the host threads into a batch of its own, solves it as ONE batch - what a fresh batch of the set returns, to the
+    byte - and that batch takes the slot, so that the next set of the shape is built on the device."""
+    per = 40
+    sets = [[synth.make_window(7700 + i, num_lines=300, num_kf=40, num_free=10, mean_track=5.0) for i in range(per)]]      # 28.9 k observations, 494 tiles per 24 windows
+    for k in (1, 2):
+        sets.append([synth.make_window(7800 + 100 * k + i, num_lines=60, num_kf=40, num_free=10, mean_track=36.0) for i in range(per)])     # 24.7 k, 568
+    assert sum(len(w["camera_index"]) for w in sets[1]) < sum(len(w["camera_index"]) for w in sets[0])
+    st = hip.LBAStream(depth=1, host_threads=2, refill_headroom_percent=5)     # (set 1 needs 15 % more tiles than set 0, set 2 4 % more pair items than set 1)
+    wsets = [hip.WindowSet(s, pinned=mode != "pageable", packed=mode == "packed") for s in sets]
+    res = [st.collect(st.submit(ws)) for ws in wsets]
+    ss, bs = st.stats(), st.build_stats()
+    assert ss["builds"] == 2 and ss["refills"] == 2, ss                     # set 1: refill accepted by the host, rebuilt at collect; set 2: a refill that fits
+    assert bs["device_builds"] == 2 and bs["fallback_windows"] == per, bs
+    for k in range(3):
+        fresh, _ = _solve_fresh(hip, sets[k])
+        for j in range(per):
+            assert np.array_equal(wsets[k].parameters(j), fresh[j][0]), (mode, k, j)
+            assert res[k][j] == fresh[j][1]
+    st.close()
+    for ws in wsets:
+        ws.close()
+
+
 def test_stream_with_narrowed_indices(hip):
     """slslam_lba_stream_submit_packed: the caller hands the three index arrays of every window narrowed to one 32-bit word per observation
     (slslam_pack_indices) - from page-locked memory (read in place) and from ordinary memory (staging copy).  Same bytes as fresh batches;

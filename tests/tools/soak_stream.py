@@ -2,7 +2,7 @@
 random window shapes - other free-camera counts, track lengths, line counts, constant lines, scrambled observation order from one batch to the
 next, so that refills reuse arrays that held something else and some batches do not fit and are rebuilt - with slslam_solver_options.reproducible = 1,
 under which a window's bytes are a function of the window alone: every streamed window must equal the same window solved alone, bit for bit, and
-a sample of them is held against the CPU oracle (checker).   python tests/tools/soak_stream.py [batches] [windows per batch] [seed] [lba_elimination 0 | 4]"""
+a sample of them is held against the CPU oracle (checker).   python tests/tools/soak_stream.py [batches] [windows per batch] [seed] [lba_elimination 0 | 4] [arrays: 0 pageable | 1 page-locked | 2 page-locked, indices narrowed by the caller]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -15,6 +15,7 @@ per = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 1)
 ELIM = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 max_free = 10 if ELIM == 4 else 20
+ARR = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 
 
 def random_window():
@@ -37,7 +38,7 @@ def random_window():
 t0 = time.time()
 sets = [[random_window() for _ in range(per)] for _ in range(nb)]
 st = capi.LBAStream(depth=3, host_threads=4, reproducible=1, lba_elimination=ELIM)
-wsets = [capi.WindowSet(s) for s in sets]
+wsets = [capi.WindowSet(s, pinned=ARR >= 1, packed=ARR == 2) for s in sets]
 tickets, summaries = [], {}
 for k in range(nb):
     if k >= 3:
@@ -46,6 +47,7 @@ for k in range(nb):
 for k in range(max(0, nb - 3), nb):
     summaries[k] = st.collect(tickets[k])
 stats = st.stats()
+bstats = st.build_stats()
 st.close()
 diff = bad = checked = 0
 for k in range(nb):
@@ -64,4 +66,5 @@ for k in range(nb):
                 print("ORACLE batch %d window %d: %s, final cost rel. diff %.2e, max |dx| %.2e" % (k, i, hard, rel, np.abs(xo - x).max()))
 print("streamed %d batches x %d random windows (lba_elimination %d, reproducible): %d differ from their solo solve; %d of %d sampled windows off the oracle; builds %d, refills %d; %.1f s" % (
     nb, per, ELIM, diff, bad, checked, stats["builds"], stats["refills"], time.time() - t0))
+print("   arrays: %s; %s" % (("pageable", "page-locked", "page-locked, indices narrowed by the caller")[ARR], bstats))
 sys.exit(1 if (diff or bad) else 0)
