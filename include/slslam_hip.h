@@ -322,7 +322,9 @@ int  slslam_lba_stream_stats(const slslam_lba_stream* s, double* ms_submit, doub
 /* Of the refills: how many were built on the device, how many of those read the callers' page-locked observations and parameters in place (no
  * staging copy; the index arrays are narrowed by the host threads on the way); windows the
  * device build handed back to the host path at collect time (a camera that sees a line twice, a line with more than 64 observations, more
- * than 20 free cameras, no room in the slot's arrays).  Any pointer may be NULL. */
+ * than 20 free cameras, no room in the slot's arrays).  A set that does not fit the slot AS A WHOLE (only the device knows the tiles it needs) is
+ * packed by the host threads at collect time, solved as one batch that then takes the slot - its windows count here and as one `builds`.
+ * Any pointer may be NULL. */
 int  slslam_lba_stream_build_stats(const slslam_lba_stream* s, long long* device_builds, long long* zero_copy, long long* fallback_windows);
 /* The batch that served `ticket` (valid until its slot is submitted to again; after collect: its traces, chunk cuts and sweep can be read
  * with the slslam_lba_batch_* getters).  Read only. */
