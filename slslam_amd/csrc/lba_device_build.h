@@ -6,18 +6,19 @@
 // STREAM of windows (BASELINE config 4) that host work bounded the product (17.5 ms of packing on 16 host threads per 1024-window batch
 // against 15 ms of GPU).  Here the same build runs as four kernels on the arrays as the caller holds them:
 //
-//   k_ingest        few workgroups read the callers' arrays straight from PINNED host memory (zero copy, 57 GB/s with 32 workgroups:
-//                   tools/micro/zero_copy_bench.hip) - observations with the NaN / Inf test, the three index arrays narrowed to one
-//                   32-bit word per observation with the range test, cameras and lines
+//   k_ingest        reads the callers' arrays where the copy engine put them in HBM (or, scattered page-locked arrays: few workgroups read
+//                   them straight from PINNED host memory, 57 GB/s with 32 workgroups, tools/micro/zero_copy_bench.hip) - observations with the
+//                   NaN / Inf test, the index arrays narrowed to one 32-bit word per observation with the range test, cameras and lines
 //   k_build_lines   one workgroup per window: counting, constness, free-camera masks, the counting sort as a bitonic sort of
 //                   (cell | line) keys
-//   k_build_rows    ONE WAVE per window (four windows to a CU): the best-fit packing of lines into rows - inherently sequential: the wave
-//                   walks the lines, the 17 open-row lists live one per lane (ballots pick the list, the rows of a list are chained
-//                   through LDS)
+//   k_build_rows    TWO WAVES per window, one per length class (four windows to a CU): the best-fit packing of lines into rows - inherently
+//                   sequential: a wave walks its lines, the 17 open-row lists live one per lane (ballots pick the list, the rows of a list
+//                   are chained through LDS)
 //   k_build_order   one workgroup per window: row order, line order, line pointers, the stable sort of every line's observations by camera
 //   k_build_layout  one workgroup: prefix sums over the windows, the (graded) chunk cuts and the dispatch order of plan_layout, the
 //                   fit test against the room the batch's arrays have
-//   k_build_tiles   thread <-> tile: lane map, skew flags, line descriptors (sorted per tile for the grouped sweep), pair items
+//   k_build_tiles   thread <-> tile over inputs staged in LDS, then wave <-> tile for the stable descriptor sort: lane map, skew flags,
+//                   line descriptors (sorted per tile for the grouped sweep), pair items
 //
 // The host packer stays the SPECIFICATION: tests/test_gpu_device_build.py compares every array this file emits with pack_window's,
 // byte for byte (tests/golden/packer_digest.json included), so a window's solved bytes do not depend on who built it.
