@@ -395,3 +395,37 @@ def test_a_window_that_fails_numerically_keeps_its_parameters(hip, oracle):
         st.close()
         for ws in wsets:
             ws.close()
+
+
+@pytest.mark.parametrize("free,kf", [(5, 10), (20, 40)])
+def test_stream_at_the_reference_window_sizes(hip, oracle, free, kf):
+    """The reference's study runs windows of W = 5 ... 40 keyframes; the bench streams W = 10.  Sets of W = 5 and W = 20 windows
+    (free cameras = W, as many constant ones beside them: src/slam.cpp:805-830) through a depth-2 stream of page-locked arrays, built on the
+    device from the second round on: every window equal to the byte to the same window in a fresh batch of its set, two of them against the
+    oracle (same steps, final cost 1e-7 relative, parameters 1e-5)."""
+    per = 8
+    sets = [[synth.make_window(9600 + 100 * free + 10 * k + i, num_lines=150 + 25 * i, num_kf=kf, num_free=free, mean_track=0.6 * kf) for i in range(per)]
+            for k in range(5)]
+    st = hip.LBAStream(depth=2, host_threads=2)
+    wsets = [hip.WindowSet(s, pinned=True) for s in sets]
+    tickets, res = [], {}
+    for k in range(5):
+        if k >= 2:
+            res[k - 2] = st.collect(tickets[k - 2])
+        tickets.append(st.submit(wsets[k]))
+    for k in (3, 4):
+        res[k] = st.collect(tickets[k])
+    bs = st.build_stats()
+    assert bs["device_builds"] == 3 and bs["fallback_windows"] == 0, bs
+    for k in range(5):
+        fresh, _, _ = _solve_fresh(hip, sets[k])
+        for j in range(per):
+            assert np.array_equal(wsets[k].parameters(j), fresh[j][0]), (free, k, j)
+            assert res[k][j] == fresh[j][1]
+    for k, j in ((2, 1), (4, 6)):
+        xo, so, _ = oracle.lba_solve(sets[k][j], linear_solver=1)
+        assert so["num_successful_steps"] == res[k][j]["num_successful_steps"] and so["num_unsuccessful_steps"] == res[k][j]["num_unsuccessful_steps"]
+        assert abs(so["final_cost"] - res[k][j]["final_cost"]) <= 1e-7 * so["final_cost"] and np.abs(xo - wsets[k].parameters(j)).max() < 1e-5
+    st.close()
+    for ws in wsets:
+        ws.close()
